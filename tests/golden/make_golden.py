@@ -1,0 +1,388 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (makgyver/rectorch)
+from /root/reference in the build container.  The reference never travels to the GPU box; these
+small .npz files (inputs + expected outputs) and this script do.
+
+Run from the repo root:   python tests/golden/make_golden.py
+
+Vector ids follow SURVEY.md §8c (G1..G9).  RNG-dependent quantities (dropout mask, eps) are captured
+by seeded replay: `torch.manual_seed(s)` then `F.dropout(ones)` then `randn` reproduces exactly what
+`MultiVAE_net.forward` consumes (dropout first, then randn_like; reference nets.py:394-411,
+tests/test_nets.py:56-74).
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True          # keep /root/reference pristine
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tools", "ref_standins"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import tempfile                          # noqa: E402
+import numpy as np                       # noqa: E402
+import torch                             # noqa: E402
+import torch.nn.functional as F          # noqa: E402
+from scipy.sparse import csr_matrix      # noqa: E402
+
+from rectorch.nets import MultiVAE_net, MultiDAE_net            # noqa: E402
+from rectorch.models import MultiVAE, MultiDAE                  # noqa: E402
+from rectorch.samplers import DataSampler                       # noqa: E402
+from rectorch.evaluation import evaluate                        # noqa: E402
+from rectorch.metrics import Metrics                            # noqa: E402
+
+import importlib.util                    # noqa: E402
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+hashinit = _load("hashinit", "rectorch_amd/utils/hashinit.py")
+synth = _load("synth", "rectorch_amd/utils/synth.py")
+
+torch.set_num_threads(8)
+
+
+def sd_np(net):
+    return {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+
+
+def load_hash(net, enc_dims, dec_dims, variant, seed, bias_std=1.0):
+    sd = hashinit.hash_state_dict(enc_dims, dec_dims, variant, seed, bias_std)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd
+
+
+def replay_rng(seed, B, I, L, p):
+    """dropout keep-mask (uint8) and eps exactly as the reference's forward would draw them."""
+    torch.manual_seed(seed)
+    m = F.dropout(torch.ones(B, I), p, True)
+    eps = torch.randn(B, L) if L else None
+    return (m != 0).numpy().astype(np.uint8), (eps.numpy() if eps is not None else None)
+
+
+def small_x(B, I, seed):
+    rng = np.random.default_rng(seed)
+    x = (rng.random((B, I)) < 0.2).astype(np.float32)
+    x[1, :] = 0.0                       # all-zero row
+    x[2, :] = 0.0
+    x[2, 7] = 1.0                       # single-item row
+    return x
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def flat(prefix, d):
+    return {prefix + k.replace(".", "__"): v for k, v in d.items()}
+
+
+# ---------------------------------------------------------------- G1 / G7
+def g1_g7():
+    I, H, L, B = 64, 16, 8, 5
+    net = MultiVAE_net([L, H, I], dropout=0.5)
+    sd = load_hash(net, [I, H, L], [L, H, I], "vae", 11)
+    x = small_x(B, I, 3)
+    model = MultiVAE(net, beta=0.2, anneal_steps=0)
+    net.eval()
+    with torch.no_grad():
+        y, mu, logvar = net(torch.from_numpy(x))
+        loss = model.loss_function(y, torch.from_numpy(x), mu, logvar, 0.2)
+    pred, pmu, plv = model.predict(torch.from_numpy(x), remove_train=True)
+    pred_keep = model.predict(torch.from_numpy(x), remove_train=False)[0]
+    save("g1_mvae_fwd_eval_small", x=x, logits=y.numpy(), mu=mu.numpy(), logvar=logvar.numpy(),
+         loss=np.float32(loss.item()), beta=np.float32(0.2),
+         dims=np.array([I, H, L]), **flat("sd__", sd))
+    save("g7_predict_remove_train", x=x, pred=pred.numpy(), pred_keep=pred_keep.numpy(),
+         mu=pmu.numpy(), logvar=plv.numpy(), n_neg_inf=np.int64(np.isneginf(pred.numpy()).sum()),
+         dims=np.array([I, H, L]), **flat("sd__", sd))
+
+
+# ---------------------------------------------------------------- G2
+def train_steps_vae(name, enc_dims, dec_dims, B, xs, gts, beta, anneal_steps, p, seeds, hseed,
+                    lr=1e-3, extra=None):
+    I, L = enc_dims[0], enc_dims[-1]
+    net = MultiVAE_net(list(dec_dims), list(enc_dims), dropout=p)
+    sd0 = load_hash(net, enc_dims, dec_dims, "vae", hseed)
+    model = MultiVAE(net, beta=beta, anneal_steps=anneal_steps, learning_rate=lr)
+    out = dict(flat("sd0__", sd0))
+    names = [k for k, _ in net.named_parameters()]
+    for t, seed in enumerate(seeds):
+        x = torch.from_numpy(xs[t])
+        gt = None if gts is None else torch.from_numpy(gts[t])
+        mask, eps = replay_rng(seed, x.shape[0], I, L, p)
+        out["mask_%d" % t] = mask
+        out["eps_%d" % t] = eps
+        # gradients of this step (before the update) via a side computation with the same RNG
+        net.train()
+        torch.manual_seed(seed)
+        ab = min(beta, model.gradient_updates / anneal_steps) if anneal_steps > 0 else beta
+        y, mu, logvar = net(x)
+        l_side = model.loss_function(y, x if gt is None else gt, mu, logvar, ab)
+        grads = torch.autograd.grad(l_side, list(net.parameters()))
+        for n, g in zip(names, grads):
+            out["grad_%d__%s" % (t, n.replace(".", "__"))] = g.numpy().copy()
+        out["logits_%d" % t] = y.detach().numpy().copy()
+        out["mu_%d" % t] = mu.detach().numpy().copy()
+        out["logvar_%d" % t] = logvar.detach().numpy().copy()
+        out["anneal_beta_%d" % t] = np.float32(ab)
+        # the real step
+        torch.manual_seed(seed)
+        loss = model.train_batch(x, gt)
+        assert abs(loss - l_side.item()) <= 1e-6 * max(1.0, abs(loss)), (loss, l_side.item())
+        out["loss_%d" % t] = np.float32(loss)
+        out.update(flat("sd_%d__" % t, sd_np(net)))
+        for i, prm in enumerate(net.parameters()):
+            st = model.optimizer.state[prm]
+            out["exp_avg_%d__%s" % (t, names[i].replace(".", "__"))] = st["exp_avg"].numpy().copy()
+            out["exp_avg_sq_%d__%s" % (t, names[i].replace(".", "__"))] = st["exp_avg_sq"].numpy().copy()
+    out["gradient_updates"] = np.float64(model.gradient_updates)
+    out["xs"] = np.stack(xs)
+    if gts is not None:
+        out["gts"] = np.stack(gts)
+    out["meta"] = np.array([beta, anneal_steps, p, lr], dtype=np.float64)
+    out["enc_dims"] = np.array(enc_dims)
+    out["dec_dims"] = np.array(dec_dims)
+    if extra:
+        out.update(extra)
+    save(name, **out)
+
+
+def g2():
+    I, H, L, B = 64, 16, 8, 5
+    xs = [small_x(B, I, 3), small_x(B, I, 4), small_x(B, I, 5)]
+    train_steps_vae("g2_mvae_train_step_small", [I, H, L], [L, H, I], B, xs, None,
+                    beta=0.2, anneal_steps=2, p=0.5, seeds=[1001, 1002, 1003], hseed=11)
+    # te_batch != None: loss target differs from encoder input (reference models.py:819-822)
+    gts = [small_x(B, I, 13), small_x(B, I, 14)]
+    train_steps_vae("g2b_mvae_train_step_te", [I, H, L], [L, H, I], B, xs[:2], gts,
+                    beta=1.0, anneal_steps=0, p=0.5, seeds=[2001, 2002], hseed=12)
+    # odd sizes + deeper nets (nothing a multiple of any tile) + non-binary values
+    I, B = 77, 7
+    rng = np.random.default_rng(9)
+    xs = [((rng.random((B, I)) < 0.15) * rng.integers(1, 4, (B, I))).astype(np.float32) for _ in range(2)]
+    train_steps_vae("g2c_mvae_train_step_deep", [I, 21, 13, 5], [5, 9, I], B, xs, None,
+                    beta=0.3, anneal_steps=0, p=0.3, seeds=[3001, 3002], hseed=13)
+
+
+# ---------------------------------------------------------------- G3
+def g3():
+    I, H, L, B = 20108, 600, 200, 8
+    X = synth.synth_interactions(4096, I, seed=777)
+    rows = np.array([5, 17, 100, 1000, 2047, 3000, 4000, 4095])
+    x = np.asarray(X[rows].toarray(), dtype=np.float32)
+    net = MultiVAE_net([L, H, I], dropout=0.5)
+    load_hash(net, [I, H, L], [L, H, I], "vae", 4242, bias_std=1.0)
+    model = MultiVAE(net, beta=0.2, anneal_steps=0)
+    net.eval()
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        y, mu, logvar = net(xt)
+        loss = model.loss_function(y, xt, mu, logvar, 0.2)
+        lse = torch.logsumexp(y, 1)
+    # one training-mode step with injected RNG at the real K: loss + gradient slices
+    seed = 5005
+    mask, eps = replay_rng(seed, B, I, L, 0.5)
+    net.train()
+    torch.manual_seed(seed)
+    yt, mut, lvt = net(xt)
+    lt = model.loss_function(yt, xt, mut, lvt, 0.2)
+    grads = torch.autograd.grad(lt, list(net.parameters()))
+    names = [k for k, _ in net.named_parameters()]
+    g = dict(zip(names, grads))
+    save("g3_mvae_fwd_ml20m_slice",
+         synth_seed=np.int64(777), synth_users=np.int64(4096), rows=rows, hash_seed=np.int64(4242),
+         dims=np.array([I, H, L]), beta=np.float32(0.2),
+         logits_s257=y.numpy()[:, ::257].copy(), lse=lse.numpy(), mu=mu.numpy(), logvar=logvar.numpy(),
+         loss=np.float32(loss.item()),
+         train_seed=np.int64(seed), mask_bits=np.packbits(mask, axis=1), eps=eps,
+         train_loss=np.float32(lt.item()), train_logits_s257=yt.detach().numpy()[:, ::257].copy(),
+         train_mu=mut.detach().numpy(), train_logvar=lvt.detach().numpy(),
+         gW1_s=g["enc_layers.0.weight"].numpy()[::37, ::211].copy(),
+         gb1=g["enc_layers.0.bias"].numpy(),
+         gW2_s=g["enc_layers.1.weight"].numpy()[::7, ::11].copy(),
+         gb2=g["enc_layers.1.bias"].numpy(),
+         gW3_s=g["dec_layers.0.weight"].numpy()[::11, ::7].copy(),
+         gb3=g["dec_layers.0.bias"].numpy(),
+         gW4_s=g["dec_layers.1.weight"].numpy()[::211, ::37].copy(),
+         gb4_s=g["dec_layers.1.bias"].numpy()[::101].copy())
+
+
+# ---------------------------------------------------------------- G4
+def g4():
+    I, H, L, B = 64, 16, 8, 5
+    p, lam = 0.5, 0.2
+    net = MultiDAE_net([L, H, I], dropout=p)
+    sd0 = load_hash(net, [I, H, L], [L, H, I], "dae", 21)
+    model = MultiDAE(net, lam=lam)
+    xs = [small_x(B, I, 3), small_x(B, I, 4), small_x(B, I, 5)]
+    names = [k for k, _ in net.named_parameters()]
+    out = dict(flat("sd0__", sd0))
+    for t, seed in enumerate([4001, 4002, 4003]):
+        x = torch.from_numpy(xs[t])
+        mask, _ = replay_rng(seed, B, I, 0, p)
+        out["mask_%d" % t] = mask
+        net.train()
+        torch.manual_seed(seed)
+        y = net(x)
+        l_side = model.loss_function(y, x)
+        grads = torch.autograd.grad(l_side, list(net.parameters()))
+        for n, g in zip(names, grads):
+            out["grad_%d__%s" % (t, n.replace(".", "__"))] = g.numpy().copy()
+        out["logits_%d" % t] = y.detach().numpy().copy()
+        torch.manual_seed(seed)
+        loss = model.train_batch(x, None)
+        assert abs(loss - l_side.item()) <= 1e-6 * max(1.0, abs(loss))
+        out["loss_%d" % t] = np.float32(loss)
+        out.update(flat("sd_%d__" % t, sd_np(net)))
+        for i, prm in enumerate(net.parameters()):
+            st = model.optimizer.state[prm]
+            out["exp_avg_%d__%s" % (t, names[i].replace(".", "__"))] = st["exp_avg"].numpy().copy()
+            out["exp_avg_sq_%d__%s" % (t, names[i].replace(".", "__"))] = st["exp_avg_sq"].numpy().copy()
+    net.eval()
+    pred = model.predict(torch.from_numpy(xs[0]), remove_train=True)
+    assert len(pred) == 1
+    out["pred_after"] = pred[0].numpy()
+    out["xs"] = np.stack(xs)
+    out["meta"] = np.array([lam, 0.001, p, 1e-3], dtype=np.float64)
+    out["enc_dims"] = np.array([I, H, L])
+    out["dec_dims"] = np.array([L, H, I])
+    save("g4_mdae_train_step_small", **out)
+
+
+# ---------------------------------------------------------------- G5
+def g5():
+    rng = np.random.default_rng(5)
+    dense = (rng.random((37, 23)) < 0.2).astype(np.float64)
+    dense_te = (rng.random((37, 23)) < 0.1).astype(np.float64)
+    tr, te = csr_matrix(dense), csr_matrix(dense_te)
+    out = dict(dense_tr=dense, dense_te=dense_te)
+    for tag, (shuffle, with_te) in {"ns": (False, False), "s": (True, False), "ste": (True, True)}.items():
+        np.random.seed(424242)
+        smp = DataSampler(tr, te if with_te else None, batch_size=8, shuffle=shuffle)
+        out["len_" + tag] = np.int64(len(smp))
+        for e in range(2):                      # two epochs: a fresh permutation each iter()
+            for b, (dtr, dte) in enumerate(smp):
+                out["%s_e%d_b%d_tr" % (tag, e, b)] = dtr.numpy()
+                if dte is not None:
+                    out["%s_e%d_b%d_te" % (tag, e, b)] = dte.numpy()
+                else:
+                    assert not with_te
+    out["np_seed"] = np.int64(424242)
+    save("g5_sampler_batches", **out)
+
+
+# ---------------------------------------------------------------- G6
+def g6():
+    rng = np.random.default_rng(6)
+    scores = rng.standard_normal((16, 300)).astype(np.float32)
+    train = rng.random((16, 300)) < 0.1
+    scores[train] = -np.inf
+    heldout = ((rng.random((16, 300)) < 0.05) & ~train).astype(np.float32)
+    heldout[0, :] = 0; heldout[0, 5] = 1          # single relevant item
+    heldout[3, ~train[3]] = 1                    # more relevant items than k
+    mets = ["ndcg@100", "ndcg@10", "recall@50", "recall@20", "hit@5", "mrr@10", "ndcg@1000"]
+    res = Metrics.compute(scores, heldout, mets)
+    out = dict(scores=scores, heldout=heldout)
+    for m in mets:
+        out["res__" + m.replace("@", "_at_")] = np.asarray(res[m], dtype=np.float64)
+    # the reference's own KATs (tests/test_metrics.py:14-61), outputs as produced by the reference
+    s = np.array([[4., 3., 2., 1.]]); gt1 = np.array([[1., 1., 0., 0.]]); gt2 = np.array([[0., 0., 1., 1.]])
+    out["kat_ndcg2_a"] = Metrics.ndcg_at_k(s, gt1, 2); out["kat_ndcg2_b"] = Metrics.ndcg_at_k(s, gt2, 2)
+    out["kat_ndcg3_b"] = Metrics.ndcg_at_k(s, gt2, 3)
+    out["kat_recall3_a"] = Metrics.recall_at_k(np.array([[4., 3., 2., 1., 0.]]), np.array([[1., 1., 0., 0., 1.]]), 3)
+    save("g6_metrics", **out)
+
+
+# ---------------------------------------------------------------- G8
+def g8():
+    U, I, H, L, B = 512, 128, 32, 8, 64
+    rng = np.random.default_rng(8)
+    # low-rank synthetic preferences
+    P, Q = rng.standard_normal((U + 64, 4)), rng.standard_normal((I, 4))
+    S = P @ Q.T + 0.5 * rng.standard_normal((U + 64, I))
+    dense = (S > np.quantile(S, 0.85, axis=1, keepdims=True)).astype(np.float64)
+    train = csr_matrix(dense[:U])
+    held = csr_matrix(dense[U:])
+    val_tr, val_te = synth.split_heldout(held, 0.2, seed=1)
+    p = 0.5
+    net = MultiVAE_net([L, H, I], dropout=p)
+    sd0 = load_hash(net, [I, H, L], [L, H, I], "vae", 88, bias_std=0.1)
+    model = MultiVAE(net, beta=0.2, anneal_steps=20)
+    n_epochs = 5
+    nb = int(np.ceil(U / B))
+    masks = np.zeros((n_epochs, nb, B, I), dtype=np.uint8)
+    epss = np.zeros((n_epochs, nb, B, L), dtype=np.float32)
+    losses = np.zeros((n_epochs, nb), dtype=np.float64)
+    ndcg = np.zeros(n_epochs); recall = np.zeros(n_epochs)
+    perms = np.zeros((n_epochs, U), dtype=np.int64)
+    for e in range(n_epochs):
+        np.random.seed(8000 + e)
+        perm = list(range(U)); np.random.shuffle(perm); perms[e] = perm
+        np.random.seed(8000 + e)
+        smp = DataSampler(train, batch_size=B, shuffle=True)
+        net.train()
+        for b, (dtr, _) in enumerate(smp):
+            assert np.array_equal(dtr.numpy(), dense[:U][perm[b * B:(b + 1) * B]].astype(np.float32))
+            seed = 80000 + e * 100 + b
+            m, eps = replay_rng(seed, dtr.shape[0], I, L, p)
+            masks[e, b], epss[e, b] = m, eps
+            torch.manual_seed(seed)
+            losses[e, b] = model.train_batch(dtr, None)
+        vs = DataSampler(val_tr, val_te, batch_size=32, shuffle=False)
+        res = evaluate(model, vs, ["ndcg@100", "recall@50"])
+        ndcg[e], recall[e] = np.mean(res["ndcg@100"]), np.mean(res["recall@50"])
+        if e == n_epochs - 1:
+            last = res
+    save("g8_epoch_curve", dense_train=dense[:U].astype(np.uint8),
+         val_tr=np.asarray(val_tr.toarray(), dtype=np.uint8), val_te=np.asarray(val_te.toarray(), dtype=np.uint8),
+         mask_bits=np.packbits(masks, axis=-1), eps=epss, losses=losses, ndcg100=ndcg, recall50=recall,
+         perms=perms, ndcg100_users=last["ndcg@100"], recall50_users=last["recall@50"],
+         dims=np.array([I, H, L]), meta=np.array([0.2, 20, p, 1e-3, B]), hash_seed=np.int64(88),
+         **flat("sd_final__", sd_np(net)))
+
+
+# ---------------------------------------------------------------- G9
+def g9():
+    I, H, L = 12, 6, 3
+    net = MultiVAE_net([L, H, I], dropout=0.5)
+    model = MultiVAE(net, beta=0.2, anneal_steps=5)
+    torch.manual_seed(9)
+    model.train_batch(torch.from_numpy(small_x(4, I, 9)), None)
+    tmp = tempfile.NamedTemporaryFile(suffix=".pth")
+    model.save_model(tmp.name, 3)
+    ck = torch.load(tmp.name, weights_only=False)
+    keys = sorted(ck.keys())
+    sd_keys = list(ck["state_dict"].keys())
+    sd_shapes = [tuple(v.shape) for v in ck["state_dict"].values()]
+    opt = ck["optimizer"]
+    pg = {k: v for k, v in opt["param_groups"][0].items() if k != "params"}
+    st0 = opt["state"][0]
+    save("g9_checkpoint_layout", top_keys=np.array(keys), sd_keys=np.array(sd_keys),
+         sd_shapes=np.array([str(s) for s in sd_shapes]),
+         sd_dtypes=np.array([str(v.dtype) for v in ck["state_dict"].values()]),
+         pg_keys=np.array(sorted(pg.keys())), pg_vals=np.array([str(pg[k]) for k in sorted(pg.keys())]),
+         pg_params=np.array(opt["param_groups"][0]["params"]),
+         state_keys=np.array(sorted(st0.keys())), state_step=np.float64(float(st0["step"])),
+         state_step_type=np.array(str(type(st0["step"]))),
+         epoch=np.int64(ck["epoch"]), gradient_updates=np.float64(ck["gradient_updates"]))
+    # a full reference-written checkpoint the build must be able to LOAD (binary data file)
+    import shutil
+    shutil.copy(tmp.name, os.path.join(HERE, "g9_reference_checkpoint.pth"))
+    x = small_x(4, I, 10)
+    pred = model.predict(torch.from_numpy(x), remove_train=True)[0].numpy()
+    save("g9_checkpoint_predict", x=x, pred=pred, dims=np.array([I, H, L]))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
+    for w in which:
+        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9}[w]()
