@@ -1,0 +1,146 @@
+/*
+ * rectorch_hip.h -- C ABI of librectorch_hip.so: the MI355X (gfx950) implementation of rectorch's
+ * Mult-VAE / Mult-DAE training and scoring path.
+ *
+ * The reference (makgyver/rectorch) is pure Python and has no FFI; its boundary for this path is the
+ * Python class API.  Each entry point below names the reference code it replaces.  The Python mirror
+ * of that API (rectorch_amd/{nets,models,samplers}.py) binds these symbols with ctypes and exposes
+ * them as torch.library ops; INTEGRATION.md shows the binding a rectorch maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch types.  Pointers are HIP DEVICE pointers unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
+ *   - return 0 on success, <0 (RTX_E*) on failure; rtx_last_error() gives the message (thread local).
+ *   - the caller owns every buffer it passes.  An rtx_engine owns its compute-precision weight copies
+ *     ("shadows"), activations and workspaces.  One engine per device, externally serialised.
+ *   - parameter tensors are float32, [out,in] row-major, in the order of net.parameters():
+ *     enc W0,b0,W1,b1,... then dec W0,b0,...   (reference rectorch/nets.py:260-270, 208-217)
+ */
+#ifndef RECTORCH_HIP_H
+#define RECTORCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_MAX_LAYERS 8
+
+#define RTX_VAE 0 /* MultiVAE_net: last encoder layer emits mu|logvar, reparameterised z        */
+#define RTX_DAE 1 /* MultiDAE_net: tanh on every encoder layer                                  */
+
+#define RTX_FP32 0 /* parity mode: v_mfma_f32_32x32x2_f32, exact f32 products and sums           */
+#define RTX_BF16 1 /* throughput mode: v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 master params */
+
+typedef struct rtx_engine rtx_engine;
+typedef struct rtx_csr rtx_csr;
+
+typedef struct {
+    int32_t n_enc;                        /* Linear layers in the encoder                          */
+    int32_t n_dec;                        /* Linear layers in the decoder                          */
+    int32_t enc_dims[RTX_MAX_LAYERS + 1]; /* enc_dims[0] = n_items ... enc_dims[n_enc] = latent    */
+    int32_t dec_dims[RTX_MAX_LAYERS + 1]; /* dec_dims[0] = latent  ... dec_dims[n_dec] = n_items   */
+    int32_t variant;                      /* RTX_VAE | RTX_DAE                                     */
+    int32_t numerics;                     /* RTX_FP32 | RTX_BF16                                   */
+    float dropout_p;                      /* nn.Dropout(p) on the normalised input (nets.py:392)   */
+    int32_t max_batch;                    /* largest batch this engine will be given               */
+    int32_t splitk;                       /* split-K factor for the two K = n_items GEMMs, 0 = auto */
+} rtx_cfg;
+
+/* A batch of users.  Either rows of a resident CSR matrix (fast path: nothing dense crosses the API)
+ * or dense [batch][n_items] float32 device tensors (drop-in for train_batch(tr_batch, te_batch) /
+ * predict(x), reference models.py:817-822, 619-624). */
+typedef struct {
+    const rtx_csr* csr;          /* input rows (NULL -> use x_dense)                                 */
+    const int32_t* row_ids;      /* device int32 [batch] row numbers (NULL -> rows 0..batch-1)       */
+    const rtx_csr* target_csr;   /* loss target rows, same row ids (NULL -> target = input)          */
+    const float* x_dense;        /* device [batch][n_items]                                          */
+    const float* target_dense;   /* device [batch][n_items] (NULL -> target = input)                 */
+    int32_t batch;
+} rtx_batch;
+
+/* Per-step scalars: what MultiVAE.train_batch / MultiDAE + torch.optim.Adam hold (models.py:817-835,
+ * 768-770, 657-659). */
+typedef struct {
+    float beta;                  /* VAE: KL weight after annealing (models.py:824-827)               */
+    float lam;                   /* DAE: weight of sum_W ||W||_2   (models.py:702-706)               */
+    float inv_batch;             /* scale of the batch mean: 1/B, or 1/B_global under data parallel  */
+    float lr, beta1, beta2, eps, weight_decay; /* Adam hyper-parameters                              */
+    int32_t step;                /* Adam step count t of THIS update (1-based)                       */
+    uint64_t seed, offset;       /* Philox stream for dropout and the reparameterisation noise       */
+    const uint8_t* dropout_mask; /* injected keep-mask [batch][n_items] (NULL -> Philox)             */
+    const float* eps_noise;      /* injected N(0,1) draws [batch][latent]  (NULL -> Philox)          */
+} rtx_step;
+
+/* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
+ * have been enqueued; layers complete in reverse order (last decoder layer first).  A data-parallel
+ * caller records an event here and starts the RCCL all-reduce of that bucket on a side stream. */
+typedef void (*rtx_layer_cb)(int32_t layer, void* user);
+
+const char* rtx_last_error(void);
+int32_t rtx_abi_version(void);
+
+/* ---- resident CSR matrices: replaces DataSampler's per-batch scipy row gather + toarray()
+ *      (rectorch/samplers.py:97-105).  Column ids must be unique within a row. -------------------- */
+int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host,
+                   int64_t n_rows, int32_t n_cols, rtx_csr** out); /* values_host NULL -> all 1.0 */
+int rtx_csr_destroy(rtx_csr* m);
+int rtx_csr_shape(const rtx_csr* m, int64_t* n_rows, int32_t* n_cols, int64_t* nnz);
+/* dense float32 [batch][n_cols] image of the given rows: what DataSampler.__iter__ yields */
+int rtx_csr_gather_dense(const rtx_csr* m, const int32_t* row_ids, int32_t batch, float* out, void* stream);
+
+/* ---- engine ------------------------------------------------------------------------------------ */
+int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out);
+int rtx_engine_destroy(rtx_engine* e);
+int32_t rtx_engine_n_tensors(const rtx_engine* e);
+/* shape of parameter tensor t: rows = out features, cols = in features (1 for a bias) */
+int rtx_engine_tensor_shape(const rtx_engine* e, int32_t t, int32_t* rows, int32_t* cols);
+/* bind the float32 master parameters, gradient buffers and Adam moments (exp_avg / exp_avg_sq of
+ * torch.optim.Adam's state) -- one device pointer per tensor.  grads/moments may be NULL for an
+ * inference-only engine. */
+int rtx_engine_bind(rtx_engine* e, float* const* params, float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq);
+/* refresh the compute-precision copies after the master parameters were changed from outside
+ * (load_state_dict, reference models.py:513) */
+int rtx_engine_sync_shadows(rtx_engine* e, void* stream);
+
+/* VAE_net.forward / AE_net.forward (nets.py:322-339, 82-91) and VAE.predict / AETrainer.predict
+ * (models.py:619-625, 467-473).  logits [batch][n_items]; mu/logvar [batch][latent] (VAE, nullable).
+ * training != 0 applies dropout and samples z (uses step->seed/offset or the injected draws). */
+int rtx_engine_forward(rtx_engine* e, const rtx_batch* batch, int32_t training, const rtx_step* step,
+                       int32_t remove_train, float* logits, float* mu, float* logvar, void* stream);
+/* MultiVAE_net.encode / MultiDAE_net.encode (nets.py:394-405, 219-225):
+ * VAE: out0 = mu, out1 = logvar; DAE: out0 = h, out1 unused.  [batch][latent] */
+int rtx_engine_encode(rtx_engine* e, const rtx_batch* batch, int32_t training, const rtx_step* step, float* out0,
+                      float* out1, void* stream);
+/* MultiVAE_net.decode / MultiDAE_net.decode (nets.py:413-417, 227-233): z [batch][latent] -> logits */
+int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logits, void* stream);
+
+/* forward + loss_function + backward of train_batch (models.py:829-832): gradients land in the bound
+ * grad buffers; loss_out[0] = loss (device float, nullable); loss_accum[0] += loss (nullable). */
+int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out,
+                          float* loss_accum, rtx_layer_cb cb, void* user, void* stream);
+/* optimizer.step() (models.py:833): fused multi-tensor Adam over the bound tensors + shadow refresh */
+int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream);
+/* both of the above: one full train_batch */
+int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out,
+                          float* loss_accum, void* stream);
+
+/* MultiVAE.loss_function / MultiDAE's likelihood term on dense tensors (models.py:813-815):
+ * loss_out[0] = mean_b(s_b*LSE_b - <x_b, y_b>) + beta * KLD   (mu/logvar NULL -> no KL term) */
+int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int32_t n_items, const float* mu,
+                         const float* logvar, int32_t latent, float beta, float* loss_out, void* stream);
+
+/* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
+int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);
+/* synchronises, returns up to `cap` entries (name, total ms, launches) and clears the counters */
+int rtx_engine_get_timings(rtx_engine* e, int32_t cap, char (*names)[48], float* total_ms, int32_t* launches,
+                           int32_t* n_out);
+/* algorithmic HBM bytes / MFMA flops of one train step at batch B (DESIGN.md derivation) */
+int rtx_engine_step_cost(const rtx_engine* e, int32_t batch, double* hbm_bytes, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,823 @@
+// engine.hip -- host orchestration of the Mult-VAE / Mult-DAE step on MI355X and the C ABI
+// (include/rectorch_hip.h).  One stream-ordered sequence of hand-written kernels per call; no host
+// synchronisation on the CSR fast path.
+//
+// Data layout in HBM (T = bf16 or f32 by cfg.numerics; P(d) = roundup(d+1,128), Bp = roundup(B,128)):
+//   layer l (in_l -> out_l), l = 0 .. NL-1 (encoder layers then decoder layers)
+//     Wsh[l]   T [P(out)][P(in)]    compute copy of W_l, K(=in)-contiguous      (forward B operand)
+//     WshT[l]  T [P(in)][P(out)]    transposed copy, K(=out)-contiguous          (backward-data B operand, l>0)
+//     A[l]     T [Bp][P(in)]        input activation of layer l                  (forward A operand)
+//     AT[l]    T [P(in)][Bp]        same, transposed, row `in` = ones            (weight-grad B operand)
+//     O32[l]   f32 [Bp][P(out)]     post-activation output (tanh layers)         (backward derivative)
+//     D[l]     T [Bp][P(out)]       d loss / d pre-activation                    (backward-data A operand)
+//     DT[l]    T [P(out)][Bp]       same, transposed                             (weight-grad A operand)
+//   Y  f32 [Bp][P(I)] logits;  Cacc f32 split-K slabs / small GEMM outputs.
+//   All pads are zero (memset at creation; producers rewrite the batch padding every call), so no GEMM
+//   needs a bounds check in its main loop.
+#include "../../include/rectorch_hip.h"
+#include "rtx_gemm.h"
+#include "rtx_kernels.h"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+const char* rtx_last_error_str();
+
+struct rtx_csr {
+    int64_t* indptr = nullptr;
+    int32_t* indices = nullptr;
+    float* values = nullptr;  // nullptr -> all ones
+    int64_t n_rows = 0, nnz = 0;
+    int32_t n_cols = 0;
+};
+
+struct Layer {
+    int in = 0, out = 0, inp = 0, outp = 0;
+    bool tanh_act = false;
+    void* Wsh = nullptr;
+    void* WshT = nullptr;
+    void* A = nullptr;
+    void* AT = nullptr;
+    float* O32 = nullptr;
+    void* D = nullptr;
+    void* DT = nullptr;
+};
+
+struct TimingSite {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+    int launches = 0;
+};
+
+struct TempCsr {  // dense batch converted to CSR on the device
+    int64_t* indptr = nullptr;
+    int32_t* counts = nullptr;
+    int32_t* indices = nullptr;
+    float* values = nullptr;
+    int64_t cap = 0;
+};
+
+struct rtx_engine {
+    rtx_cfg cfg;
+    int NL = 0, I = 0, Z = 0, Ip = 0, Zp = 0;
+    int Bp_alloc = 0;
+    bool bf16 = false, vae = false;
+    size_t esz = 4;
+    std::vector<Layer> L;
+    std::vector<void*> allocs;
+    float* Y = nullptr;
+    float* Cacc = nullptr;
+    size_t cacc_elems = 0;
+    float *mu32 = nullptr, *lv32 = nullptr, *eps32 = nullptr;
+    float *tsum = nullptr, *lse = nullptr, *row_loss = nullptr, *sumsq = nullptr, *scratch_loss = nullptr;
+    // bound tensors
+    std::vector<float*> params, grads, m, v;
+    bool bound = false, can_train = false, shadows_valid = false;
+    TempCsr tmp_in, tmp_tg;
+    // timing
+    bool timing_all = false;
+    std::map<std::string, bool> timing_sites;
+    std::map<std::string, TimingSite> sites;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// ------------------------------------------------------------------------------------------------
+static int dev_alloc(rtx_engine* e, void** p, size_t bytes, bool zero = true)
+{
+    if (bytes == 0) bytes = 16;
+    hipError_t rc = hipMalloc(p, bytes);
+    if (rc != hipSuccess) {
+        rtx_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(rc));
+        return RTX_ENOMEM;
+    }
+    if (e) e->allocs.push_back(*p);
+    if (zero) RTX_HIP(hipMemset(*p, 0, bytes));
+    return RTX_OK;
+}
+
+static int build_layers(const rtx_cfg& c, std::vector<Layer>& L)
+{
+    RTX_CHECK(c.n_enc >= 1 && c.n_dec >= 1 && c.n_enc <= RTX_MAX_LAYERS && c.n_dec <= RTX_MAX_LAYERS, RTX_EINVAL,
+              "bad layer counts %d/%d", c.n_enc, c.n_dec);
+    RTX_CHECK(c.enc_dims[c.n_enc] == c.dec_dims[0], RTX_EINVAL, "latent size mismatch: enc %d vs dec %d",
+              c.enc_dims[c.n_enc], c.dec_dims[0]);
+    RTX_CHECK(c.enc_dims[0] == c.dec_dims[c.n_dec], RTX_EINVAL, "n_items mismatch: enc %d vs dec %d", c.enc_dims[0],
+              c.dec_dims[c.n_dec]);
+    L.clear();
+    for (int i = 0; i < c.n_enc; ++i) {
+        Layer l;
+        l.in = c.enc_dims[i];
+        l.out = c.enc_dims[i + 1];
+        l.tanh_act = true;
+        if (i == c.n_enc - 1 && c.variant == RTX_VAE) {  // mu | logvar, linear (reference nets.py:262-265, 398-404)
+            l.out = 2 * c.enc_dims[i + 1];
+            l.tanh_act = false;
+        }
+        L.push_back(l);
+    }
+    for (int i = 0; i < c.n_dec; ++i) {
+        Layer l;
+        l.in = c.dec_dims[i];
+        l.out = c.dec_dims[i + 1];
+        l.tanh_act = (i != c.n_dec - 1);  // reference nets.py:413-417 / 227-233
+        L.push_back(l);
+    }
+    for (auto& l : L) {
+        RTX_CHECK(l.in > 0 && l.out > 0, RTX_EINVAL, "non-positive layer size");
+        l.inp = rtx_pad(l.in);
+        l.outp = rtx_pad(l.out);
+    }
+    return RTX_OK;
+}
+
+// ---- timing -------------------------------------------------------------------------------------
+struct ScopedTimer {
+    rtx_engine* e;
+    hipStream_t s;
+    TimingSite* site = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ScopedTimer(rtx_engine* eng, const char* name, hipStream_t st) : e(eng), s(st)
+    {
+        if (!e->timing_all && e->timing_sites.empty()) return;
+        if (!e->timing_all && !e->timing_sites.count(name)) return;
+        site = &e->sites[name];
+        auto get = [&]() {
+            hipEvent_t ev;
+            if (!e->event_pool.empty()) {
+                ev = e->event_pool.back();
+                e->event_pool.pop_back();
+            } else if (hipEventCreate(&ev) != hipSuccess) {
+                ev = nullptr;
+            }
+            return ev;
+        };
+        e0 = get();
+        e1 = get();
+        if (e0) (void)hipEventRecord(e0, s);
+    }
+    ~ScopedTimer()
+    {
+        if (!site) return;
+        if (e1) (void)hipEventRecord(e1, s);
+        if (e0 && e1) site->pending.push_back({e0, e1});
+    }
+};
+#define RTX_CAT2(a, b) a##b
+#define RTX_CAT(a, b) RTX_CAT2(a, b)
+#define TIMED(name) ScopedTimer RTX_CAT(_timer_, __LINE__)(e, name, st)
+
+// ---- GEMM helper -------------------------------------------------------------------------------------
+static int choose_splits(const rtx_engine* e, int tiles, int k_slices)
+{
+    if (tiles >= 192) return 1;
+    int s = (512 + tiles - 1) / tiles;
+    if (k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
+    const int max_s = k_slices / 4 > 0 ? k_slices / 4 : 1;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// C[Mp][Np] (+slabs) = A[Mp][Kp] * B[Np][Kp]^T into e->Cacc; returns the split count used
+static int gemm_to_cacc(rtx_engine* e, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, int* splits_out,
+                        hipStream_t st)
+{
+    RtxGemm g = {};
+    g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
+    g.m_tiles = Mp / 128; g.n_tiles = Np / 128;
+    g.k_slices = (int)((size_t)Kp * e->esz / 128);
+    g.splits = choose_splits(e, g.m_tiles * g.n_tiles, g.k_slices);
+    g.C = e->Cacc; g.ldc = Np; g.slab_stride = (long)Mp * Np;
+    while (g.splits > 1 && (size_t)g.splits * Mp * Np > e->cacc_elems) --g.splits;  // smaller batches: fewer tiles, same scratch
+    RTX_CHECK((size_t)g.splits * Mp * Np <= e->cacc_elems, RTX_ESTATE, "internal: Cacc too small (%d x %d x %d)", g.splits, Mp, Np);
+    g.n_major = 0;
+    *splits_out = g.splits;
+    return rtx_gemm_launch(g, e->bf16, RTX_EPI_STORE, st);
+}
+
+// ---- batch resolution --------------------------------------------------------------------------------
+static int ensure_tmp(rtx_engine* e, TempCsr& t, int64_t nnz)
+{
+    if (!t.indptr) {
+        RTX_TRY(dev_alloc(e, (void**)&t.indptr, sizeof(int64_t) * (e->cfg.max_batch + 1)));
+        RTX_TRY(dev_alloc(e, (void**)&t.counts, sizeof(int32_t) * (e->cfg.max_batch + 1)));
+    }
+    if (nnz > t.cap) {
+        int64_t cap = nnz + nnz / 2 + 1024;
+        // old buffers stay in e->allocs and are freed with the engine (growth is rare)
+        RTX_TRY(dev_alloc(e, (void**)&t.indices, sizeof(int32_t) * cap, false));
+        RTX_TRY(dev_alloc(e, (void**)&t.values, sizeof(float) * cap, false));
+        t.cap = cap;
+    }
+    return RTX_OK;
+}
+
+static int dense_to_view(rtx_engine* e, TempCsr& t, const float* x, int B, RtxCsrView* v, hipStream_t st)
+{
+    RTX_TRY(ensure_tmp(e, t, 0));
+    RTX_TRY(rtx_launch_dense_count(x, B, e->I, t.counts, st));
+    RTX_TRY(rtx_launch_scan_counts(t.counts, B, t.indptr, st));
+    int64_t nnz = 0;
+    RTX_HIP(hipMemcpyAsync(&nnz, t.indptr + B, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    RTX_HIP(hipStreamSynchronize(st));  // dense drop-in path only; the CSR path never synchronises
+    RTX_TRY(ensure_tmp(e, t, nnz));
+    RTX_TRY(rtx_launch_dense_fill(x, B, e->I, t.indptr, t.indices, t.values, st));
+    v->indptr = t.indptr; v->indices = t.indices; v->values = t.values; v->row_ids = nullptr;
+    return RTX_OK;
+}
+
+static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxCsrView* tg, hipStream_t st)
+{
+    RTX_CHECK(b, RTX_EINVAL, "batch is NULL");
+    RTX_CHECK(b->batch >= 1 && b->batch <= e->cfg.max_batch, RTX_EINVAL, "batch %d outside [1, max_batch=%d]", b->batch,
+              e->cfg.max_batch);
+    if (b->csr) {
+        RTX_CHECK(b->csr->n_cols == e->I, RTX_EINVAL, "CSR has %d columns, network expects %d items", b->csr->n_cols, e->I);
+        RTX_CHECK(b->row_ids || b->batch <= b->csr->n_rows, RTX_EINVAL, "batch larger than the matrix");
+        in->indptr = b->csr->indptr; in->indices = b->csr->indices; in->values = b->csr->values; in->row_ids = b->row_ids;
+    } else {
+        RTX_CHECK(b->x_dense, RTX_EINVAL, "batch has neither csr nor x_dense");
+        RTX_TRY(dense_to_view(e, e->tmp_in, b->x_dense, b->batch, in, st));
+    }
+    if (b->target_csr) {
+        RTX_CHECK(b->target_csr->n_cols == e->I, RTX_EINVAL, "target CSR has %d columns, expected %d", b->target_csr->n_cols, e->I);
+        tg->indptr = b->target_csr->indptr; tg->indices = b->target_csr->indices; tg->values = b->target_csr->values;
+        tg->row_ids = b->row_ids;
+    } else if (b->target_dense) {
+        RTX_TRY(dense_to_view(e, e->tmp_tg, b->target_dense, b->batch, tg, st));
+    } else {
+        *tg = *in;
+    }
+    return RTX_OK;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------
+// Runs layers [l0, l1).  If l0 == 0 the gather kernel builds A[0] from `in`.  The last network layer
+// writes logits to `logits` (ld = ldlog).  need_T: also produce the transposed activations (training).
+static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg, int B, int training, const rtx_step* step,
+                       int need_T, int l0, int l1, float* logits, long ldlog, float* mu_out, float* lv_out, hipStream_t st)
+{
+    const int Bp = rtx_pad_batch(B), ldt = e->Bp_alloc;
+    static const rtx_step zero_step = {};
+    if (!step) step = &zero_step;
+    if (l0 == 0) {
+        Layer& l = e->L[0];
+        if (need_T) {
+            TIMED("memset_xT");
+            RTX_HIP(hipMemset2DAsync(l.AT, (size_t)ldt * e->esz, 0, (size_t)Bp * e->esz, (size_t)l.inp, st));
+        }
+        RtxGatherArgs a = {};
+        a.in = *in; a.target = *tg;
+        a.B = B; a.Bp = Bp; a.I = e->I; a.ldx = l.inp; a.ldt = ldt;
+        a.X = l.A; a.XT = need_T ? l.AT : nullptr; a.tsum = e->tsum;
+        a.training = training; a.dropout_p = e->cfg.dropout_p;
+        a.mask = step->dropout_mask; a.seed = step->seed; a.offset = step->offset;
+        TIMED("gather");
+        RTX_TRY(rtx_launch_gather(a, e->bf16, st));
+    }
+    for (int li = l0; li < l1; ++li) {
+        Layer& l = e->L[li];
+        if (li == e->NL - 1) {
+            RtxGemm g = {};
+            g.A = l.A; g.B = l.Wsh; g.lda = l.inp; g.ldb = l.inp;
+            g.m_tiles = Bp / 128; g.n_tiles = l.outp / 128;
+            g.k_slices = (int)((size_t)l.inp * e->esz / 128);
+            g.splits = 1; g.C = logits; g.ldc = ldlog; g.bias = e->params[2 * li + 1];
+            g.M_real = B; g.N_real = l.out; g.n_major = 0;
+            TIMED("gemm_logits");
+            RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_BIAS_ROWS, st));
+            break;
+        }
+        int splits = 1;
+        {
+            TIMED(li == 0 ? "gemm_fwd_in" : "gemm_fwd_hidden");
+            RTX_TRY(gemm_to_cacc(e, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, &splits, st));
+        }
+        Layer& nx = e->L[li + 1];
+        if (e->vae && li == e->cfg.n_enc - 1) {
+            RtxVaeFwdArgs a = {};
+            a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.outp; a.ldc = l.outp;
+            a.B = B; a.Bp = Bp; a.ldt = ldt; a.Z = e->Z; a.Zp = e->Zp;
+            a.bias = e->params[2 * li + 1];
+            a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32;
+            a.mu_out = mu_out; a.lv_out = lv_out;
+            a.Zr = nx.A; a.ZT = nx.AT;
+            a.training = training; a.eps_in = step->eps_noise; a.seed = step->seed; a.offset = step->offset;
+            TIMED("vae_head_fwd");
+            RTX_TRY(rtx_launch_vae_fwd(a, e->bf16, st));
+        } else {
+            RtxPostArgs a = {};
+            a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.outp; a.ldc = l.outp;
+            a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = l.out; a.Np = l.outp;
+            a.tanh_act = l.tanh_act; a.bias = e->params[2 * li + 1];
+            a.O32 = l.O32; a.R = nx.A; a.RT = need_T ? nx.AT : nullptr; a.ones_row = 1;
+            TIMED("post_fwd");
+            RTX_TRY(rtx_launch_post(a, RTX_POST_FWD, e->bf16, st));
+        }
+    }
+    return RTX_OK;
+}
+
+static int check_ready(rtx_engine* e, bool train)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    RTX_CHECK(e->bound, RTX_ESTATE, "rtx_engine_bind() has not been called");
+    RTX_CHECK(!train || e->can_train, RTX_ESTATE, "engine was bound without gradient / Adam buffers");
+    return RTX_OK;
+}
+
+static int ensure_shadows(rtx_engine* e, hipStream_t st)
+{
+    if (e->shadows_valid) return RTX_OK;
+    return rtx_engine_sync_shadows(e, st);
+}
+
+static void fill_adam_tensors(rtx_engine* e, RtxAdamArgs& a)
+{
+    a.n = 2 * e->NL;
+    for (int li = 0; li < e->NL; ++li) {
+        Layer& l = e->L[li];
+        RtxAdamTensor& w = a.t[2 * li];
+        w.p = e->params[2 * li];
+        w.g = e->can_train ? e->grads[2 * li] : nullptr;
+        w.m = e->can_train ? e->m[2 * li] : nullptr;
+        w.v = e->can_train ? e->v[2 * li] : nullptr;
+        w.sh = l.Wsh; w.shT = l.WshT; w.rows = l.out; w.cols = l.in; w.ld_sh = l.inp; w.ld_shT = l.outp;
+        RtxAdamTensor& b = a.t[2 * li + 1];
+        b.p = e->params[2 * li + 1];
+        b.g = e->can_train ? e->grads[2 * li + 1] : nullptr;
+        b.m = e->can_train ? e->m[2 * li + 1] : nullptr;
+        b.v = e->can_train ? e->v[2 * li + 1] : nullptr;
+        b.sh = nullptr; b.shT = nullptr; b.rows = 1; b.cols = l.out; b.ld_sh = 0; b.ld_shT = 0;
+    }
+}
+
+static int launch_sumsq(rtx_engine* e, hipStream_t st)
+{
+    std::vector<const float*> ps(2 * e->NL);
+    std::vector<long> sz(2 * e->NL);
+    for (int li = 0; li < e->NL; ++li) {
+        ps[2 * li] = e->params[2 * li];
+        sz[2 * li] = (long)e->L[li].out * e->L[li].in;
+        ps[2 * li + 1] = e->params[2 * li + 1];
+        sz[2 * li + 1] = e->L[li].out;
+    }
+    return rtx_launch_sumsq(ps.data(), sz.data(), 2 * e->NL, e->sumsq, st);
+}
+
+__global__ void k_unpad_copy(const float* src, int ld, int B, int n, float* dst)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)B * n) dst[i] = src[(i / n) * ld + (i % n)];
+}
+
+template <typename T>
+__global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, int Bp)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)Bp * ld) {
+        const int b = (int)(i / ld), j = (int)(i % ld);
+        dst[i] = Elem<T>::from((b < B && j < n) ? src[(long)b * n + j] : 0.f);
+    }
+}
+
+// =================================================================================================
+extern "C" {
+
+const char* rtx_last_error(void) { return rtx_last_error_str(); }
+int32_t rtx_abi_version(void) { return 1; }
+
+// ---- CSR -------------------------------------------------------------------------------------------
+int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
+                   int32_t n_cols, rtx_csr** out)
+{
+    RTX_CHECK(indptr_host && out && n_rows >= 0 && n_cols > 0, RTX_EINVAL, "csr_upload: bad arguments");
+    const int64_t nnz = indptr_host[n_rows];
+    RTX_CHECK(nnz == 0 || indices_host, RTX_EINVAL, "csr_upload: indices is NULL");
+    rtx_csr* m = new rtx_csr();
+    m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
+    int rc = dev_alloc(nullptr, (void**)&m->indptr, sizeof(int64_t) * (n_rows + 1), false);
+    if (!rc) rc = dev_alloc(nullptr, (void**)&m->indices, sizeof(int32_t) * (nnz > 0 ? nnz : 1), false);
+    if (!rc && values_host) rc = dev_alloc(nullptr, (void**)&m->values, sizeof(float) * (nnz > 0 ? nnz : 1), false);
+    if (rc) { rtx_csr_destroy(m); return rc; }
+    hipError_t h = hipMemcpy(m->indptr, indptr_host, sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice);
+    if (h == hipSuccess && nnz) h = hipMemcpy(m->indices, indices_host, sizeof(int32_t) * nnz, hipMemcpyHostToDevice);
+    if (h == hipSuccess && nnz && values_host) h = hipMemcpy(m->values, values_host, sizeof(float) * nnz, hipMemcpyHostToDevice);
+    if (h != hipSuccess) {
+        rtx_set_error("csr_upload: hipMemcpy failed: %s", hipGetErrorString(h));
+        rtx_csr_destroy(m);
+        return RTX_EHIP;
+    }
+    *out = m;
+    return RTX_OK;
+}
+
+int rtx_csr_destroy(rtx_csr* m)
+{
+    if (!m) return RTX_OK;
+    if (m->indptr) (void)hipFree(m->indptr);
+    if (m->indices) (void)hipFree(m->indices);
+    if (m->values) (void)hipFree(m->values);
+    delete m;
+    return RTX_OK;
+}
+
+int rtx_csr_shape(const rtx_csr* m, int64_t* n_rows, int32_t* n_cols, int64_t* nnz)
+{
+    RTX_CHECK(m, RTX_EINVAL, "csr is NULL");
+    if (n_rows) *n_rows = m->n_rows;
+    if (n_cols) *n_cols = m->n_cols;
+    if (nnz) *nnz = m->nnz;
+    return RTX_OK;
+}
+
+int rtx_csr_gather_dense(const rtx_csr* m, const int32_t* row_ids, int32_t batch, float* out, void* stream)
+{
+    RTX_CHECK(m && out, RTX_EINVAL, "csr_gather_dense: bad arguments");
+    RTX_CHECK(batch >= 0 && (row_ids || batch <= m->n_rows), RTX_EINVAL, "csr_gather_dense: bad batch %d", batch);
+    RtxCsrView v = {m->indptr, m->indices, m->values, row_ids};
+    return rtx_launch_csr_to_dense(v, batch, m->n_cols, out, (hipStream_t)stream);
+}
+
+// ---- engine lifecycle ------------------------------------------------------------------------------
+int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
+{
+    RTX_CHECK(cfg && out, RTX_EINVAL, "engine_create: NULL argument");
+    RTX_CHECK(cfg->variant == RTX_VAE || cfg->variant == RTX_DAE, RTX_EINVAL, "bad variant %d", cfg->variant);
+    RTX_CHECK(cfg->numerics == RTX_FP32 || cfg->numerics == RTX_BF16, RTX_EINVAL, "bad numerics %d", cfg->numerics);
+    RTX_CHECK(cfg->max_batch >= 1, RTX_EINVAL, "max_batch must be >= 1");
+    RTX_CHECK(cfg->dropout_p >= 0.f && cfg->dropout_p <= 1.f, RTX_EINVAL, "dropout_p outside [0,1]");
+    int ndev = 0;
+    hipError_t h = hipGetDeviceCount(&ndev);
+    RTX_CHECK(h == hipSuccess && ndev > 0, RTX_EHIP, "no HIP device available (%s): librectorch_hip has no CPU path",
+              hipGetErrorString(h));
+    rtx_engine* e = new rtx_engine();
+    e->cfg = *cfg;
+    int rc = build_layers(*cfg, e->L);
+    if (rc) { delete e; return rc; }
+    e->NL = (int)e->L.size();
+    e->I = cfg->enc_dims[0];
+    e->Z = cfg->enc_dims[cfg->n_enc];
+    e->Ip = rtx_pad(e->I);
+    e->Zp = rtx_pad(e->Z);
+    e->bf16 = cfg->numerics == RTX_BF16;
+    e->vae = cfg->variant == RTX_VAE;
+    e->esz = e->bf16 ? 2 : 4;
+    e->Bp_alloc = rtx_pad_batch(cfg->max_batch);
+    const size_t Bp = e->Bp_alloc, es = e->esz;
+    size_t cacc = 0;
+#define ALLOC(ptr, bytes)                                  \
+    do {                                                   \
+        rc = dev_alloc(e, (void**)&(ptr), (bytes));        \
+        if (rc) { rtx_engine_destroy(e); return rc; }      \
+    } while (0)
+    for (int li = 0; li < e->NL; ++li) {
+        Layer& l = e->L[li];
+        ALLOC(l.Wsh, (size_t)l.outp * l.inp * es);
+        if (li > 0) ALLOC(l.WshT, (size_t)l.inp * l.outp * es);
+        ALLOC(l.A, Bp * l.inp * es);
+        ALLOC(l.AT, (size_t)l.inp * Bp * es);
+        if (li < e->NL - 1) ALLOC(l.O32, Bp * l.outp * sizeof(float));
+        ALLOC(l.D, Bp * l.outp * es);
+        ALLOC(l.DT, (size_t)l.outp * Bp * es);
+        // scratch for the forward output and the backward-data output of this layer (with split-K slabs)
+        const int m_tiles = (int)(Bp / 128);
+        if (li < e->NL - 1) {
+            const int ks = (int)((size_t)l.inp * es / 128);
+            const size_t s = choose_splits(e, m_tiles * (l.outp / 128), ks);
+            cacc = std::max(cacc, s * Bp * l.outp);
+        }
+        if (li > 0) {
+            const int ks = (int)((size_t)l.outp * es / 128);
+            const size_t s = choose_splits(e, m_tiles * (l.inp / 128), ks);
+            cacc = std::max(cacc, s * Bp * l.inp);
+        }
+    }
+    e->cacc_elems = cacc;
+    ALLOC(e->Cacc, cacc * sizeof(float));
+    ALLOC(e->Y, Bp * e->Ip * sizeof(float));
+    ALLOC(e->mu32, Bp * e->Z * sizeof(float));
+    ALLOC(e->lv32, Bp * e->Z * sizeof(float));
+    ALLOC(e->eps32, Bp * e->Z * sizeof(float));
+    ALLOC(e->tsum, Bp * sizeof(float));
+    ALLOC(e->lse, Bp * sizeof(float));
+    ALLOC(e->row_loss, Bp * sizeof(float));
+    ALLOC(e->sumsq, sizeof(float) * 2 * RTX_MAX_LAYERS * 2);
+    ALLOC(e->scratch_loss, sizeof(float) * 4);
+#undef ALLOC
+    *out = e;
+    return RTX_OK;
+}
+
+int rtx_engine_destroy(rtx_engine* e)
+{
+    if (!e) return RTX_OK;
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (auto& kv : e->sites)
+        for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    delete e;
+    return RTX_OK;
+}
+
+int32_t rtx_engine_n_tensors(const rtx_engine* e) { return e ? 2 * e->NL : 0; }
+
+int rtx_engine_tensor_shape(const rtx_engine* e, int32_t t, int32_t* rows, int32_t* cols)
+{
+    RTX_CHECK(e && t >= 0 && t < 2 * e->NL, RTX_EINVAL, "tensor index %d out of range", t);
+    const Layer& l = e->L[t / 2];
+    if (rows) *rows = l.out;
+    if (cols) *cols = (t & 1) ? 1 : l.in;
+    return RTX_OK;
+}
+
+int rtx_engine_bind(rtx_engine* e, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq)
+{
+    RTX_CHECK(e && params, RTX_EINVAL, "engine_bind: NULL argument");
+    const int n = 2 * e->NL;
+    for (int t = 0; t < n; ++t) {
+        RTX_CHECK(params[t], RTX_EINVAL, "engine_bind: params[%d] is NULL", t);
+        RTX_CHECK(((uintptr_t)params[t] & 15) == 0, RTX_EINVAL, "engine_bind: params[%d] is not 16-byte aligned", t);
+    }
+    e->params.assign(params, params + n);
+    e->can_train = grads && exp_avg && exp_avg_sq;
+    if (e->can_train) {
+        for (int t = 0; t < n; ++t) {
+            RTX_CHECK(grads[t] && exp_avg[t] && exp_avg_sq[t], RTX_EINVAL, "engine_bind: NULL grad/moment pointer for tensor %d", t);
+            RTX_CHECK((((uintptr_t)grads[t] | (uintptr_t)exp_avg[t] | (uintptr_t)exp_avg_sq[t]) & 15) == 0, RTX_EINVAL,
+                      "engine_bind: tensor %d buffers are not 16-byte aligned", t);
+        }
+        e->grads.assign(grads, grads + n);
+        e->m.assign(exp_avg, exp_avg + n);
+        e->v.assign(exp_avg_sq, exp_avg_sq + n);
+    }
+    e->bound = true;
+    e->shadows_valid = false;
+    return RTX_OK;
+}
+
+int rtx_engine_sync_shadows(rtx_engine* e, void* stream)
+{
+    RTX_TRY(check_ready(e, false));
+    hipStream_t st = (hipStream_t)stream;
+    RtxAdamArgs a = {};
+    fill_adam_tensors(e, a);
+    a.update = 0;
+    a.grad_scale = 1.f;
+    TIMED("sync_shadows");
+    RTX_TRY(rtx_launch_adam(a, e->bf16, st));
+    e->shadows_valid = true;
+    return RTX_OK;
+}
+
+// ---- forward family --------------------------------------------------------------------------------
+int rtx_engine_forward(rtx_engine* e, const rtx_batch* batch, int32_t training, const rtx_step* step, int32_t remove_train,
+                       float* logits, float* mu, float* logvar, void* stream)
+{
+    RTX_TRY(check_ready(e, false));
+    RTX_CHECK(logits, RTX_EINVAL, "forward: logits is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(ensure_shadows(e, st));
+    RtxCsrView in, tg;
+    RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
+    RTX_TRY(run_forward(e, &in, &in, batch->batch, training, step, 0, 0, e->NL, logits, e->I, mu, logvar, st));
+    if (remove_train) {
+        TIMED("neg_inf");
+        RTX_TRY(rtx_launch_neg_inf(in, batch->batch, logits, e->I, st));
+    }
+    return RTX_OK;
+}
+
+int rtx_engine_encode(rtx_engine* e, const rtx_batch* batch, int32_t training, const rtx_step* step, float* out0, float* out1,
+                      void* stream)
+{
+    RTX_TRY(check_ready(e, false));
+    RTX_CHECK(out0, RTX_EINVAL, "encode: out0 is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(ensure_shadows(e, st));
+    RtxCsrView in, tg;
+    RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
+    const int ne = e->cfg.n_enc;
+    RTX_TRY(run_forward(e, &in, &in, batch->batch, training, step, 0, 0, ne, nullptr, 0, out0, out1, st));
+    if (!e->vae) {
+        const Layer& l = e->L[ne - 1];
+        const long n = (long)batch->batch * l.out;
+        hipLaunchKernelGGL(k_unpad_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, l.O32, l.outp, batch->batch, l.out, out0);
+        RTX_HIP(hipGetLastError());
+    }
+    return RTX_OK;
+}
+
+int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logits, void* stream)
+{
+    RTX_TRY(check_ready(e, false));
+    RTX_CHECK(z && logits, RTX_EINVAL, "decode: NULL argument");
+    RTX_CHECK(batch >= 1 && batch <= e->cfg.max_batch, RTX_EINVAL, "decode: batch %d outside [1,%d]", batch, e->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(ensure_shadows(e, st));
+    const int ne = e->cfg.n_enc, Bp = rtx_pad_batch(batch);
+    Layer& l = e->L[ne];
+    const long n = (long)Bp * l.inp;
+    if (e->bf16)
+        hipLaunchKernelGGL(k_pad_convert<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, batch, l.in, (bf16_t*)l.A, l.inp, Bp);
+    else
+        hipLaunchKernelGGL(k_pad_convert<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, batch, l.in, (float*)l.A, l.inp, Bp);
+    RTX_HIP(hipGetLastError());
+    return run_forward(e, nullptr, nullptr, batch, 0, nullptr, 0, ne, e->NL, logits, e->I, nullptr, nullptr, st);
+}
+
+// ---- training --------------------------------------------------------------------------------------
+int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
+                          rtx_layer_cb cb, void* user, void* stream)
+{
+    RTX_TRY(check_ready(e, true));
+    RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(ensure_shadows(e, st));
+    RtxCsrView in, tg;
+    RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
+    const int B = batch->batch, Bp = rtx_pad_batch(B), ldt = e->Bp_alloc, NL = e->NL;
+    RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
+    // loss
+    {
+        RtxLossArgs a = {};
+        a.Y = e->Y; a.ldy = e->Ip; a.B = B; a.I = e->I; a.target = tg; a.tsum = e->tsum;
+        a.lse = e->lse; a.row_loss = e->row_loss; a.inv_batch = step->inv_batch;
+        if (e->vae) { a.mu32 = e->mu32; a.lv32 = e->lv32; a.Z = e->Z; a.beta = step->beta; }
+        TIMED("lse_loss");
+        RTX_TRY(rtx_launch_lse_loss(a, st));
+    }
+    const bool dae_reg = !e->vae && step->lam != 0.f;
+    if (dae_reg) {
+        TIMED("sumsq");
+        RTX_TRY(launch_sumsq(e, st));
+    }
+    {
+        TIMED("reduce_loss");
+        RTX_TRY(rtx_launch_reduce_loss(e->row_loss, B, step->lam, dae_reg ? e->sumsq : nullptr, 2 * NL, loss_out, loss_accum, st));
+    }
+    // d logits
+    {
+        Layer& l = e->L[NL - 1];
+        RtxPostArgs a = {};
+        a.C = e->Y; a.splits = 1; a.slab_stride = 0; a.ldc = e->Ip;
+        a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = e->I; a.Np = e->Ip;
+        a.R = l.D; a.RT = l.DT; a.lse = e->lse; a.tsum = e->tsum; a.inv_batch = step->inv_batch;
+        {
+            TIMED("dlogits");
+            RTX_TRY(rtx_launch_post(a, RTX_POST_DLOGITS, e->bf16, st));
+        }
+        TIMED("target_fixup");
+        RTX_TRY(rtx_launch_target_fixup(tg, B, step->inv_batch, l.D, e->Ip, l.DT, ldt, e->bf16, st));
+    }
+    for (int li = NL - 1; li >= 0; --li) {
+        Layer& l = e->L[li];
+        {   // weight + bias gradient: gW[out][in] = DT[outp][Bp] x AT[inp][Bp]^T ; column `in` = bias gradient
+            RtxGemm g = {};
+            g.A = l.DT; g.B = l.AT; g.lda = ldt; g.ldb = ldt;
+            g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
+            g.k_slices = (int)((size_t)Bp * e->esz / 128);
+            g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
+            g.M_real = l.out; g.N_real = l.in; g.n_major = (l.outp >= l.inp) ? 0 : 1;
+            TIMED(li == NL - 1 ? "gemm_dW_out" : (li == 0 ? "gemm_dW_in" : "gemm_dW_hidden"));
+            RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_GRAD, st));
+        }
+        if (cb) cb(li, user);
+        if (li == 0) break;
+        int splits = 1;
+        {   // data gradient: dA[Bp][inp] = D[Bp][outp] x WshT[inp][outp]^T
+            TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
+            RTX_TRY(gemm_to_cacc(e, l.D, l.outp, l.WshT, l.outp, Bp, l.inp, l.outp, &splits, st));
+        }
+        Layer& pv = e->L[li - 1];
+        if (e->vae && li == e->cfg.n_enc) {
+            RtxVaeBwdArgs a = {};
+            a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
+            a.B = B; a.Bp = Bp; a.ldt = ldt; a.Z = e->Z; a.Np = pv.outp;
+            a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32; a.training = 1;
+            a.beta = step->beta; a.inv_batch = step->inv_batch; a.D = pv.D; a.DT = pv.DT;
+            TIMED("vae_head_bwd");
+            RTX_TRY(rtx_launch_vae_bwd(a, e->bf16, st));
+        } else {
+            RtxPostArgs a = {};
+            a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
+            a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = pv.out; a.Np = pv.outp;
+            a.tanh_act = pv.tanh_act; a.O32 = pv.O32; a.R = (li - 1 > 0) ? pv.D : nullptr; a.RT = pv.DT;
+            TIMED("post_bwd");
+            RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
+        }
+    }
+    return RTX_OK;
+}
+
+int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
+{
+    RTX_TRY(check_ready(e, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "apply_adam: step count must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    RtxAdamArgs a = {};
+    fill_adam_tensors(e, a);
+    a.update = 1;
+    const double bc1 = 1.0 - pow((double)step->beta1, (double)step->step);
+    const double bc2 = 1.0 - pow((double)step->beta2, (double)step->step);
+    a.step_size = (float)((double)step->lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
+    a.grad_scale = 1.f;
+    if (!e->vae && step->lam != 0.f) { a.lam = step->lam; a.sumsq = e->sumsq; }
+    TIMED("adam");
+    RTX_TRY(rtx_launch_adam(a, e->bf16, st));
+    e->shadows_valid = true;
+    return RTX_OK;
+}
+
+int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
+                          void* stream)
+{
+    RTX_TRY(rtx_engine_loss_grads(e, batch, step, loss_out, loss_accum, nullptr, nullptr, stream));
+    return rtx_engine_apply_adam(e, step, stream);
+}
+
+int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int32_t n_items, const float* mu, const float* logvar,
+                         int32_t latent, float beta, float* loss_out, void* stream)
+{
+    RTX_CHECK(recon && x && loss_out && batch >= 1 && n_items >= 1, RTX_EINVAL, "multinomial_loss: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* row_loss = nullptr;
+    RTX_HIP(hipMallocAsync((void**)&row_loss, sizeof(float) * batch, st));
+    int rc = rtx_launch_dense_loss(recon, x, batch, n_items, (mu && logvar) ? mu : nullptr, logvar, latent, beta, 1.f / (float)batch,
+                                   row_loss, st);
+    if (!rc) rc = rtx_launch_reduce_loss(row_loss, batch, 0.f, nullptr, 0, loss_out, nullptr, st);
+    (void)hipFreeAsync(row_loss, st);
+    return rc;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------------
+int rtx_engine_set_timing(rtx_engine* e, const char* site, int32_t enable)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    if (!site) {
+        e->timing_all = enable != 0;
+        if (!enable) e->timing_sites.clear();
+    } else if (enable) {
+        e->timing_sites[site] = true;
+    } else {
+        e->timing_sites.erase(site);
+    }
+    return RTX_OK;
+}
+
+int rtx_engine_get_timings(rtx_engine* e, int32_t cap, char (*names)[48], float* total_ms, int32_t* launches, int32_t* n_out)
+{
+    RTX_CHECK(e && n_out, RTX_EINVAL, "get_timings: NULL argument");
+    RTX_HIP(hipDeviceSynchronize());
+    int n = 0;
+    for (auto& kv : e->sites) {
+        TimingSite& s = kv.second;
+        for (auto& pr : s.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                s.total_ms += ms;
+                s.launches += 1;
+            }
+            e->event_pool.push_back(pr.first);
+            e->event_pool.push_back(pr.second);
+        }
+        s.pending.clear();
+        if (n < cap && names && total_ms && launches) {
+            strncpy(names[n], kv.first.c_str(), 47);
+            names[n][47] = 0;
+            total_ms[n] = (float)s.total_ms;
+            launches[n] = s.launches;
+            ++n;
+        }
+        s.total_ms = 0;
+        s.launches = 0;
+    }
+    *n_out = n;
+    return RTX_OK;
+}
+
+int rtx_engine_step_cost(const rtx_engine* e, int32_t batch, double* hbm_bytes, double* flops)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    // bytes = 38*P + 12*B*I  (fp32 master params + Adam state, logits written once and read twice)
+    //               flops = forward 2*sum(in*out) + weight grads 2*sum(in*out) + data grads 2*sum_{l>0}(in*out), per user
+    double P = 0, f_all = 0, f_rest = 0;
+    for (int li = 0; li < e->NL; ++li) {
+        const double w = (double)e->L[li].in * e->L[li].out;
+        P += w + e->L[li].out;
+        f_all += w;
+        if (li > 0) f_rest += w;
+    }
+    if (hbm_bytes) *hbm_bytes = 38.0 * P + 12.0 * (double)batch * e->I;
+    if (flops) *flops = (double)batch * 2.0 * (2.0 * f_all + f_rest);
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,794 @@
+// kernels.hip -- the non-GEMM kernels of the Mult-VAE / Mult-DAE step for gfx950 (HBM-bound work):
+// sparse-row gather (K1), activation/transposition post kernels, VAE head, multinomial loss, dlogits,
+// fused multi-tensor Adam with shadow refresh, dense<->CSR conversions.  Wave = 64 lanes throughout.
+#include "rtx_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for 256-thread blocks; red must hold >= 4 floats; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* dst, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* dst, float a, float b, float c, float d)
+{
+    *(float4*)dst = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d)
+{
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    u.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    *(uint2*)dst = u;
+}
+
+__device__ __forceinline__ int64_t csr_row(const RtxCsrView& v, int b) { return v.row_ids ? (int64_t)v.row_ids[b] : (int64_t)b; }
+
+// ------------------------------------------------------------------------------------------------
+// K1: gather.  One workgroup per (padded) batch row.  The row's stored entries are read coalesced
+// from the CSR arrays, normalised (F.normalize), dropped out, scattered into an LDS image of a chunk of
+// the dense row, and the chunk is streamed to HBM with 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+#define RTX_GATHER_CHUNK 4096  // elements per LDS chunk (16 KB fp32 / 8 KB bf16)
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
+{
+    __shared__ __attribute__((aligned(16))) T row[RTX_GATHER_CHUNK];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    T* X = (T*)a.X + (size_t)b * a.ldx;
+    T* XT = (T*)a.XT;
+    if (b >= a.B) {  // padding row of the batch: zeros (it multiplies nothing that is kept)
+        for (int i = tid * 4; i < a.ldx; i += 256 * 4) store4<T>(X + i, 0.f, 0.f, 0.f, 0.f);
+        if (tid == 0) a.tsum[b] = 0.f;
+        return;
+    }
+    const int64_t u = csr_row(a.in, b);
+    const int64_t beg = a.in.indptr[u], end = a.in.indptr[u + 1];
+    // ||x||_2 over the stored entries (F.normalize: x / max(||x||, 1e-12))
+    float ss = 0.f;
+    for (int64_t k = beg + tid; k < end; k += 256) {
+        const float v = a.in.values ? a.in.values[k] : 1.f;
+        ss += v * v;
+    }
+    ss = block_sum(ss, red);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    // s_b = sum of the TARGET row
+    {
+        const int64_t ut = csr_row(a.target, b);
+        const int64_t tb = a.target.indptr[ut], te = a.target.indptr[ut + 1];
+        float ts = 0.f;
+        for (int64_t k = tb + tid; k < te; k += 256) ts += a.target.values ? a.target.values[k] : 1.f;
+        ts = block_sum(ts, red);
+        if (tid == 0) a.tsum[b] = ts;
+    }
+    const bool drop = a.training && a.dropout_p > 0.f;
+    const float scale = drop ? (a.dropout_p < 1.f ? 1.f / (1.f - a.dropout_p) : 0.f) : 1.f;
+    for (int c0 = 0; c0 < a.ldx; c0 += RTX_GATHER_CHUNK) {
+        const int cn = min(RTX_GATHER_CHUNK, a.ldx - c0);
+        for (int i = tid * 4; i < cn; i += 256 * 4) store4<T>(row + i, 0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        for (int64_t k = beg + tid; k < end; k += 256) {
+            const int i = a.in.indices[k];
+            if (i >= c0 && i < c0 + cn) {
+                float v = (a.in.values ? a.in.values[k] : 1.f) * inv;
+                if (drop) {
+                    const uint64_t e = (uint64_t)b * (uint64_t)a.I + (uint64_t)i;
+                    const bool keep = a.mask ? (a.mask[e] != 0) : rtx_dropout_keep(a.seed, a.offset, e, a.dropout_p);
+                    v = keep ? v * scale : 0.f;
+                }
+                const T t = Elem<T>::from(v);
+                row[i - c0] = t;
+                if (XT) XT[(size_t)i * a.ldt + b] = t;
+            }
+        }
+        __syncthreads();
+        if (sizeof(T) == 2) {
+            for (int i = tid * 8; i < cn; i += 256 * 8) *(uint4*)(X + c0 + i) = *(const uint4*)(row + i);
+        } else {
+            for (int i = tid * 4; i < cn; i += 256 * 4) *(uint4*)(X + c0 + i) = *(const uint4*)(row + i);
+        }
+        __syncthreads();
+    }
+    if (XT && tid == 0) XT[(size_t)a.I * a.ldt + b] = Elem<T>::from(1.f);  // ones row -> bias gradient
+}
+
+int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream)
+{
+    RTX_CHECK(a.ldx % 8 == 0, RTX_EINVAL, "gather: ldx must be a multiple of 8");
+    if (is_bf16)
+        hipLaunchKernelGGL(k_gather<bf16_t>, dim3(a.Bp), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_gather<float>, dim3(a.Bp), dim3(256), 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// DataSampler densify (samplers.py:99-105): rows -> float32 [B][I], ld = I (arbitrary alignment)
+__global__ __launch_bounds__(256) void k_csr_to_dense(const RtxCsrView v, int I, float* out)
+{
+    __shared__ float row[RTX_GATHER_CHUNK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t u = csr_row(v, b);
+    const int64_t beg = v.indptr[u], end = v.indptr[u + 1];
+    float* o = out + (size_t)b * I;
+    for (int c0 = 0; c0 < I; c0 += RTX_GATHER_CHUNK) {
+        const int cn = min(RTX_GATHER_CHUNK, I - c0);
+        for (int i = tid; i < cn; i += 256) row[i] = 0.f;
+        __syncthreads();
+        for (int64_t k = beg + tid; k < end; k += 256) {
+            const int i = v.indices[k];
+            if (i >= c0 && i < c0 + cn) row[i - c0] = v.values ? v.values[k] : 1.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < cn; i += 256) o[c0 + i] = row[i];
+        __syncthreads();
+    }
+}
+
+int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipStream_t stream)
+{
+    if (B <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_csr_to_dense, dim3(B), dim3(256), 0, stream, v, I, out);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// post kernels: TB x 64 tiles (TB batch rows, 64 features) of an fp32 [Bp][*] matrix -> T row-major and
+// T transposed, through LDS so both orientations are written in contiguous pieces.  TB = 64 for the
+// [B, n_items] logits gradient (full 128-B runs in the transposed image), TB = 16 for the small hidden
+// activations (4x more workgroups: these kernels are latency-, not bandwidth-bound).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TB>
+__device__ __forceinline__ void tile_write_transposed(const float (*tile)[65], T* __restrict__ RT, int ldt, int b0, int n0, int tid,
+                                                      int ones_n, int B)
+{
+    constexpr int EPT = TB / 4;  // consecutive batch entries per thread
+    const int nl = tid >> 2, bq = (tid & 3) * EPT;
+    T* dst = RT + (size_t)(n0 + nl) * ldt + b0 + bq;
+    float v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) v[e] = tile[bq + e][nl];
+    if (n0 + nl == ones_n) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) v[e] = (b0 + bq + e < B) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e += 4) store4<T>(dst + e, v[e], v[e + 1], v[e + 2], v[e + 3]);
+}
+
+template <typename T, int MODE, int TB>
+__global__ __launch_bounds__(256) void k_post(const RtxPostArgs a)
+{
+    __shared__ float tile[TB][65];
+    constexpr int NP = TB / 16;  // passes: 16 rows x 64 columns (float4 per thread) each
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * TB;
+    const int nl = (tid & 15) * 4, n = n0 + nl;
+    const float* __restrict__ C = a.C;
+    float4 c[NP];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) c[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // split-K slabs: keep NP * 4 independent 16-byte loads in flight per thread
+#pragma unroll 4
+    for (int s = 0; s < a.splits; ++s) {
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
+            const int b = b0 + pass * 16 + (tid >> 4);
+            const float4 t = *(const float4*)(C + (size_t)s * a.slab_stride + (size_t)b * a.ldc + n);
+            c[pass].x += t.x; c[pass].y += t.y; c[pass].z += t.z; c[pass].w += t.w;
+        }
+    }
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int bl = pass * 16 + (tid >> 4);
+        const int b = b0 + bl;
+        float v[4] = {c[pass].x, c[pass].y, c[pass].z, c[pass].w};
+        if (MODE == RTX_POST_BWD && a.tanh_act) {
+            const float4 o = *(const float4*)(a.O32 + (size_t)b * a.Np + n);
+            v[0] *= (1.f - o.x * o.x); v[1] *= (1.f - o.y * o.y);
+            v[2] *= (1.f - o.z * o.z); v[3] *= (1.f - o.w * o.w);
+        }
+        float lse = 0.f, sc = 0.f;
+        if (MODE == RTX_POST_DLOGITS && b < a.B) {
+            lse = a.lse[b];
+            sc = a.tsum[b] * a.inv_batch;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = (b < a.B) && (n + e < a.N_real);
+            float x = v[e];
+            if (MODE == RTX_POST_FWD) {
+                if (valid) {
+                    x += a.bias[n + e];
+                    if (a.tanh_act) x = tanhf(x);
+                }
+            } else if (MODE == RTX_POST_DLOGITS) {
+                x = valid ? sc * __expf(x - lse) : 0.f;
+            }
+            v[e] = valid ? x : 0.f;
+            tile[bl][nl + e] = v[e];
+        }
+        if (MODE == RTX_POST_FWD && a.O32) *(float4*)(a.O32 + (size_t)b * a.Np + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.R) store4<T>((T*)a.R + (size_t)b * a.Np + n, v[0], v[1], v[2], v[3]);
+    }
+    if (a.RT) {
+        __syncthreads();
+        tile_write_transposed<T, TB>(tile, (T*)a.RT, a.ldt, b0, n0, tid, (MODE == RTX_POST_FWD && a.ones_row) ? a.N_real : -1, a.B);
+    }
+}
+
+int rtx_launch_post(const RtxPostArgs& a, int mode, int is_bf16, hipStream_t stream)
+{
+    RTX_CHECK(a.Np % 64 == 0 && a.Bp % 64 == 0 && a.ldc % 4 == 0, RTX_EINVAL, "post: bad padding");
+    const dim3 block(256);
+#define RTX_P(T, M, TB) hipLaunchKernelGGL((k_post<T, M, TB>), dim3(a.Np / 64, a.Bp / TB), block, 0, stream, a)
+    if (is_bf16) {
+        if (mode == RTX_POST_FWD) RTX_P(bf16_t, RTX_POST_FWD, 16);
+        else if (mode == RTX_POST_BWD) RTX_P(bf16_t, RTX_POST_BWD, 16);
+        else RTX_P(bf16_t, RTX_POST_DLOGITS, 64);
+    } else {
+        if (mode == RTX_POST_FWD) RTX_P(float, RTX_POST_FWD, 16);
+        else if (mode == RTX_POST_BWD) RTX_P(float, RTX_POST_BWD, 16);
+        else RTX_P(float, RTX_POST_DLOGITS, 64);
+    }
+#undef RTX_P
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VAE head.  forward: [mu | logvar] = C + b ; z = mu + eps * exp(logvar / 2)  (eval: z = mu)
+//            backward: dmu = dz + beta*mu/B ; dlogvar = dz*eps*std/2 + beta*(exp(logvar)-1)/(2B)
+// 16 x 64 tiles, 4 elements per thread; all loads of a thread are issued before the first use.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_vae_fwd(const RtxVaeFwdArgs a)
+{
+    __shared__ float tile[16][65];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const float* __restrict__ C = a.C;
+    const int jl = tid & 63, j = j0 + jl;
+    float m[4], lv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = b0 + k * 4 + (tid >> 6);
+        m[k] = 0.f; lv[k] = 0.f;
+        if (b < a.B && j < a.Z) {
+            for (int s = 0; s < a.splits; ++s) {
+                const float* c = C + (size_t)s * a.slab_stride + (size_t)b * a.ldc;
+                m[k] += c[j];
+                lv[k] += c[a.Z + j];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int bl = k * 4 + (tid >> 6), b = b0 + bl;
+        float z = 0.f;
+        if (b < a.B && j < a.Z) {
+            const float mm = m[k] + a.bias[j], l = lv[k] + a.bias[a.Z + j];
+            float eps = 0.f;
+            if (a.training)
+                eps = a.eps_in ? a.eps_in[(size_t)b * a.Z + j] : rtx_normal(a.seed, a.offset, (uint64_t)b * a.Z + j);
+            z = a.training ? mm + eps * expf(0.5f * l) : mm;
+            const size_t o = (size_t)b * a.Z + j;
+            a.mu32[o] = mm;
+            a.lv32[o] = l;
+            a.eps32[o] = eps;
+            if (a.mu_out) a.mu_out[o] = mm;
+            if (a.lv_out) a.lv_out[o] = l;
+        }
+        tile[bl][jl] = z;
+        ((T*)a.Zr)[(size_t)b * a.Zp + j] = Elem<T>::from(z);
+    }
+    __syncthreads();
+    tile_write_transposed<T, 16>(tile, (T*)a.ZT, a.ldt, b0, j0, tid, a.Z, a.B);
+}
+
+int rtx_launch_vae_fwd(const RtxVaeFwdArgs& a, int is_bf16, hipStream_t stream)
+{
+    const dim3 grid(a.Zp / 64, a.Bp / 16), block(256);
+    if (is_bf16)
+        hipLaunchKernelGGL(k_vae_fwd<bf16_t>, grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_vae_fwd<float>, grid, block, 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_vae_bwd(const RtxVaeBwdArgs a)
+{
+    __shared__ float tile[16][65];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const float* __restrict__ C = a.C;
+    const int nl = tid & 63, n = n0 + nl;
+    const int j = (n < a.Z) ? n : n - a.Z;
+    float dz[4], mu[4], lv[4], ep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = b0 + k * 4 + (tid >> 6);
+        dz[k] = 0.f; mu[k] = 0.f; lv[k] = 0.f; ep[k] = 0.f;
+        if (b < a.B && n < 2 * a.Z) {
+            for (int s = 0; s < a.splits; ++s) dz[k] += C[(size_t)s * a.slab_stride + (size_t)b * a.ldc + j];
+            const size_t o = (size_t)b * a.Z + j;
+            mu[k] = a.mu32[o]; lv[k] = a.lv32[o]; ep[k] = a.eps32[o];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int bl = k * 4 + (tid >> 6), b = b0 + bl;
+        float d = 0.f;
+        if (b < a.B && n < 2 * a.Z) {
+            if (n < a.Z) {
+                d = dz[k] + a.beta * mu[k] * a.inv_batch;
+            } else {
+                d = a.beta * 0.5f * (expf(lv[k]) - 1.f) * a.inv_batch;
+                if (a.training) d += dz[k] * ep[k] * 0.5f * expf(0.5f * lv[k]);
+            }
+        }
+        tile[bl][nl] = d;
+        ((T*)a.D)[(size_t)b * a.Np + n] = Elem<T>::from(d);
+    }
+    __syncthreads();
+    tile_write_transposed<T, 16>(tile, (T*)a.DT, a.ldt, b0, n0, tid, -1, a.B);
+}
+
+int rtx_launch_vae_bwd(const RtxVaeBwdArgs& a, int is_bf16, hipStream_t stream)
+{
+    const dim3 grid(a.Np / 64, a.Bp / 16), block(256);
+    if (is_bf16)
+        hipLaunchKernelGGL(k_vae_bwd<bf16_t>, grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_vae_bwd<float>, grid, block, 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multinomial log-likelihood: per row  lse_b = logsumexp(Y_b) ;  row_loss_b = (s_b*lse_b - <t_b,Y_b>)/B
+//  (+ beta * KL_b / B for the VAE).   One workgroup per user, online max/sum, float4 reads.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void online_add(float& m, float& s, float x)
+{
+    if (x > m) {
+        s = s * __expf(m - x) + 1.f;
+        m = x;
+    } else {
+        s += __expf(x - m);
+    }
+}
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2)
+{
+    const float mm = fmaxf(m, m2);
+    if (mm == -INFINITY) { m = mm; s = 0.f; return; }
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+}
+
+// block-wide logsumexp of row y[0..I) (y 16-byte aligned); scratch: >= 8 floats
+__device__ float block_lse(const float* y, int I, float* red)
+{
+    const int tid = threadIdx.x;
+    float m = -INFINITY, s = 0.f;
+    const int I4 = I & ~3;
+    for (int i = tid * 4; i < I4; i += 256 * 4) {
+        const float4 t = *(const float4*)(y + i);
+        online_add(m, s, t.x); online_add(m, s, t.y); online_add(m, s, t.z); online_add(m, s, t.w);
+    }
+    for (int i = I4 + tid; i < I; i += 256) online_add(m, s, y[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        online_merge(m, s, m2, s2);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = s; }
+    __syncthreads();
+    float M = red[0], S = red[4];
+    online_merge(M, S, red[1], red[5]);
+    online_merge(M, S, red[2], red[6]);
+    online_merge(M, S, red[3], red[7]);
+    return M + logf(S);
+}
+
+__global__ __launch_bounds__(256) void k_lse_loss(const RtxLossArgs a)
+{
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* y = a.Y + (size_t)b * a.ldy;
+    const float lse = block_lse(y, a.I, red);
+    const int64_t u = csr_row(a.target, b);
+    float dot = 0.f;
+    for (int64_t k = a.target.indptr[u] + tid; k < a.target.indptr[u + 1]; k += 256)
+        dot += (a.target.values ? a.target.values[k] : 1.f) * y[a.target.indices[k]];
+    dot = block_sum(dot, red);
+    float kl = 0.f;
+    if (a.mu32) {
+        for (int j = tid; j < a.Z; j += 256) {
+            const float m = a.mu32[(size_t)b * a.Z + j], lv = a.lv32[(size_t)b * a.Z + j];
+            kl += 1.f + lv - m * m - expf(lv);
+        }
+        kl = block_sum(kl, red);
+    }
+    if (tid == 0) {
+        a.lse[b] = lse;
+        a.row_loss[b] = (a.tsum[b] * lse - dot) * a.inv_batch + a.beta * (-0.5f * kl) * a.inv_batch;
+    }
+}
+
+int rtx_launch_lse_loss(const RtxLossArgs& a, hipStream_t stream)
+{
+    if (a.B <= 0) return RTX_OK;
+    RTX_CHECK(a.ldy % 4 == 0, RTX_EINVAL, "lse: ldy must be a multiple of 4");
+    hipLaunchKernelGGL(k_lse_loss, dim3(a.B), dim3(256), 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int nt,
+                                                     float* loss_out, float* loss_accum)
+{
+    __shared__ float red[4];
+    // fixed summation order -> bit-reproducible loss for a given batch
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) s += row_loss[b];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        if (sumsq)
+            for (int t = 0; t < nt; ++t) s += lam * sqrtf(sumsq[t]);
+        if (loss_out) loss_out[0] = s;
+        if (loss_accum) loss_accum[0] += s;
+    }
+}
+
+int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int n_tensors, float* loss_out,
+                           float* loss_accum, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_reduce_loss, dim3(1), dim3(256), 0, stream, row_loss, B, lam, sumsq, n_tensors, loss_out, loss_accum);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_target_fixup(const RtxCsrView t, float inv_batch, T* D, int ldd, T* DT, int ldt)
+{
+    const int b = blockIdx.x;
+    const int64_t u = csr_row(t, b);
+    for (int64_t k = t.indptr[u] + threadIdx.x; k < t.indptr[u + 1]; k += 256) {
+        const int i = t.indices[k];
+        const float val = t.values ? t.values[k] : 1.f;
+        const size_t o = (size_t)b * ldd + i;
+        const T nv = Elem<T>::from(Elem<T>::to(D[o]) - val * inv_batch);
+        D[o] = nv;
+        DT[(size_t)i * ldt + b] = nv;
+    }
+}
+
+int rtx_launch_target_fixup(const RtxCsrView& target, int B, float inv_batch, void* D, int ldd, void* DT, int ldt,
+                            int is_bf16, hipStream_t stream)
+{
+    if (B <= 0) return RTX_OK;
+    if (is_bf16)
+        hipLaunchKernelGGL(k_target_fixup<bf16_t>, dim3(B), dim3(256), 0, stream, target, inv_batch, (bf16_t*)D, ldd, (bf16_t*)DT, ldt);
+    else
+        hipLaunchKernelGGL(k_target_fixup<float>, dim3(B), dim3(256), 0, stream, target, inv_batch, (float*)D, ldd, (float*)DT, ldt);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_neg_inf(const RtxCsrView v, float* logits, long ld)
+{
+    const int b = blockIdx.x;
+    const int64_t u = csr_row(v, b);
+    for (int64_t k = v.indptr[u] + threadIdx.x; k < v.indptr[u + 1]; k += 256) {
+        const float val = v.values ? v.values[k] : 1.f;
+        if (val != 0.f) logits[(size_t)b * ld + v.indices[k]] = -INFINITY;
+    }
+}
+
+int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, hipStream_t stream)
+{
+    if (B <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_neg_inf, dim3(B), dim3(256), 0, stream, in, logits, ld);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// loss_function(recon_x, x, mu, logvar, beta) on dense tensors (reference models.py:813-815)
+__global__ __launch_bounds__(256) void k_dense_loss(const float* Y, const float* X, int I, const float* mu, const float* lv, int Z,
+                                                    float beta, float inv_batch, float* row_loss)
+{
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* y = Y + (size_t)b * I;
+    const float* x = X + (size_t)b * I;
+    // rows of an [B][I] tensor are not 16-byte aligned in general: scalar online pass
+    float m = -INFINITY, s = 0.f, dot = 0.f, sx = 0.f;
+    for (int i = tid; i < I; i += 256) {
+        const float yi = y[i], xi = x[i];
+        online_add(m, s, yi);
+        dot += xi * yi;
+        sx += xi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        online_merge(m, s, m2, s2);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = s; }
+    __syncthreads();
+    float M = red[0], S = red[4];
+    online_merge(M, S, red[1], red[5]);
+    online_merge(M, S, red[2], red[6]);
+    online_merge(M, S, red[3], red[7]);
+    const float lse = M + logf(S);
+    dot = block_sum(dot, red);
+    sx = block_sum(sx, red);
+    float kl = 0.f;
+    if (mu) {
+        for (int j = tid; j < Z; j += 256) {
+            const float mm = mu[(size_t)b * Z + j], l = lv[(size_t)b * Z + j];
+            kl += 1.f + l - mm * mm - expf(l);
+        }
+        kl = block_sum(kl, red);
+    }
+    if (tid == 0) row_loss[b] = (sx * lse - dot) * inv_batch + beta * (-0.5f * kl) * inv_batch;
+}
+
+int rtx_launch_dense_loss(const float* Y, const float* X, int B, int I, const float* mu, const float* lv, int Z, float beta,
+                          float inv_batch, float* row_loss, hipStream_t stream)
+{
+    if (B <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_dense_loss, dim3(B), dim3(256), 0, stream, Y, X, I, mu, lv, Z, beta, inv_batch, row_loss);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense [B][I] float32 -> CSR (stored entries = non-zeros, column order preserved)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_count(const float* X, int I, int32_t* counts)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float c = 0.f;
+    for (int i = threadIdx.x; i < I; i += 256) c += (X[(size_t)b * I + i] != 0.f) ? 1.f : 0.f;
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) counts[b] = (int32_t)c;
+}
+
+__global__ void k_scan_counts(const int32_t* counts, int B, int64_t* indptr)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t acc = 0;
+        indptr[0] = 0;
+        for (int b = 0; b < B; ++b) {
+            acc += counts[b];
+            indptr[b + 1] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dense_fill(const float* X, int I, const int64_t* indptr, int32_t* indices, float* values)
+{
+    __shared__ int wave_cnt[4];
+    __shared__ int base_sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    const int64_t out0 = indptr[b];
+    for (int c0 = 0; c0 < I; c0 += 256) {
+        const int i = c0 + tid;
+        const float v = (i < I) ? X[(size_t)b * I + i] : 0.f;
+        const bool nz = v != 0.f;
+        const unsigned long long bal = __ballot(nz);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+        const int base = base_sh;
+        if (nz) {
+            const int64_t o = out0 + base + woff + before;
+            indices[o] = i;
+            values[o] = v;
+        }
+        __syncthreads();
+        if (tid == 0) base_sh = base + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+int rtx_launch_dense_count(const float* X, int B, int I, int32_t* counts, hipStream_t stream)
+{
+    if (B <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_dense_count, dim3(B), dim3(256), 0, stream, X, I, counts);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+int rtx_launch_scan_counts(const int32_t* counts, int B, int64_t* indptr, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(64), 0, stream, counts, B, indptr);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+int rtx_launch_dense_fill(const float* X, int B, int I, const int64_t* indptr, int32_t* indices, float* values, hipStream_t stream)
+{
+    if (B <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_dense_fill, dim3(B), dim3(256), 0, stream, X, I, indptr, indices, values);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-tensor Adam (torch.optim.Adam, amsgrad off, coupled weight decay) + refresh of the
+// compute-precision shadows in both orientations.  One launch for all tensors: 64x64 tiles.
+//   HBM per parameter: read p,g,m,v (16 B) + write p,m,v (12 B) + shadows.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
+{
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    int ti = 0;
+#pragma unroll 1
+    for (int k = 1; k < a.n; ++k)
+        if ((int)blockIdx.x >= a.t[k].tile_start) ti = k;
+    const RtxAdamTensor& t = a.t[ti];
+    const int local = blockIdx.x - t.tile_start;
+    const int tiles_c = (t.cols + 63) / 64;
+    const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+    float reg = 0.f;
+    if (a.lam != 0.f && a.sumsq) {
+        const float nrm = sqrtf(a.sumsq[ti]);
+        reg = nrm > 0.f ? a.lam / nrm : 0.f;
+    }
+    const int cl = (tid & 15) * 4;
+    const bool vec = (t.cols & 3) == 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int rl = pass * 16 + (tid >> 4);
+        const int r = r0 + rl, c = c0 + cl;
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < t.rows && c < t.cols) {
+            const size_t o = (size_t)r * t.cols + c;
+            const int nv = min(4, t.cols - c);
+            float gv[4], mv[4], vv[4];
+            if (vec) {
+                const float4 p4 = *(const float4*)(t.p + o);
+                pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
+                if (a.update) {
+                    const float4 g4 = *(const float4*)(t.g + o), m4 = *(const float4*)(t.m + o), v4 = *(const float4*)(t.v + o);
+                    gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+                    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+                    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+                }
+            } else {
+                for (int e = 0; e < nv; ++e) {
+                    pv[e] = t.p[o + e];
+                    if (a.update) { gv[e] = t.g[o + e]; mv[e] = t.m[o + e]; vv[e] = t.v[o + e]; }
+                }
+            }
+            if (a.update) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e < nv) {
+                        float g = gv[e] * a.grad_scale + reg * pv[e];
+                        if (a.weight_decay != 0.f) g += a.weight_decay * pv[e];
+                        const float m = mv[e] + (g - mv[e]) * (1.f - a.beta1);
+                        const float v = vv[e] * a.beta2 + (1.f - a.beta2) * g * g;
+                        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+                        pv[e] = pv[e] - a.step_size * (m / denom);
+                        mv[e] = m;
+                        vv[e] = v;
+                    }
+                }
+                if (vec) {
+                    *(float4*)(t.p + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    *(float4*)(t.m + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                    *(float4*)(t.v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                } else {
+                    for (int e = 0; e < nv; ++e) { t.p[o + e] = pv[e]; t.m[o + e] = mv[e]; t.v[o + e] = vv[e]; }
+                }
+            }
+            if (t.sh) {
+                T* s = (T*)t.sh + (size_t)r * t.ld_sh + c;  // ld_sh is a multiple of 128 -> aligned
+                if (nv == 4) store4<T>(s, pv[0], pv[1], pv[2], pv[3]);
+                else for (int e = 0; e < nv; ++e) s[e] = Elem<T>::from(pv[e]);
+            }
+        }
+        if (t.shT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[rl][cl + e] = (r < t.rows && c + e < t.cols) ? pv[e] : 0.f;
+        }
+    }
+    if (t.shT) {
+        __syncthreads();
+        // transposed shadow [cols_p][ld_shT]: thread -> column c0+nl, 16 consecutive rows
+        const int nl = tid >> 2, rq = (tid & 3) * 16;
+        if (c0 + nl < t.cols) {
+            T* dst = (T*)t.shT + (size_t)(c0 + nl) * t.ld_shT + r0 + rq;
+            if (r0 + rq + 16 <= t.rows) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 4)
+                    store4<T>(dst + e, tile[rq + e][nl], tile[rq + e + 1][nl], tile[rq + e + 2][nl], tile[rq + e + 3][nl]);
+            } else {
+                for (int e = 0; e < 16; ++e)
+                    if (r0 + rq + e < t.rows) dst[e] = Elem<T>::from(tile[rq + e][nl]);
+            }
+        }
+    }
+}
+
+int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
+{
+    RTX_CHECK(a.n > 0 && a.n <= RTX_MAX_TENSORS, RTX_EINVAL, "adam: bad tensor count %d", a.n);
+    int tiles = 0;
+    for (int k = 0; k < a.n; ++k) {
+        a.t[k].tile_start = tiles;
+        tiles += ((a.t[k].rows + 63) / 64) * ((a.t[k].cols + 63) / 64);
+    }
+    if (tiles == 0) return RTX_OK;
+    if (is_bf16)
+        hipLaunchKernelGGL(k_adam<bf16_t>, dim3(tiles), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_adam<float>, dim3(tiles), dim3(256), 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// sum of squares of each parameter tensor (Mult-DAE's lam * sum_W ||W||_2, models.py:702-706)
+__global__ __launch_bounds__(256) void k_sumsq(const float* p, long n, float* out)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += p[i] * p[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, float* sumsq, hipStream_t stream)
+{
+    RTX_HIP(hipMemsetAsync(sumsq, 0, sizeof(float) * n, stream));
+    for (int t = 0; t < n; ++t) {
+        const int blocks = (int)((sizes[t] + 256 * 16 - 1) / (256 * 16));
+        hipLaunchKernelGGL(k_sumsq, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(256), 0, stream, params_host[t],
+                           sizes[t], sumsq + t);
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}

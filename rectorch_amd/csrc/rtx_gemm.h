@@ -1,0 +1,41 @@
+// rtx_gemm.h -- the one MFMA GEMM of the Mult-VAE/DAE path (gfx950).
+//
+//   C[m][n] = sum_k A[m][k] * B[n][k]            ("NT": both operands K-contiguous)
+//
+// Every contraction of the training step is expressed in this form by keeping the operands in the
+// layouts it wants (engine.hip): forward  Act[B,in]  x W[out,in];  backward-data  dOut[B,out] x W^T[in,out];
+// weight gradient  dOut^T[out,B] x Act^T[in,B].  Operand buffers are zero-padded to multiples of the
+// 128x128 tile (rtx_pad), so the main loop carries no bounds checks.
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA 32x32 blocks).
+// K is consumed in 128-BYTE slices per row (64 bf16 / 32 f32): global -> registers (16 B per lane,
+// 8 lanes cover one 128-B row segment) -> LDS (144-B row stride: 16-B pad makes the ds_read_b128
+// fragment reads conflict-free) -> MFMA.  Double-buffered LDS, one barrier per slice.
+//   bf16 : v_mfma_f32_32x32x16_bf16  (8 bf16 per lane per operand = one ds_read_b128)
+//   f32  : v_mfma_f32_32x32x2_f32    (one ds_read_b128 feeds 4 MFMAs; exact f32, parity mode)
+#pragma once
+#include "rtx_common.h"
+
+enum RtxEpilogue {
+    RTX_EPI_STORE = 0,   // C (fp32) [M_pad][ldc] (+ split * slab_stride): raw accumulators, unguarded
+    RTX_EPI_BIAS_ROWS = 1,  // C[m][n] = acc + bias[n] for m < M_real, n < N_real (ldc arbitrary): logits
+    RTX_EPI_GRAD = 2,    // gW[m * N_real + n] = acc (m < M_real, n < N_real); gb[m] = acc at n == N_real
+};
+
+struct RtxGemm {
+    const void* A;       // [M_pad][lda] elements of T
+    const void* B;       // [N_pad][ldb]
+    long lda, ldb;       // leading dimensions in elements
+    int m_tiles, n_tiles;
+    int k_slices;        // total 128-byte K slices  (= K_pad * sizeof(T) / 128)
+    int splits;          // split-K factor (grid.y); only with RTX_EPI_STORE
+    float* C;
+    long ldc;
+    long slab_stride;    // elements between split-K slabs
+    const float* bias;   // RTX_EPI_BIAS_ROWS
+    float* gbias;        // RTX_EPI_GRAD (nullable)
+    int M_real, N_real;
+    int n_major;         // 0: blockIdx.x walks m fastest, 1: n fastest
+};
+
+int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t stream);

@@ -1,0 +1,154 @@
+// rtx_kernels.h -- launchers of the non-GEMM kernels of the Mult-VAE/DAE step (kernels.hip).
+// All pointers are device pointers; every launcher enqueues on `stream` and returns RTX_OK / RTX_E*.
+#pragma once
+#include "rtx_common.h"
+
+// A batch of users as rows of a CSR matrix resident in HBM.  Batch row b is CSR row
+// (row_ids ? row_ids[b] : b).  values == NULL means every stored entry is 1.0 (implicit feedback).
+struct RtxCsrView {
+    const int64_t* indptr;
+    const int32_t* indices;
+    const float* values;
+    const int32_t* row_ids;
+};
+
+// ---- K1: sparse user rows -> dense normalised (+dropout) input, both orientations ------------------
+//   X  [Bp][ldx]  row-major   (forward A operand; rows >= B are written as zeros)
+//   XT [P(I)][ldt] transposed (weight-gradient B operand; caller memsets it, the kernel scatters the
+//                  non-zeros and sets row I to ones for b < B -> bias gradient column)
+//   tsum[b] = sum of the TARGET row's values (s_b of the multinomial likelihood)
+struct RtxGatherArgs {
+    RtxCsrView in, target;
+    int B, Bp, I, ldx, ldt;
+    void* X;
+    void* XT;
+    float* tsum;
+    int training;
+    float dropout_p;
+    const uint8_t* mask;  // [B][I] injected keep-mask (nullable -> Philox)
+    uint64_t seed, offset;
+};
+int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream);
+
+// DataSampler densify: rows -> float32 [B][I] (ld = I), optional second matrix
+int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipStream_t stream);
+
+// ---- post kernels: fp32 GEMM output (possibly split-K slabs) -> activations in the layouts the next
+//      GEMMs want.  Tiles of 64x64 go through LDS so both orientations are written coalesced. ---------
+enum { RTX_POST_FWD = 0, RTX_POST_BWD = 1, RTX_POST_DLOGITS = 2 };
+struct RtxPostArgs {
+    const float* C;     // [splits][Bp][ldc]
+    int splits;
+    long slab_stride;
+    int ldc;
+    int B, Bp;          // valid / padded batch rows processed by this call
+    int ldt;            // leading dimension (allocated padded batch) of the transposed output
+    int N_real, Np;     // valid / padded feature columns
+    int tanh_act;
+    const float* bias;  // FWD
+    float* O32;         // FWD: post-activation fp32 [Bp][Np] (nullable); BWD: input (the saved activation)
+    void* R;            // row-major output  T [Bp][Np]   (nullable)
+    void* RT;           // transposed output T [Np][Bp]   (nullable)
+    int ones_row;       // FWD: write ones (b < B) into RT row N_real
+    const float* lse;   // DLOGITS
+    const float* tsum;  // DLOGITS
+    float inv_batch;    // DLOGITS
+};
+int rtx_launch_post(const RtxPostArgs& a, int mode, int is_bf16, hipStream_t stream);
+
+// ---- VAE head -------------------------------------------------------------------------------------
+struct RtxVaeFwdArgs {
+    const float* C;  // [splits][Bp][ldc], columns [0,Z) = mu, [Z,2Z) = logvar (pre-bias)
+    int splits;
+    long slab_stride;
+    int ldc;
+    int B, Bp, ldt, Z, Zp;
+    const float* bias;   // [2Z]
+    float* mu32;         // [Bp][Z] engine copies for the backward
+    float* lv32;
+    float* eps32;
+    float* mu_out;       // [B][Z] user outputs (nullable)
+    float* lv_out;
+    void* Zr;            // T [Bp][Zp]
+    void* ZT;            // T [Zp][Bp], row Z = ones
+    int training;
+    const float* eps_in; // [B][Z] injected (nullable -> Philox)
+    uint64_t seed, offset;
+};
+int rtx_launch_vae_fwd(const RtxVaeFwdArgs& a, int is_bf16, hipStream_t stream);
+
+struct RtxVaeBwdArgs {
+    const float* C;  // dz [splits][Bp][ldc]
+    int splits;
+    long slab_stride;
+    int ldc;
+    int B, Bp, ldt, Z, Np;  // Np = P(2Z)
+    const float* mu32;
+    const float* lv32;
+    const float* eps32;
+    int training;
+    float beta, inv_batch;
+    void* D;   // T [Bp][Np]
+    void* DT;  // T [Np][Bp]
+};
+int rtx_launch_vae_bwd(const RtxVaeBwdArgs& a, int is_bf16, hipStream_t stream);
+
+// ---- loss ------------------------------------------------------------------------------------------
+struct RtxLossArgs {
+    const float* Y;  // logits [Bp][ldy]
+    int ldy, B, I;
+    RtxCsrView target;
+    const float* tsum;
+    float* lse;       // [Bp] out
+    float* row_loss;  // [Bp] out
+    float inv_batch;
+    // VAE KL term
+    const float* mu32;
+    const float* lv32;
+    int Z;
+    float beta;
+};
+int rtx_launch_lse_loss(const RtxLossArgs& a, hipStream_t stream);
+// loss_out[0] = sum(row_loss[0..B)) + lam * sum_t sqrt(sumsq[t]);  loss_accum[0] += the same (nullable)
+int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int n_tensors,
+                           float* loss_out, float* loss_accum, hipStream_t stream);
+// D[b][i] -= val/B, DT[i][b] likewise, at the target's stored entries
+int rtx_launch_target_fixup(const RtxCsrView& target, int B, float inv_batch, void* D, int ldd, void* DT, int ldt,
+                            int is_bf16, hipStream_t stream);
+// predict(): logits[b][i] = -inf where the input has a stored non-zero
+int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, hipStream_t stream);
+// public loss_function on dense tensors: row_loss[b] = s*lse - <x,y>  (+ beta * KL_b)
+int rtx_launch_dense_loss(const float* Y, const float* X, int B, int I, const float* mu, const float* lv, int Z,
+                          float beta, float inv_batch, float* row_loss, hipStream_t stream);
+
+// ---- dense batch -> CSR (drop-in train_batch(tr_batch, te_batch) / predict(x) with dense tensors) --
+int rtx_launch_dense_count(const float* X, int B, int I, int32_t* counts, hipStream_t stream);
+int rtx_launch_scan_counts(const int32_t* counts, int B, int64_t* indptr, hipStream_t stream);
+int rtx_launch_dense_fill(const float* X, int B, int I, const int64_t* indptr, int32_t* indices, float* values,
+                          hipStream_t stream);
+
+// ---- fused multi-tensor Adam (+ shadow refresh) ------------------------------------------------------
+#define RTX_MAX_TENSORS 32
+struct RtxAdamTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    void* sh;    // T [rows_p][ld_sh]   compute copy, same orientation   (nullable)
+    void* shT;   // T [cols_p][ld_shT]  compute copy, transposed          (nullable)
+    int rows, cols, ld_sh, ld_shT;
+    int tile_start;  // first 64x64 tile of this tensor in the launch
+};
+struct RtxAdamArgs {
+    RtxAdamTensor t[RTX_MAX_TENSORS];
+    int n;
+    int update;        // 0: only refresh the shadows from the master parameters
+    float step_size;   // lr / (1 - beta1^t)
+    float bc2_sqrt;    // sqrt(1 - beta2^t)
+    float beta1, beta2, eps, weight_decay;
+    float lam;         // DAE: g += lam * p / ||p||
+    const float* sumsq;  // [n] squared norms (DAE), nullable
+    float grad_scale;  // multiplies g before use (1.0; data-parallel averaging hooks)
+};
+int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream);
+int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, float* sumsq, hipStream_t stream);
