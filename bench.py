@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Headline benchmark: MultiVAE training users/sec on ml-20m-shaped synthetic data (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one MultiVAE.train_batch on one batch of 500 users per GPU: sparse-row gather -> forward ->
+multinomial + beta-KL loss -> backward -> (RCCL all-reduce of the gradients when N > 1) -> fused Adam, through
+the same ``_fused_step`` that ``MultiVAE.train_epoch`` drives with a device-resident ``DataSampler``.
+Workload = BASELINE.json configs[1]: MultiVAE [20108, 600, 200], B = 500 per GPU, bf16 MFMA operands with f32
+accumulation / f32 master weights + Adam, dropout 0.5, beta 0.2 annealed over 100 000 steps, lr 1e-3, synthetic
+CSR 116 677 x 20 108, inputs resident in HBM before the timed region.  Weak scaling: per-GPU batch
+fixed, global batch = 500 * N.
+
+Rank 0 prints ONE JSON line with `roofline` (the dominant kernel = fused Adam, HBM-bound, timed live with HIP
+events on the compute stream) and `cpu_baseline` (the oracle's torch-CPU restatement of the reference trainer,
+timed on this box's host cores on a bounded sample of the same workload; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_TBS = 8.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=500, help="users per GPU per step")
+    ap.add_argument("--numerics", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--users", type=int, default=116677)
+    ap.add_argument("--items", type=int, default=20108)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(X, dims, batch, seconds):
+    """the reference trainer's op sequence on this box's host cores (oracle/rectorch_cpu.py), bounded sample"""
+    from oracle.rectorch_cpu import CpuNet, CpuTrainer, densify_batch
+    import psutil
+    cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    torch.set_num_threads(cores)
+    I, H, L = dims
+    net = CpuNet([I, H, L], [L, H, I], "vae", 0.5)
+    tr = CpuTrainer(net, beta=0.2, anneal_steps=100000, lr=1e-3)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(X.shape[0])
+    times, t_start, i = [], time.time(), 0
+    while True:
+        idx = perm[(i * batch) % (len(perm) - batch):][:batch]
+        t0 = time.time()
+        x = densify_batch(X, list(idx))           # DataSampler.__iter__ work (samplers.py:99-100)
+        tr.train_batch(x)                         # MultiVAE.train_batch (models.py:817-835)
+        dt = time.time() - t0
+        if i >= 2:                                # 2 warm-up steps
+            times.append(dt)
+        i += 1
+        if (time.time() - t_start > seconds and len(times) >= 3) or len(times) >= 40:
+            break
+    per = float(np.median(times))
+    return {"value": batch / per, "unit": "users/s", "cores": int(cores), "kind": "port",
+            "sample": "%d steps of B=%d (sampler densify + train_batch) after 2 warm-up, median; torch %s CPU, %d threads"
+                      % (len(times), batch, torch.__version__, cores),
+            "ms_per_step": per * 1e3}
+
+
+def main():
+    args = parse()
+    from rectorch_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus, "launch with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
+    import torch.distributed as dist
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.nets import MultiVAE_net
+    from rectorch_amd.models import MultiVAE
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.engine import RowBatch
+
+    I, H, L, B = args.items, 600, 200, args.batch
+    X = synth_interactions(args.users, I, seed=20240927)          # same matrix on every rank
+    net = MultiVAE_net([L, H, I], dropout=0.5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in hash_state_dict([I, H, L], [L, H, I], "vae", 1234).items()})
+    model = MultiVAE(net, beta=0.2, anneal_steps=100000, learning_rate=1e-3, numerics=args.numerics)
+    if world > 1:
+        parallel.attach(model, fixed_global_batch=B * world)
+    # resident sampler over the global batch; each rank takes its slice of every global batch
+    np.random.seed(20240927)
+    smp = DataSampler(X, batch_size=B * world, shuffle=True)
+    batches = []
+    for rb in smp.iter_rows():
+        if len(rb) < B * world:
+            break
+        s, e = parallel.shard_rows(len(rb), rank, world)
+        batches.append(RowBatch(rb.tr, None, rb.rows[s:e].contiguous()))
+    net.train()
+    torch.manual_seed(1000 + rank)
+
+    def run(n, start):
+        for i in range(n):
+            model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
+
+    run(args.warmup, 0)
+    eng = net._rtx_engines[args.numerics]
+    eng.set_timing("adam", True)            # HIP events around the dominant kernel, on the compute stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timings = eng.get_timings()
+    eng.set_timing(None, False)
+    loss_mean = model._read_loss_sum() / (args.steps + args.warmup)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+    step_bytes, step_flops = eng.step_cost(B)
+    P = sum(p.numel() for p in net.parameters())
+    adam_ms, adam_n = timings.get("adam", (0.0, 0))
+    adam_us = adam_ms * 1e3 / max(adam_n, 1)
+    adam_bytes = 28.0 * P       # Adam reads p,g,m,v (16 B/param) and writes p,m,v (12 B/param)
+    achieved = adam_bytes / (adam_us * 1e-6) / 1e9 if adam_us else None
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1_pmc_adam.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "MultiVAE train users/sec on ml-20m (synthetic, ml-20m-shaped)",
+        "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.numerics == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "MultiVAE [20108,600,200] on ml-20m-shaped synthetic CSR %dx%d, B=%d per GPU, dropout 0.5, "
+                               "beta 0.2 anneal 100000, Adam lr 1e-3 (BASELINE.json configs[1])" % (args.users, I, B),
+                   "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "numerics": "bf16 MFMA operands, f32 accumulate, f32 master weights + Adam" if args.numerics == "bf16"
+                               else "f32 MFMA (parity mode)"},
+        "roofline": {"kernel": "k_adam (fused multi-tensor Adam + shadow refresh)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_TBS * 1000.0, "unit": "GB/s",
+                     "frac": (achieved / (HBM_PEAK_TBS * 1000.0)) if achieved else None,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": adam_bytes, "avg_us": adam_us, "launches": adam_n},
+        "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000.0),
+                          "algorithmic_flops_per_step": step_flops,
+                          "achieved_TFLOPs": step_flops / (ms_step * 1e-3) / 1e12},
+        "mean_loss": loss_mean,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(X, (I, H, L), B, args.cpu_seconds)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,10 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
 int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int32_t n_items, const float* mu,
                          const float* logvar, int32_t latent, float beta, float* loss_out, void* stream);
 
+/* the regulariser of MultiDAE.loss_function (models.py:702-706): out[0] = sum_t ||tensor_t||_2.
+ * `tensors` is a HOST array of n device pointers, `sizes` a HOST array of element counts. */
+int rtx_sum_l2_norms(const float* const* tensors, const int64_t* sizes, int32_t n, float* out, void* stream);
+
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
 int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);
 /* synchronises, returns up to `cap` entries (name, total ms, launches) and clears the counters */

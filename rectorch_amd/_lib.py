@@ -1,0 +1,134 @@
+"""ctypes binding of librectorch_hip.so (the C ABI declared in include/rectorch_hip.h).
+
+There is NO CPU implementation behind these entry points: if the shared library is missing, or no HIP
+device is visible, every compute call raises.  ``build()`` compiles the library in-tree with hipcc for
+gfx950 (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "librectorch_hip.so")
+MAX_LAYERS = 8
+
+RTX_VAE, RTX_DAE = 0, 1
+RTX_FP32, RTX_BF16 = 0, 1
+NUMERICS = {"fp32": RTX_FP32, "bf16": RTX_BF16}
+
+
+class RtxError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [("n_enc", C.c_int32), ("n_dec", C.c_int32),
+                ("enc_dims", C.c_int32 * (MAX_LAYERS + 1)), ("dec_dims", C.c_int32 * (MAX_LAYERS + 1)),
+                ("variant", C.c_int32), ("numerics", C.c_int32), ("dropout_p", C.c_float),
+                ("max_batch", C.c_int32), ("splitk", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("csr", C.c_void_p), ("row_ids", C.c_void_p), ("target_csr", C.c_void_p),
+                ("x_dense", C.c_void_p), ("target_dense", C.c_void_p), ("batch", C.c_int32)]
+
+
+class Step(C.Structure):
+    _fields_ = [("beta", C.c_float), ("lam", C.c_float), ("inv_batch", C.c_float),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step", C.c_int32),
+                ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("dropout_mask", C.c_void_p), ("eps_noise", C.c_void_p)]
+
+
+LAYER_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
+
+# every symbol include/rectorch_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "rtx_last_error": (C.c_char_p, []),
+    "rtx_abi_version": (C.c_int32, []),
+    "rtx_csr_upload": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    "rtx_csr_destroy": (C.c_int, [_P]),
+    "rtx_csr_shape": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "rtx_csr_gather_dense": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "rtx_engine_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(_P)]),
+    "rtx_engine_destroy": (C.c_int, [_P]),
+    "rtx_engine_n_tensors": (C.c_int32, [_P]),
+    "rtx_engine_tensor_shape": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rtx_engine_bind": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rtx_engine_sync_shadows": (C.c_int, [_P, _P]),
+    "rtx_engine_forward": (C.c_int, [_P, C.POINTER(Batch), C.c_int32, C.POINTER(Step), C.c_int32, _P, _P, _P, _P]),
+    "rtx_engine_encode": (C.c_int, [_P, C.POINTER(Batch), C.c_int32, C.POINTER(Step), _P, _P, _P]),
+    "rtx_engine_decode": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "rtx_engine_loss_grads": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, LAYER_CB, _P, _P]),
+    "rtx_engine_apply_adam": (C.c_int, [_P, C.POINTER(Step), _P]),
+    "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
+    "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
+    "rtx_sum_l2_norms": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "rtx_engine_set_timing": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "rtx_engine_get_timings": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
+    "rtx_engine_step_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile librectorch_hip.so for gfx950 with hipcc (in-tree, no GPU needed)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j8"], stdout=out)
+    assert os.path.exists(LIB_PATH)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises RtxError when it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtxError("librectorch_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; "
+                           "g.build()\"` or `make -C rectorch_amd/csrc`. rectorch_amd has no CPU path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().rtx_last_error()
+        raise RtxError("librectorch_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RtxError("rectorch_amd computes only on an AMD MI355X (HIP) device and none is visible; "
+                       "there is no CPU implementation of this path (the reference's CPU trainer is rectorch itself).")
+
+
+def make_cfg(enc_dims, dec_dims, variant, numerics, dropout, max_batch, splitk=0):
+    cfg = Cfg()
+    if len(enc_dims) - 1 > MAX_LAYERS or len(dec_dims) - 1 > MAX_LAYERS:
+        raise RtxError("at most %d layers per encoder/decoder are supported" % MAX_LAYERS)
+    cfg.n_enc, cfg.n_dec = len(enc_dims) - 1, len(dec_dims) - 1
+    for i, d in enumerate(enc_dims):
+        cfg.enc_dims[i] = int(d)
+    for i, d in enumerate(dec_dims):
+        cfg.dec_dims[i] = int(d)
+    cfg.variant = RTX_VAE if variant == "vae" else RTX_DAE
+    cfg.numerics = NUMERICS[numerics] if isinstance(numerics, str) else int(numerics)
+    cfg.dropout_p = float(dropout)
+    cfg.max_batch = int(max_batch)
+    cfg.splitk = int(splitk)
+    return cfg
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

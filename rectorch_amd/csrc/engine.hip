@@ -757,6 +757,19 @@ int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int3
     return rc;
 }
 
+int rtx_sum_l2_norms(const float* const* tensors, const int64_t* sizes, int32_t n, float* out, void* stream)
+{
+    RTX_CHECK(tensors && sizes && out && n >= 1 && n <= RTX_MAX_TENSORS, RTX_EINVAL, "sum_l2_norms: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* sumsq = nullptr;
+    RTX_HIP(hipMallocAsync((void**)&sumsq, sizeof(float) * n, st));
+    std::vector<long> sz(sizes, sizes + n);
+    int rc = rtx_launch_sumsq(tensors, sz.data(), n, sumsq, st);
+    if (!rc) rc = rtx_launch_reduce_loss(nullptr, 0, 1.f, sumsq, n, out, nullptr, st);
+    (void)hipFreeAsync(sumsq, st);
+    return rc;
+}
+
 // ---- instrumentation -------------------------------------------------------------------------------
 int rtx_engine_set_timing(rtx_engine* e, const char* site, int32_t enable)
 {

@@ -1,0 +1,267 @@
+"""Python handles over the C ABI: device-resident CSR matrices and the Mult-VAE/DAE engine.
+
+PyTorch is plumbing here (device memory, streams): tensors are passed to librectorch_hip as raw device
+pointers on torch's current HIP stream.  No arithmetic of the path is done by torch.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Batch, Step, check, lib, stream_ptr
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class CsrMatrix:
+    """A scipy CSR matrix uploaded once to HBM (indptr int64, indices int32, values float32 or
+    implicit ones).  Replaces the per-batch ``sparse[idx].toarray()`` of the reference's DataSampler
+    (rectorch/samplers.py:99-105)."""
+
+    def __init__(self, sparse):
+        _lib.require_gpu()
+        m = sparse.tocsr().copy()
+        m.sum_duplicates()
+        self.shape = m.shape
+        self.nnz = int(m.nnz)
+        indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+        data = np.asarray(m.data)
+        self.binary = bool(np.all(data == 1))
+        values = None if self.binary else np.ascontiguousarray(data, dtype=np.float32)
+        h = C.c_void_p()
+        check(lib().rtx_csr_upload(indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p),
+                                   None if values is None else values.ctypes.data_as(C.c_void_p),
+                                   C.c_int64(m.shape[0]), C.c_int32(m.shape[1]), C.byref(h)))
+        self.handle = h
+
+    def gather_dense(self, row_ids, out=None):
+        """float32 [len(row_ids), n_cols] device tensor holding the given rows (K1 in dense form)."""
+        n = int(row_ids.numel())
+        if out is None:
+            out = torch.empty((n, self.shape[1]), dtype=torch.float32, device=row_ids.device)
+        if n:
+            check(lib().rtx_csr_gather_dense(self.handle, _ptr(row_ids), n, _ptr(out), stream_ptr()))
+        return out
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                lib().rtx_csr_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class RowBatch:
+    """What the resident DataSampler hands to the trainer on the fast path: row numbers only."""
+    __slots__ = ("tr", "te", "rows")
+
+    def __init__(self, tr, te, rows):
+        self.tr, self.te, self.rows = tr, te, rows
+
+    def __len__(self):
+        return int(self.rows.numel())
+
+
+def _check_width(t, n_items, what):
+    if n_items is not None and (t.dim() != 2 or t.shape[1] != n_items):
+        raise _lib.RtxError("%s must be [batch, %d] (n_items of the network), got %s" % (what, n_items, tuple(t.shape)))
+
+
+def make_batch(x, target=None, keep=None, n_items=None):
+    """Build the C ``rtx_batch`` for ``x`` (a RowBatch, or a dense [B, n_items] device tensor, or a dense
+    tensor carrying the RowBatch it was gathered from).  ``keep`` collects tensors that must outlive the call."""
+    b = Batch()
+    rb = x if isinstance(x, RowBatch) else getattr(x, "_rtx_rows", None)
+    if rb is not None:
+        b.csr = rb.tr.handle
+        b.row_ids = rb.rows.data_ptr()
+        b.batch = len(rb)
+        if target is None and rb.te is not None and isinstance(x, RowBatch) and x.te is not None:
+            b.target_csr = rb.te.handle
+    else:
+        _check_width(x, n_items, "the input batch")
+        x = x.to(torch.float32).contiguous()
+        if keep is not None:
+            keep.append(x)
+        b.x_dense = x.data_ptr()
+        b.batch = x.shape[0]
+    if target is not None:
+        trb = getattr(target, "_rtx_rows", None)
+        if trb is not None and rb is not None and trb.rows is rb.rows and trb.te is not None:
+            b.target_csr = trb.te.handle
+        else:
+            _check_width(target, n_items, "the target batch")
+            target = target.to(torch.float32).contiguous()
+            if keep is not None:
+                keep.append(target)
+            if rb is not None:
+                # input by rows, target dense: densify the input as well (mixed forms are not in the ABI)
+                xin = rb.tr.gather_dense(rb.rows)
+                if keep is not None:
+                    keep.append(xin)
+                b.csr = None
+                b.row_ids = None
+                b.x_dense = xin.data_ptr()
+            b.target_dense = target.data_ptr()
+    return b
+
+
+class Engine:
+    """One ``rtx_engine``: a network's compute state at one numerics mode, bound to the network's float32
+    master parameters (the nn.Parameters themselves) and, for training, to gradient buffers and the Adam
+    moments held in ``torch.optim.Adam``'s state."""
+
+    def __init__(self, enc_dims, dec_dims, variant, dropout, numerics="bf16", max_batch=512, splitk=0):
+        _lib.require_gpu()
+        self.enc_dims, self.dec_dims = [int(d) for d in enc_dims], [int(d) for d in dec_dims]
+        self.variant, self.numerics = variant, numerics
+        self.max_batch = int(max_batch)
+        self.n_items, self.latent = self.enc_dims[0], self.enc_dims[-1]
+        cfg = _lib.make_cfg(self.enc_dims, self.dec_dims, variant, numerics, dropout, max_batch, splitk)
+        h = C.c_void_p()
+        check(lib().rtx_engine_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.n_tensors = lib().rtx_engine_n_tensors(h)
+        self._bound = None
+        self._keep = []
+
+    # ---- binding --------------------------------------------------------------------------------
+    def bind(self, params, grads=None, exp_avg=None, exp_avg_sq=None):
+        n = self.n_tensors
+        assert len(params) == n, "expected %d parameter tensors, got %d" % (n, len(params))
+        rows, cols = C.c_int32(), C.c_int32()
+        for t, p in enumerate(params):
+            check(lib().rtx_engine_tensor_shape(self.handle, t, C.byref(rows), C.byref(cols)))
+            want = (rows.value, cols.value) if p.dim() == 2 else (rows.value,)
+            if tuple(p.shape) != want or p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                raise _lib.RtxError("parameter %d must be a contiguous float32 HIP tensor of shape %s, got %s %s on %s"
+                                    % (t, want, tuple(p.shape), p.dtype, p.device))
+        arr_t = C.c_void_p * n
+
+        def arr(ts):
+            return None if ts is None else arr_t(*[t.data_ptr() for t in ts])
+        check(lib().rtx_engine_bind(self.handle, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq)))
+        self._bound = (list(params), grads, exp_avg, exp_avg_sq)   # keep the tensors alive
+
+    def sync_shadows(self):
+        check(lib().rtx_engine_sync_shadows(self.handle, stream_ptr()))
+
+    # ---- forward family ---------------------------------------------------------------------------
+    def _step(self, seed=0, offset=0, mask=None, noise=None, **kw):
+        s = Step()
+        s.seed, s.offset = int(seed) & (2 ** 64 - 1), int(offset)
+        s.dropout_mask = None if mask is None else mask.data_ptr()
+        s.eps_noise = None if noise is None else noise.data_ptr()
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+    def forward(self, x, training=False, remove_train=False, seed=0, offset=0, mask=None, noise=None):
+        keep = []
+        b = make_batch(x, keep=keep, n_items=self.n_items)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        logits = torch.empty((b.batch, self.n_items), dtype=torch.float32, device=dev)
+        mu = logvar = None
+        if self.variant == "vae":
+            mu = torch.empty((b.batch, self.latent), dtype=torch.float32, device=dev)
+            logvar = torch.empty_like(mu)
+        st = self._step(seed, offset, mask, noise)
+        check(lib().rtx_engine_forward(self.handle, C.byref(b), int(training), C.byref(st), int(remove_train),
+                                       _ptr(logits), _ptr(mu), _ptr(logvar), stream_ptr()))
+        return logits, mu, logvar
+
+    def encode(self, x, training=False, seed=0, offset=0, mask=None):
+        keep = []
+        b = make_batch(x, keep=keep, n_items=self.n_items)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        o0 = torch.empty((b.batch, self.latent), dtype=torch.float32, device=dev)
+        o1 = torch.empty_like(o0) if self.variant == "vae" else None
+        st = self._step(seed, offset, mask, None)
+        check(lib().rtx_engine_encode(self.handle, C.byref(b), int(training), C.byref(st), _ptr(o0), _ptr(o1), stream_ptr()))
+        return o0, o1
+
+    def decode(self, z):
+        _check_width(z, self.latent, "z")
+        z = z.contiguous().float()
+        logits = torch.empty((z.shape[0], self.n_items), dtype=torch.float32, device=z.device)
+        check(lib().rtx_engine_decode(self.handle, _ptr(z), z.shape[0], _ptr(logits), stream_ptr()))
+        return logits
+
+    # ---- training ---------------------------------------------------------------------------------
+    def loss_grads(self, x, target, step, loss_out, loss_accum=None, layer_cb=None):
+        keep = []
+        b = make_batch(x, target, keep=keep, n_items=self.n_items)
+        cb = _lib.LAYER_CB(layer_cb) if layer_cb is not None else _lib.LAYER_CB()
+        check(lib().rtx_engine_loss_grads(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
+                                          cb, None, stream_ptr()))
+
+    def apply_adam(self, step):
+        check(lib().rtx_engine_apply_adam(self.handle, C.byref(step), stream_ptr()))
+
+    def train_step(self, x, target, step, loss_out, loss_accum=None):
+        keep = []
+        b = make_batch(x, target, keep=keep, n_items=self.n_items)
+        check(lib().rtx_engine_train_step(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
+                                          stream_ptr()))
+
+    # ---- instrumentation --------------------------------------------------------------------------
+    def set_timing(self, site=None, enable=True):
+        check(lib().rtx_engine_set_timing(self.handle, None if site is None else site.encode(), int(enable)))
+
+    def get_timings(self):
+        cap = 64
+        names = (C.c_char * 48 * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (C.c_int32 * cap)()
+        n = C.c_int32()
+        check(lib().rtx_engine_get_timings(self.handle, cap, names, ms, cnt, C.byref(n)))
+        return {names[i].value.decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
+
+    def step_cost(self, batch):
+        b, f = C.c_double(), C.c_double()
+        check(lib().rtx_engine_step_cost(self.handle, int(batch), C.byref(b), C.byref(f)))
+        return b.value, f.value
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                lib().rtx_engine_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+
+def multinomial_loss(recon, x, mu=None, logvar=None, beta=0.0):
+    """``-mean_b sum_i log_softmax(recon)_bi x_bi + beta * KLD`` as a 0-dim device tensor
+    (reference MultiVAE.loss_function, rectorch/models.py:813-815)."""
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    recon = recon.to(dev, torch.float32).contiguous()
+    x = x.to(dev, torch.float32).contiguous()
+    if mu is not None:
+        mu = mu.to(dev, torch.float32).contiguous()
+        logvar = logvar.to(dev, torch.float32).contiguous()
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    check(lib().rtx_multinomial_loss(_ptr(recon), _ptr(x), recon.shape[0], recon.shape[1], _ptr(mu), _ptr(logvar),
+                                     0 if mu is None else mu.shape[1], float(beta), _ptr(out), stream_ptr()))
+    return out
+
+
+def sum_l2_norms(tensors):
+    """``sum_t ||tensor_t||_2`` as a 0-dim device tensor (the regulariser of MultiDAE.loss_function,
+    reference rectorch/models.py:702-706)."""
+    _lib.require_gpu()
+    ts = [t.contiguous() for t in tensors]
+    n = len(ts)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (C.c_int64 * n)(*[t.numel() for t in ts])
+    out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+    check(lib().rtx_sum_l2_norms(ptrs, sizes, n, _ptr(out), stream_ptr()))
+    return out

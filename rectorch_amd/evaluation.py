@@ -1,0 +1,96 @@
+r"""Evaluation utilities with the reference's API (rectorch/evaluation.py:11-178).
+
+These are the host-side consumers of the hot path: they iterate a sampler, call ``model.predict`` (the HIP
+forward) and score the returned logits with :class:`rectorch_amd.metrics.Metrics`.  The duck-typed contract
+is the reference's: ``predict(x)[0]`` supports ``.cpu().numpy()``, samplers yield ``(data_tr, heldout)``
+pairs supporting ``.view``, ``.shape`` and ``.cpu().numpy()`` (evaluation.py:100-103).
+"""
+from functools import partial
+import inspect
+import random
+
+import numpy as np
+
+from .metrics import Metrics
+
+__all__ = ['ValidFunc', 'evaluate', 'one_plus_random']
+
+
+class ValidFunc():
+    """Wrapper adapting an evaluation function to the ``(model, test_loader, metric_list)`` signature the
+    trainers call (reference evaluation.py:11-64): extra keyword arguments are bound at construction and the
+    remaining positional arguments must be exactly those three names.
+
+    >>> opr = ValidFunc(one_plus_random, r=5)
+    >>> opr
+    ValidFunc(fun='one_plus_random', params={'r': 5})
+    """
+    def __init__(self, func, **kwargs):
+        self.func_name = func.__name__
+        self.function = partial(func, **kwargs)
+        args = inspect.getfullargspec(self.function).args
+        assert args == ["model", "test_loader", "metric_list"],\
+            "A (partial) validation function must have the following kwargs: model, test_loader and\
+            metric_list"
+
+    def __call__(self, model, test_loader, metric):
+        return self.function(model, test_loader, [metric])[metric]
+
+    def __str__(self):
+        kwdefargs = inspect.getfullargspec(self.function).kwonlydefaults
+        return "ValidFunc(fun='%s', params=%s)" % (self.func_name, kwdefargs)
+
+    def __repr__(self):
+        return str(self)
+
+
+def _to_numpy(t):
+    t = t.view(t.shape[0], -1)
+    return t.cpu().numpy()
+
+
+def evaluate(model, test_loader, metric_list):
+    r"""Evaluate ``model`` on every batch of ``test_loader`` with every metric of ``metric_list``
+    (``"name@k"`` strings).  Returns ``dict metric -> per-user numpy array`` in loader order
+    (reference evaluation.py:67-110)."""
+    results = {m: [] for m in metric_list}
+    for _, (data_tr, heldout) in enumerate(test_loader):
+        data_tensor = data_tr.view(data_tr.shape[0], -1)
+        if getattr(data_tr, "_rtx_rows", None) is not None:
+            data_tensor._rtx_rows = data_tr._rtx_rows       # keep the resident-rows shortcut across .view()
+        recon_batch = model.predict(data_tensor)[0].cpu().numpy()
+        heldout = _to_numpy(heldout)
+        res = Metrics.compute(recon_batch, heldout, metric_list)
+        for m in res:
+            results[m].append(res[m])
+    for m in results:
+        results[m] = np.concatenate(results[m])
+    return results
+
+
+def one_plus_random(model, test_loader, metric_list, r=1000):
+    r"""One-plus-random evaluation (reference evaluation.py:113-178): for every held-out positive of every
+    user, rank it against ``r`` random items the user has not interacted with in the held-out part and
+    compute the metrics on those ``r + 1`` scores (the positive is column 0).  Raises ``ValueError`` when
+    fewer than ``r`` negatives exist."""
+    results = {m: [] for m in metric_list}
+    for _, (data_tr, heldout) in enumerate(test_loader):
+        tot = set(range(heldout.shape[1]))
+        data_tensor = data_tr.view(data_tr.shape[0], -1)
+        recon_batch = model.predict(data_tensor)[0].cpu().numpy()
+        heldout = _to_numpy(heldout)
+        users, items = heldout.nonzero()
+        rows = []
+        for u, i in zip(users, items):
+            negatives = sorted(tot - set(heldout[u].nonzero()[0].tolist()))
+            rnd = random.sample(negatives, r)
+            rows.append(list(recon_batch[u][[i] + list(rnd)]))
+        pred = np.array(rows)
+        ground_truth = np.zeros_like(pred)
+        ground_truth[:, 0] = 1
+        res = Metrics.compute(pred, ground_truth, metric_list)
+        for m in res:
+            results[m].append(res[m])
+    for m in results:
+        results[m] = np.concatenate(results[m])
+    return results

@@ -1,0 +1,490 @@
+r"""Trainer classes of the Mult-VAE / Mult-DAE path with the reference's API (rectorch/models.py), running
+on the MI355X engine.
+
+Same class hierarchy and signatures as the reference: ``RecSysModel`` (models.py:70-161) ->
+``TorchNNTrainer`` (:164-322) -> ``AETrainer`` (:325-516) -> ``VAE`` (:519-625) -> ``MultiVAE`` (:709-908), and
+``MultiDAE`` (:628-706).  What changes is underneath: ``train_batch`` is ONE call into librectorch_hip
+(gather -> forward -> multinomial/KL loss -> backward -> fused Adam, all hand-written HIP), ``predict`` is the
+HIP forward, and ``train_epoch`` feeds row numbers of a device-resident CSR instead of dense host batches and
+reads the loss back only at the logging boundaries.  ``model.optimizer`` is still a ``torch.optim.Adam``
+object whose ``state`` tensors ARE the buffers the fused Adam kernel updates, so checkpoints round-trip with the
+reference's layout (``epoch``, ``state_dict``, ``optimizer``, ``gradient_updates``).
+"""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import _lib
+from .engine import RowBatch, multinomial_loss
+from .evaluation import ValidFunc, evaluate
+from .samplers import DataSampler
+
+__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE']
+
+logger = logging.getLogger(__name__)
+
+
+class RecSysModel():
+    r"""Abstract base class that any Recommendation model must inherit from (reference models.py:70-161)."""
+    def train(self, train_data, **kwargs):
+        raise NotImplementedError()
+
+    def predict(self, x, *args, **kwargs):
+        raise NotImplementedError()
+
+    def save_model(self, filepath, *args, **kwargs):
+        raise NotImplementedError()
+
+    def load_model(self, filepath, *args, **kwargs):
+        raise NotImplementedError()
+
+
+class _RtxState:
+    """Private per-trainer state of the HIP path (kept in one object with a short repr because the
+    reference's ``__str__`` prints every attribute of the model)."""
+    def __init__(self):
+        self.flat_grads = None
+        self.grads = None
+        self.layer_ranges = None
+        self.adam_step = 0
+        self.loss_buf = None      # [0] = last loss, [1] = running sum since the last read-back
+        self.reducer = None       # data parallel: rectorch_amd.parallel.GradAllReducer
+        self.inject = None        # parity tests: (dropout keep-mask, eps) captured from the reference's RNG
+
+    def __repr__(self):
+        return "<MI355X engine state>"
+
+
+class TorchNNTrainer(RecSysModel):
+    r"""Abstract class representing a neural network-based model (reference models.py:164-322).
+
+    Parameters
+    ----------
+    net : :class:`torch.nn.Module`
+        The neural network architecture (a :mod:`rectorch_amd.nets` network).
+    learning_rate : :obj:`float` [optional]
+        The learning rate for the optimizer, by default 1e-3.
+
+    Attributes
+    ----------
+    network, learning_rate, optimizer, device : as in the reference.  ``device`` is the HIP device: a
+        network still on the host is moved to the MI355X at construction (this package has no CPU compute
+        path); without any HIP device the object can be built, saved and loaded but not run.
+    """
+    def __init__(self, net, learning_rate=1e-3):
+        self.network = net
+        self.learning_rate = learning_rate
+        self.optimizer = None #to be initialized in the sub-classes
+
+        if not next(self.network.parameters()).is_cuda and torch.cuda.is_available():
+            logger.info("moving the network to the MI355X (rectorch_amd computes only on the HIP device)")
+            self.network.to(torch.device("cuda"))
+        if next(self.network.parameters()).is_cuda:
+            self.device = torch.device("cuda")
+        else:
+            self.device = torch.device("cpu")
+
+    def loss_function(self, prediction, ground_truth, *args, **kwargs):
+        raise NotImplementedError()
+
+    def train(self, train_data, *args, **kwargs):
+        raise NotImplementedError()
+
+    def train_epoch(self, epoch, train_data, *args, **kwargs):
+        raise NotImplementedError()
+
+    def train_batch(self, epoch, tr_batch, te_batch, *args, **kwargs):
+        raise NotImplementedError()
+
+    def predict(self, x, *args, **kwargs):
+        raise NotImplementedError()
+
+    def __str__(self):
+        s = self.__class__.__name__ + "(\n"
+        for k, v in self.__dict__.items():
+            sv = "\n".join(["  "+line for line in str(str(v)).split("\n")])[2:]
+            s += "  %s = %s,\n" % (k, sv)
+        s = s[:-2] + "\n)"
+        return s
+
+    def __repr__(self):
+        return str(self)
+
+
+class AETrainer(TorchNNTrainer):
+    r"""Base class for Autoencoder-based models (reference models.py:325-516).  Holds the Adam optimizer, the
+    epoch loop, prediction and checkpointing shared by :class:`MultiDAE` and :class:`MultiVAE`.
+
+    Extra keyword arguments (not in the reference): ``numerics`` = arithmetic of the training step
+    ("bf16": bf16 MFMA operands, f32 accumulation, f32 master weights and Adam; "fp32": exact-f32 MFMA) and
+    ``predict_numerics`` (default "fp32", the parity mode: logits within 1e-5 of the reference's CPU path).
+    """
+    _variant = "dae"
+    _uses_te = False     # train_batch ignores te_batch (reference models.py:444-445)
+
+    def __init__(self, ae_net, learning_rate=1e-3, numerics="bf16", predict_numerics="fp32"):
+        super(AETrainer, self).__init__(ae_net, learning_rate)
+        self.optimizer = optim.Adam(self.network.parameters(), lr=learning_rate)
+        self.numerics = numerics
+        self.predict_numerics = predict_numerics
+        self._rtx = _RtxState()
+
+    # ------------------------------------------------------------------------------------------ loss
+    def loss_function(self, prediction, ground_truth):
+        r"""The reference's vanilla autoencoder uses an MSE loss here (models.py:347-377); that model is not
+        part of the Mult-VAE / Mult-DAE path."""
+        raise NotImplementedError("the MSE autoencoder is outside the MI355X hot path; use MultiDAE / MultiVAE")
+
+    # ------------------------------------------------------------------------------------- training
+    def train(self,
+              train_data,
+              valid_data=None,
+              valid_metric=None,
+              valid_func=ValidFunc(evaluate),
+              num_epochs=100,
+              verbose=1):
+        r"""Training of a neural network-based model (reference models.py:379-398)."""
+        try:
+            for epoch in range(1, num_epochs + 1):
+                self.train_epoch(epoch, train_data, verbose)
+                if valid_data is not None:
+                    assert valid_metric is not None, \
+                                "In case of validation 'valid_metric' must be provided"
+                    valid_res = valid_func(self, valid_data, valid_metric)
+                    mu_val = np.mean(valid_res)
+                    std_err_val = np.std(valid_res) / np.sqrt(len(valid_res))
+                    logger.info('| epoch %d | %s %.3f (%.4f) |',
+                                epoch, valid_metric, mu_val, std_err_val)
+        except KeyboardInterrupt:
+            logger.warning('Handled KeyboardInterrupt: exiting from training early')
+
+    def train_epoch(self, epoch, train_loader, verbose=1):
+        r"""Training of a single epoch (reference models.py:401-422): same loop, same log lines.  With a
+        device-resident :class:`DataSampler` the batches are row numbers, steps are enqueued back to back
+        and the loss is read from the device only every ``log_delay`` batches."""
+        self.network.train()
+        train_loss = 0
+        partial_loss = 0
+        epoch_start_time = time.time()
+        start_time = time.time()
+        log_delay = max(10, len(train_loader) // 10**verbose)
+
+        fast = isinstance(train_loader, DataSampler) and train_loader.resident
+        batches = train_loader.iter_rows() if fast else train_loader
+        for batch_idx, item in enumerate(batches):
+            if fast:
+                if not self._uses_te and item.te is not None:
+                    item = RowBatch(item.tr, None, item.rows)
+                self._fused_step(item, None, want_loss=False)
+            else:
+                data, gt = item
+                partial_loss += self.train_batch(data, gt)
+            if (batch_idx+1) % log_delay == 0:
+                if fast:
+                    partial_loss = self._read_loss_sum()
+                elapsed = time.time() - start_time
+                logger.info('| epoch %d | %d/%d batches | ms/batch %.2f | loss %.2f |',
+                            epoch, (batch_idx+1), len(train_loader),
+                            elapsed * 1000 / log_delay,
+                            partial_loss / log_delay)
+                train_loss += partial_loss
+                partial_loss = 0.0
+                start_time = time.time()
+        if fast:
+            partial_loss = self._read_loss_sum()
+        total_loss = (train_loss + partial_loss) / len(train_loader)
+        time_diff = time.time() - epoch_start_time
+        logger.info("| epoch %d | loss %.4f | total time: %.2fs |", epoch, total_loss, time_diff)
+
+    def train_batch(self, tr_batch, te_batch=None):
+        r"""Training of a single batch (reference models.py:424-447): the loss target is the batch itself
+        (``te_batch`` is ignored, as in the reference).  Returns the loss as a Python float."""
+        return self._fused_step(tr_batch, None, want_loss=True)
+
+    # ---------------------------------------------------------------------------- the fused HIP step
+    def _step_scalars(self):
+        """(beta, lam) of this update; sub-classes fill them."""
+        return 0.0, 0.0
+
+    def _after_step(self):
+        pass
+
+    def _ensure_train_state(self):
+        st = self._rtx
+        params = self.network._param_list()
+        if st.grads is None or st.flat_grads.device != params[0].device:
+            # one flat gradient buffer (one RCCL all-reduce region per layer); p.grad are views into it
+            offs, total = [], 0
+            for p in params:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64
+            st.flat_grads = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            st.grads = [st.flat_grads[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+            st.layer_ranges = [(offs[2 * l], offs[2 * l + 1] + params[2 * l + 1].numel()) for l in range(len(params) // 2)]
+            for p, g in zip(params, st.grads):
+                p.grad = g
+            st.loss_buf = torch.zeros(2, dtype=torch.float32, device=params[0].device)
+        first = True
+        for p in params:
+            state = self.optimizer.state[p]
+            if len(state) == 0:
+                # what torch.optim.Adam._init_group creates lazily on its first step()
+                state['step'] = torch.tensor(0.0, dtype=torch.float32)
+                state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if first:
+                st.adam_step = max(st.adam_step, int(float(state['step'])))
+                first = False
+        m = [self.optimizer.state[p]['exp_avg'] for p in params]
+        v = [self.optimizer.state[p]['exp_avg_sq'] for p in params]
+        return st, params, m, v
+
+    def _fused_step(self, x, target, want_loss=True):
+        _lib.require_gpu()
+        st, params, m, v = self._ensure_train_state()
+        if not isinstance(x, RowBatch):
+            x = self.network._as_input(x)
+            if target is not None:
+                target = self.network._as_input(target)
+        B = len(x) if isinstance(x, RowBatch) else x.shape[0]
+        eng = self.network.rtx_engine(self.numerics, B, train_buffers=(st.grads, m, v))
+        g = self.optimizer.param_groups[0]
+        beta, lam = self._step_scalars()
+        st.adam_step += 1
+        from .nets import draw_seed
+        red = st.reducer
+        inj = self._rtx.inject or (None, None)     # (keep-mask uint8 [B, n_items], eps [B, latent]) for parity tests
+        step = eng._step(seed=draw_seed(), offset=0 if red is None else red.rank, mask=inj[0], noise=inj[1],
+                         beta=float(beta), lam=float(lam),
+                         inv_batch=1.0 / (B if red is None else red.global_batch(B)),
+                         lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
+                         eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step)
+        loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]
+        if red is None:
+            eng.train_step(x, target, step, loss_out, loss_acc)
+        else:
+            eng.loss_grads(x, target, step, loss_out, loss_acc, layer_cb=red.on_layer)
+            red.wait()
+            eng.apply_adam(step)
+        self.network._rtx_mark_updated(self.numerics)
+        self._after_step()
+        if want_loss:
+            if red is not None:
+                return red.reduce_scalar(st.loss_buf[0:1].clone())
+            return st.loss_buf[0].item()       # the reference's per-step loss.item() sync
+        return None
+
+    def _read_loss_sum(self):
+        st = self._rtx
+        if st.reducer is not None:
+            s = st.reducer.reduce_scalar(st.loss_buf[1:2].clone())
+        else:
+            s = st.loss_buf[1].item()
+        st.loss_buf[1].zero_()
+        return s
+
+    # ----------------------------------------------------------------------------------- prediction
+    def _predict_tuple(self, x, remove_train):
+        _lib.require_gpu()
+        self.network.eval()
+        x_in = self.network._as_input(x)
+        eng = self.network.rtx_engine(self.predict_numerics, x_in.shape[0])
+        return eng.forward(x_in, training=False, remove_train=remove_train)
+
+    def predict(self, x, remove_train=True):
+        r"""Perform the prediction using a trained Autoencoder (reference models.py:449-473).  Returns the
+        1-tuple ``(recon_x,)``; with ``remove_train`` the items of ``x`` are scored :math:`-\infty`."""
+        recon_x, _, _ = self._predict_tuple(x, remove_train)
+        return (recon_x, )
+
+    # -------------------------------------------------------------------------------- checkpointing
+    def _sync_optimizer_state(self):
+        """write the step count the fused Adam kernel is at into torch.optim.Adam's state"""
+        for p in self.network.parameters():
+            state = self.optimizer.state.get(p)
+            if state is not None and 'step' in state:
+                state['step'] = torch.tensor(float(self._rtx.adam_step), dtype=torch.float32)
+
+    def save_model(self, filepath, cur_epoch):
+        r"""Save the model to file (reference models.py:475-489): ``epoch``, ``state_dict``, ``optimizer``."""
+        self._sync_optimizer_state()
+        state = {'epoch': cur_epoch,
+                 'state_dict': self.network.state_dict(),
+                 'optimizer': self.optimizer.state_dict()
+                }
+        self._save_checkpoint(filepath, state)
+
+    def _save_checkpoint(self, filepath, state):
+        logger.info("Saving model checkpoint to %s...", filepath)
+        torch.save(state, filepath)
+        logger.info("Model checkpoint saved!")
+
+    def load_model(self, filepath):
+        r"""Load the model from file (reference models.py:496-516); returns the checkpoint dictionary."""
+        assert os.path.isfile(filepath), "The checkpoint file %s does not exist." %filepath
+        logger.info("Loading model checkpoint from %s...", filepath)
+        checkpoint = torch.load(filepath, map_location=self.device)
+        self.network.load_state_dict(checkpoint['state_dict'])
+        self.optimizer.load_state_dict(checkpoint['optimizer'])
+        steps = [int(float(s['step'])) for s in self.optimizer.state.values() if 'step' in s]
+        self._rtx.adam_step = steps[0] if steps else 0
+        logger.info("Model checkpoint loaded!")
+        return checkpoint
+
+
+class VAE(AETrainer):
+    r"""Plumbing shared with the reference's ``VAE`` class (models.py:519-625): ``predict`` returning
+    ``(recon_x, mu, logvar)``.  The reference's own BCE loss for a sigmoid VAE is not on the hot path."""
+    _variant = "vae"
+
+    def loss_function(self, recon_x, x, mu, logvar):
+        raise NotImplementedError("the generic BCE VAE is outside the MI355X hot path; use MultiVAE")
+
+    def predict(self, x, remove_train=True):
+        r"""Perform the prediction using a trained Variational Autoencoder (reference models.py:594-625).
+        Returns ``(recon_x, mu, logvar)``; with ``remove_train`` the items of ``x`` are scored
+        :math:`-\infty`."""
+        return self._predict_tuple(x, remove_train)
+
+
+class MultiDAE(AETrainer):
+    r"""Denoising Autoencoder with multinomial likelihood for collaborative filtering (reference
+    models.py:628-706): Adam with (coupled) ``weight_decay=0.001``; loss = multinomial NLL +
+    :math:`\lambda \sum_W \lVert W \rVert_2`.
+
+    Parameters
+    ----------
+    mdae_net : :class:`rectorch_amd.nets.MultiDAE_net`
+    lam : :obj:`float` [optional]
+        The regularization hyper-parameter, by default 0.2.
+    learning_rate : :obj:`float` [optional]
+        By default 1e-3.
+    """
+    _variant = "dae"
+
+    def __init__(self,
+                 mdae_net,
+                 lam=0.2,
+                 learning_rate=1e-3,
+                 numerics="bf16",
+                 predict_numerics="fp32"):
+        super(MultiDAE, self).__init__(mdae_net, learning_rate, numerics, predict_numerics)
+        self.optimizer = optim.Adam(self.network.parameters(),
+                                    lr=self.learning_rate,
+                                    weight_decay=0.001)
+        self.lam = lam
+
+    def loss_function(self, recon_x, x):
+        r"""Multinomial likelihood denoising autoencoder loss (reference models.py:662-706), on the HIP
+        device; returns a 0-dim tensor."""
+        from .engine import sum_l2_norms
+        nll = multinomial_loss(recon_x, x)
+        return nll + self.lam * sum_l2_norms([p.data for p in self.network.parameters()])
+
+    def _step_scalars(self):
+        return 0.0, self.lam
+
+
+class MultiVAE(VAE):
+    r"""Variational Autoencoder for collaborative Filtering (reference models.py:709-908).
+
+    Parameters
+    ----------
+    mvae_net : :class:`rectorch_amd.nets.MultiVAE_net`
+    beta : :obj:`float` [optional]
+        The :math:`\beta` hyper-parameter of Multi-VAE, by default 1.0.
+    anneal_steps : :obj:`int` [optional]
+        Number of annealing steps for reaching the target value ``beta``, by default 0 (no annealing).
+    learning_rate : :obj:`float` [optional]
+        By default 1e-3.
+
+    Attributes
+    ----------
+    anneal_steps, annealing, gradient_updates (a float, as in the reference), beta.
+    """
+    _uses_te = True      # the loss target is te_batch when given (reference models.py:819-822)
+
+    def __init__(self,
+                 mvae_net,
+                 beta=1.,
+                 anneal_steps=0,
+                 learning_rate=1e-3,
+                 numerics="bf16",
+                 predict_numerics="fp32"):
+        super(MultiVAE, self).__init__(mvae_net, learning_rate, numerics, predict_numerics)
+        self.optimizer = optim.Adam(self.network.parameters(),
+                                    lr=learning_rate,
+                                    weight_decay=0.0)
+        self.anneal_steps = anneal_steps
+        self.annealing = anneal_steps > 0
+        self.gradient_updates = 0.
+        self.beta = beta
+
+    def loss_function(self, recon_x, x, mu, logvar, beta=1.0):
+        r"""VAE for collaborative filtering loss function (reference models.py:776-815):
+        multinomial NLL + ``beta`` * KL, on the HIP device; returns a 0-dim tensor."""
+        return multinomial_loss(recon_x, x, mu, logvar, beta)
+
+    def _step_scalars(self):
+        if self.annealing:
+            anneal_beta = min(self.beta, 1. * self.gradient_updates / self.anneal_steps)
+        else:
+            anneal_beta = self.beta
+        return anneal_beta, 0.0
+
+    def _after_step(self):
+        self.gradient_updates += 1.
+
+    def train_batch(self, tr_batch, te_batch=None):
+        r"""Training of a single batch (reference models.py:817-835): the encoder input is ``tr_batch``, the
+        loss target ``te_batch`` when given, the KL weight is annealed with ``gradient_updates``."""
+        return self._fused_step(tr_batch, te_batch, want_loss=True)
+
+    def train(self,
+              train_data,
+              valid_data=None,
+              valid_metric=None,
+              valid_func=ValidFunc(evaluate),
+              num_epochs=200,
+              best_path="chkpt_best.pth",
+              verbose=1):
+        r"""Training procedure for Multi-VAE (reference models.py:837-895): per epoch ``train_epoch``, then
+        validation with ``valid_func`` and a checkpoint to ``best_path`` whenever the mean of
+        ``valid_metric`` improves."""
+        try:
+            best_perf = -1. #Assume the higher the better >= 0
+            for epoch in range(1, num_epochs + 1):
+                self.train_epoch(epoch, train_data, verbose)
+                if valid_data:
+                    assert valid_metric is not None, \
+                                "In case of validation 'valid_metric' must be provided"
+                    valid_res = valid_func(self, valid_data, valid_metric)
+                    mu_val = np.mean(valid_res)
+                    std_err_val = np.std(valid_res) / np.sqrt(len(valid_res))
+                    logger.info('| epoch %d | %s %.3f (%.4f) |',
+                                epoch, valid_metric, mu_val, std_err_val)
+                    if best_perf < mu_val:
+                        self.save_model(best_path, epoch)
+                        best_perf = mu_val
+        except KeyboardInterrupt:
+            logger.warning('Handled KeyboardInterrupt: exiting from training early')
+
+    def save_model(self, filepath, cur_epoch):
+        r"""Save the model to file (reference models.py:897-903): adds ``gradient_updates``."""
+        self._sync_optimizer_state()
+        state = {'epoch': cur_epoch,
+                 'state_dict': self.network.state_dict(),
+                 'optimizer': self.optimizer.state_dict(),
+                 'gradient_updates': self.gradient_updates
+                }
+        self._save_checkpoint(filepath, state)
+
+    def load_model(self, filepath):
+        r"""Load the model from file and restore ``gradient_updates`` (reference models.py:905-908)."""
+        checkpoint = super().load_model(filepath)
+        self.gradient_updates = checkpoint['gradient_updates']
+        return checkpoint

@@ -1,0 +1,454 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the Python mirror of the
+reference API and the C ABI, against (a) golden vectors generated from the reference itself and (b) the CPU
+oracle on the same seeded inputs, plus size-independent properties at the full ml-20m shape.
+
+Tolerances.  fp32 ("parity") mode: logits within 1e-5 relative to max|logits| (the north star's criterion),
+gradients 2e-4, parameters after Adam 2e-6 absolute.  bf16 mode: operands rounded to 8 bits of mantissa with
+f32 accumulation -> logits ~1e-2 relative; gated by nDCG@100 / Recall@50 parity instead.
+"""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+from scipy.sparse import csr_matrix
+
+from conftest import ROOT, load_golden, sd_from, params_in_order
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_native_path():
+    from rectorch_amd import _lib
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _lib.lib()          # raises if librectorch_hip.so is missing: no fallback
+
+
+def make_vae(enc, dec, p, sd, **kw):
+    from rectorch_amd.nets import MultiVAE_net
+    from rectorch_amd.models import MultiVAE
+    net = MultiVAE_net(list(dec), list(enc), dropout=p)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return net, MultiVAE(net, **kw)
+
+
+def make_dae(enc, dec, p, sd, **kw):
+    from rectorch_amd.nets import MultiDAE_net
+    from rectorch_amd.models import MultiDAE
+    net = MultiDAE_net(list(dec), list(enc), dropout=p)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return net, MultiDAE(net, **kw)
+
+
+# ---------------------------------------------------------------------------------------------- native drivers
+@pytest.mark.parametrize("exe", ["test_gemm", "test_engine"])
+def test_native_driver(exe):
+    """the no-Python drivers: MFMA GEMM vs host double loops; the whole engine vs the C oracle via the C ABI"""
+    path = os.path.join(ROOT, "build", "native", exe)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native")])
+    out = subprocess.run([path], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "PASSED" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------- golden: forward
+def test_g1_eval_forward_logits_1e5():
+    g = load_golden("g1_mvae_fwd_eval_small")
+    I, H, L = [int(v) for v in g["dims"]]
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd_from(g, "sd__"), beta=0.2)
+    net.eval()
+    y, mu, logvar = net(torch.from_numpy(g["x"]))
+    assert y.is_cuda and y.shape == (5, I) and mu.shape == (5, L)
+    assert rel(y.cpu(), g["logits"]) < 1e-5
+    assert rel(mu.cpu(), g["mu"]) < 1e-5 and rel(logvar.cpu(), g["logvar"]) < 1e-5
+    mu2, lv2 = net.encode(torch.from_numpy(g["x"]))
+    assert torch.equal(mu, mu2) and torch.equal(logvar, lv2)
+    assert rel(net.decode(mu).cpu(), g["logits"]) < 1e-5
+    loss = model.loss_function(y, dev(g["x"]), mu, logvar, float(g["beta"]))
+    assert loss.dim() == 0 and abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+
+
+def test_g7_predict_remove_train():
+    g = load_golden("g7_predict_remove_train")
+    I, H, L = [int(v) for v in g["dims"]]
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd_from(g, "sd__"))
+    x = torch.from_numpy(g["x"])
+    pred, mu, logvar = model.predict(x, remove_train=True)
+    p = pred.cpu().numpy()
+    assert np.array_equal(np.isneginf(p), np.isneginf(g["pred"]))
+    assert int(np.isneginf(p).sum()) == int(g["n_neg_inf"])
+    fin = np.isfinite(g["pred"])
+    assert rel(p[fin], g["pred"][fin]) < 1e-5
+    assert rel(model.predict(x, remove_train=False)[0].cpu(), g["pred_keep"]) < 1e-5
+    assert np.array_equal(x.numpy(), g["x"])        # the caller's x is not modified
+    assert not net.training                         # predict() leaves the net in eval mode, like the reference
+
+
+# ---------------------------------------------------------------------------------------------- golden: training
+@pytest.mark.parametrize("name", ["g2_mvae_train_step_small", "g2b_mvae_train_step_te", "g2c_mvae_train_step_deep"])
+def test_g2_train_steps_fp32(name):
+    """3 Adam steps with the reference's own dropout masks / eps injected: loss, grads, params, moments"""
+    g = load_golden(name)
+    enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
+    beta, anneal, p, lr = [float(v) for v in g["meta"]]
+    net, model = make_vae(enc, dec, p, sd_from(g, "sd0__"), beta=beta, anneal_steps=int(anneal), learning_rate=lr,
+                          numerics="fp32")
+    _, keys = params_in_order(sd_from(g, "sd0__"))
+    for t in range(g["xs"].shape[0]):
+        model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), dev(g["eps_%d" % t]))
+        gt = torch.from_numpy(g["gts"][t]) if "gts" in g else None
+        loss = model.train_batch(torch.from_numpy(g["xs"][t]), gt)
+        assert isinstance(loss, float)
+        assert abs(loss - float(g["loss_%d" % t])) < 1e-5 * abs(float(g["loss_%d" % t])), (t, loss)
+        sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
+        for k, prm, ref in zip(keys, net._param_list(), sd_t):
+            gref = g["grad_%d__%s" % (t, k.replace(".", "__"))]
+            assert rel(prm.grad.cpu(), gref) < 2e-4, (t, k)
+            assert float(np.max(np.abs(prm.detach().cpu().numpy() - ref))) < 5e-6, (t, k)
+            st = model.optimizer.state[prm]
+            assert rel(st["exp_avg"].cpu(), g["exp_avg_%d__%s" % (t, k.replace(".", "__"))]) < 2e-4
+            assert rel(st["exp_avg_sq"].cpu(), g["exp_avg_sq_%d__%s" % (t, k.replace(".", "__"))]) < 4e-4
+    assert model.gradient_updates == float(g["gradient_updates"])
+
+
+def test_g4_dae_train_steps_fp32():
+    g = load_golden("g4_mdae_train_step_small")
+    enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
+    lam, wd, p, lr = [float(v) for v in g["meta"]]
+    net, model = make_dae(enc, dec, p, sd_from(g, "sd0__"), lam=lam, learning_rate=lr, numerics="fp32")
+    assert model.optimizer.param_groups[0]["weight_decay"] == wd
+    _, keys = params_in_order(sd_from(g, "sd0__"))
+    for t in range(3):
+        model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), None)
+        loss = model.train_batch(torch.from_numpy(g["xs"][t]))
+        assert abs(loss - float(g["loss_%d" % t])) < 1e-5 * abs(float(g["loss_%d" % t]))
+        sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
+        for k, prm, ref in zip(keys, net._param_list(), sd_t):
+            assert float(np.max(np.abs(prm.detach().cpu().numpy() - ref))) < 5e-6, (t, k)
+    pred = model.predict(torch.from_numpy(g["xs"][0]), True)
+    assert isinstance(pred, tuple) and len(pred) == 1
+    fin = np.isfinite(g["pred_after"])
+    assert rel(pred[0].cpu().numpy()[fin], g["pred_after"][fin]) < 1e-4
+    x0 = dev(g["xs"][0])
+    lf = model.loss_function(model.predict(x0, False)[0], x0)
+    assert lf.dim() == 0 and np.isfinite(lf.item())
+
+
+# ---------------------------------------------------------------------------------------------- golden: real K = 20108
+def _g3_setup(numerics):
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    g = load_golden("g3_mvae_fwd_ml20m_slice")
+    I, H, L = [int(v) for v in g["dims"]]
+    X = synth_interactions(int(g["synth_users"]), I, seed=int(g["synth_seed"]))
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", int(g["hash_seed"]))
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=float(g["beta"]), numerics=numerics, predict_numerics=numerics)
+    x = torch.from_numpy(np.asarray(X[g["rows"]].toarray(), dtype=np.float32))
+    return g, I, H, L, net, model, x
+
+
+def test_g3_full_size_forward_fp32_1e5():
+    """the 1e-5 logits criterion at the real contraction length (K = 20108 and K = 600)"""
+    g, I, H, L, net, model, x = _g3_setup("fp32")
+    net.eval()
+    y, mu, logvar = net(x)
+    assert rel(y.cpu().numpy()[:, ::257], g["logits_s257"]) < 1e-5
+    assert rel(mu.cpu(), g["mu"]) < 1e-5 and rel(logvar.cpu(), g["logvar"]) < 1e-5
+    lse = torch.logsumexp(y.double(), 1).cpu().numpy()
+    assert np.max(np.abs(lse - g["lse"])) < 2e-5
+    loss = model.loss_function(y, x.cuda(), mu, logvar, float(g["beta"])).item()
+    assert abs(loss - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+
+
+def test_g3_full_size_training_step_fp32():
+    g, I, H, L, net, model, x = _g3_setup("fp32")
+    mask = np.unpackbits(g["mask_bits"], axis=1)[:, :I]
+    model._rtx.inject = (dev(mask, torch.uint8), dev(g["eps"]))
+    loss = model.train_batch(x)
+    assert abs(loss - float(g["train_loss"])) < 1e-5 * abs(float(g["train_loss"]))
+    ps = net._param_list()
+    assert rel(ps[0].grad.cpu().numpy()[::37, ::211], g["gW1_s"]) < 2e-4
+    assert rel(ps[1].grad.cpu(), g["gb1"]) < 2e-4
+    assert rel(ps[2].grad.cpu().numpy()[::7, ::11], g["gW2_s"]) < 2e-4
+    assert rel(ps[3].grad.cpu(), g["gb2"]) < 2e-4
+    assert rel(ps[4].grad.cpu().numpy()[::11, ::7], g["gW3_s"]) < 2e-4
+    assert rel(ps[5].grad.cpu(), g["gb3"]) < 2e-4
+    assert rel(ps[6].grad.cpu().numpy()[::211, ::37], g["gW4_s"]) < 2e-4
+    assert rel(ps[7].grad.cpu().numpy()[::101], g["gb4_s"]) < 2e-4
+
+
+def test_g3_full_size_bf16_within_stated_tolerance():
+    g, I, H, L, net, model, x = _g3_setup("bf16")
+    net.eval()
+    eng = net.rtx_engine("bf16", x.shape[0])
+    y, mu, logvar = eng.forward(net._as_input(x))
+    e_logits = rel(y.cpu().numpy()[:, ::257], g["logits_s257"])
+    print("bf16 logits rel err at K=20108: %.3e" % e_logits)
+    assert e_logits < 3e-2
+    mask = np.unpackbits(g["mask_bits"], axis=1)[:, :I]
+    model._rtx.inject = (dev(mask, torch.uint8), dev(g["eps"]))
+    loss = model.train_batch(x)
+    assert abs(loss - float(g["train_loss"])) < 5e-3 * abs(float(g["train_loss"]))
+    ps = net._param_list()
+    assert rel(ps[6].grad.cpu().numpy()[::211, ::37], g["gW4_s"]) < 5e-2
+    assert rel(ps[0].grad.cpu().numpy()[::37, ::211], g["gW1_s"]) < 5e-2
+
+
+# ---------------------------------------------------------------------------------------------- sampler on the device
+def test_g5_resident_sampler_matches_reference_batches():
+    from rectorch_amd.samplers import DataSampler
+    g = load_golden("g5_sampler_batches")
+    tr, te = csr_matrix(g["dense_tr"]), csr_matrix(g["dense_te"])
+    for tag, (shuffle, with_te) in {"ns": (False, False), "s": (True, False), "ste": (True, True)}.items():
+        np.random.seed(int(g["np_seed"]))
+        smp = DataSampler(tr, te if with_te else None, batch_size=8, shuffle=shuffle)
+        assert smp.resident and len(smp) == 5
+        for e in range(2):
+            for b, (dtr, dte) in enumerate(smp):
+                assert dtr.is_cuda and dtr.dtype == torch.float32
+                assert np.array_equal(dtr.cpu().numpy(), g["%s_e%d_b%d_tr" % (tag, e, b)])
+                if with_te:
+                    assert np.array_equal(dte.cpu().numpy(), g["%s_e%d_b%d_te" % (tag, e, b)])
+                else:
+                    assert dte is None
+    # weighted (non-binary) values survive the upload
+    w = csr_matrix(np.array([[0, 2.5, 0, 1.0], [3.0, 0, 0, 0]]))
+    (d, _), = list(DataSampler(w, batch_size=2, shuffle=False))
+    assert np.array_equal(d.cpu().numpy(), w.toarray().astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------- end-to-end trajectory
+@pytest.mark.parametrize("numerics,tol_loss,tol_metric", [("fp32", 2e-4, 2e-3), ("bf16", 2e-2, 3e-2)])
+def test_g8_epoch_curve(numerics, tol_loss, tol_metric):
+    """5 epochs (8 batches each) on 512x128 synthetic data with the reference's RNG draws injected: per-batch
+    loss trajectory, and nDCG@100 / Recall@50 per epoch through evaluate()."""
+    from rectorch_amd.utils import hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.evaluation import evaluate
+    g = load_golden("g8_epoch_curve")
+    I, H, L = [int(v) for v in g["dims"]]
+    beta, anneal, p, lr, B = [float(v) for v in g["meta"]]
+    B = int(B)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", int(g["hash_seed"]), bias_std=0.1)
+    net, model = make_vae([I, H, L], [L, H, I], p, sd, beta=beta, anneal_steps=int(anneal), learning_rate=lr,
+                          numerics=numerics)
+    train = csr_matrix(g["dense_train"].astype(np.float64))
+    val_tr, val_te = csr_matrix(g["val_tr"].astype(np.float64)), csr_matrix(g["val_te"].astype(np.float64))
+    masks = np.unpackbits(g["mask_bits"], axis=-1)[..., :I]
+    n_epochs = g["losses"].shape[0]
+    for e in range(n_epochs):
+        np.random.seed(8000 + e)
+        smp = DataSampler(train, batch_size=B, shuffle=True)
+        net.train()
+        for b, rb in enumerate(smp.iter_rows()):
+            assert np.array_equal(rb.rows.cpu().numpy(), g["perms"][e][b * B:(b + 1) * B])
+            model._rtx.inject = (dev(masks[e, b], torch.uint8), dev(g["eps"][e, b]))
+            loss = model._fused_step(rb, None, want_loss=True)
+            assert abs(loss - g["losses"][e, b]) < tol_loss * abs(g["losses"][e, b]), (e, b, loss, g["losses"][e, b])
+        res = evaluate(model, DataSampler(val_tr, val_te, batch_size=32, shuffle=False), ["ndcg@100", "recall@50"])
+        assert abs(np.mean(res["ndcg@100"]) - g["ndcg100"][e]) < tol_metric
+        assert abs(np.mean(res["recall@50"]) - g["recall50"][e]) < tol_metric
+    if numerics == "fp32":
+        assert np.max(np.abs(res["ndcg@100"] - g["ndcg100_users"])) < 2e-2    # per-user, rank flips on near-ties only
+        sdf = sd_from(g, "sd_final__")
+        for k, v in net.state_dict().items():
+            assert float(np.max(np.abs(v.cpu().numpy() - sdf[k]))) < 2e-4, k
+
+
+# ---------------------------------------------------------------------------------------------- the reference's own model tests
+def test_reference_test_multivae_semantics():
+    """restates reference tests/test_models.py:213-283 (test_MultiVAE) on the HIP path"""
+    from rectorch_amd.nets import MultiVAE_net
+    from rectorch_amd.models import MultiVAE
+    from rectorch_amd.samplers import DataSampler
+    net = MultiVAE_net([1, 2], [2, 1], .1)
+    model = MultiVAE(net)
+    assert model.device == torch.device("cuda") and isinstance(model.optimizer, torch.optim.Adam)
+    gt = torch.FloatTensor([[1, 1], [2, 1]])
+    pred = torch.sigmoid(torch.FloatTensor([[1, 1], [1, 1]]))
+    torch.manual_seed(12345)
+    mu, logvar = model.network.encode(gt)
+    assert model.loss_function(pred, gt, mu, logvar).item() != 0.0
+    train = csr_matrix((np.ones(3), (np.array([0, 0, 1]), np.array([0, 1, 1]))))
+    sampler = DataSampler(train, batch_size=1, shuffle=False)
+    x = torch.FloatTensor([[1, 1], [2, 2]])
+    model.predict(x, True)
+    out_1 = model.predict(x, False)[0]
+    model.train(sampler, num_epochs=10, verbose=4)
+    out_2 = model.predict(x, False)[0]
+    assert not torch.all(out_1.eq(out_2)), "the outputs should be different after training"
+    tmp = tempfile.NamedTemporaryFile()
+    model.save_model(tmp.name, 1)
+    model2 = MultiVAE(MultiVAE_net([1, 2], [2, 1], .1))
+    model2.load_model(tmp.name)
+    assert torch.all(model.predict(x, False)[0].eq(model2.predict(x, False)[0])), "the outputs should be the same"
+    sampler = DataSampler(train, train, batch_size=1, shuffle=False)
+    tmp2 = tempfile.NamedTemporaryFile()
+    model = MultiVAE(MultiVAE_net([1, 2], [2, 1], .1), 1., 5)
+    model.train(sampler, valid_data=sampler, valid_metric="ndcg@1", num_epochs=10, best_path=tmp2.name)
+    model2 = MultiVAE(MultiVAE_net([1, 2], [2, 1], .1), 1., 5)
+    assert model2.gradient_updates == 0
+    model2.load_model(tmp2.name)
+    assert model2.gradient_updates > 0
+    with pytest.raises(AssertionError):
+        model.train(sampler, valid_data=sampler, num_epochs=1)          # valid_metric is required
+
+
+def test_reference_test_multidae_and_nets_semantics():
+    """restates reference tests/test_models.py:159-211 (test_MultiDAE) and tests/test_nets.py:27-75"""
+    from rectorch_amd.nets import MultiDAE_net, MultiVAE_net
+    from rectorch_amd.models import MultiDAE
+    from rectorch_amd.samplers import DataSampler
+    net = MultiDAE_net([1, 2], [2, 1], dropout=.1)
+    model = MultiDAE(net)
+    x = torch.FloatTensor([[1, 1], [2, 2]])
+    y = net(x)
+    assert y.shape == x.shape and y.dtype == torch.float32
+    train = csr_matrix((np.ones(3), (np.array([0, 0, 1]), np.array([0, 1, 1]))))
+    sampler = DataSampler(train, batch_size=1, shuffle=False)
+    out_1 = model.predict(x, False)[0]
+    model.train(sampler, num_epochs=10, verbose=4)
+    out_2 = model.predict(x, False)[0]
+    assert not torch.all(out_1.eq(out_2))
+    tmp = tempfile.NamedTemporaryFile()
+    model.save_model(tmp.name, 1)
+    model2 = MultiDAE(MultiDAE_net([1, 2], [2, 1], dropout=.1))
+    model2.load_model(tmp.name)
+    assert torch.all(model.predict(x, False)[0].eq(model2.predict(x, False)[0]))
+    # MultiVAE_net: same seed -> encode() and forward() agree on mu/logvar in training mode (RNG order)
+    vnet = MultiVAE_net([1, 2], [2, 1], .1).cuda()
+    vnet.train()
+    torch.manual_seed(98765)
+    mu, logvar = vnet.encode(x)
+    torch.manual_seed(98765)
+    y, mu2, logvar2 = vnet(x)
+    assert mu.equal(mu2) and logvar.equal(logvar2) and y.shape == x.shape
+
+
+# ---------------------------------------------------------------------------------------------- oracle parity at scale
+@pytest.mark.parametrize("numerics", ["fp32", "bf16"])
+def test_ndcg_recall_parity_vs_oracle_ml20m_items(numerics):
+    """nDCG@100 / Recall@50 of predict() on 192 held-out users at I = 20108 vs the CPU oracle, same weights"""
+    from oracle import c_oracle
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.utils.synth import split_heldout
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.evaluation import evaluate
+    from rectorch_amd.metrics import Metrics
+    I, H, L = 20108, 600, 200
+    X = synth_interactions(192, I, seed=99)
+    val_tr, val_te = split_heldout(X, 0.2, seed=3)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 777, bias_std=0.05)
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, predict_numerics=numerics)
+    res = evaluate(model, DataSampler(val_tr, val_te, batch_size=64, shuffle=False), ["ndcg@100", "recall@50"])
+    params, _ = params_in_order(sd)
+    xo = np.asarray(val_tr.toarray(), dtype=np.float32)
+    lo = c_oracle.predict([I, H, L], [L, H, I], params, xo, True)[0]
+    ro = Metrics.compute(lo, np.asarray(val_te.toarray(), dtype=np.float32), ["ndcg@100", "recall@50"])
+    d_ndcg = abs(np.mean(res["ndcg@100"]) - np.mean(ro["ndcg@100"]))
+    d_rec = abs(np.mean(res["recall@50"]) - np.mean(ro["recall@50"]))
+    print("%s: nDCG@100 hip %.5f oracle %.5f | Recall@50 hip %.5f oracle %.5f" % (
+        numerics, np.mean(res["ndcg@100"]), np.mean(ro["ndcg@100"]), np.mean(res["recall@50"]), np.mean(ro["recall@50"])))
+    tol = 1e-4 if numerics == "fp32" else 5e-3
+    assert d_ndcg < tol and d_rec < tol
+    if numerics == "fp32":
+        assert np.max(np.abs(res["ndcg@100"] - ro["ndcg@100"])) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- properties at the full shape
+def test_full_size_properties_b500():
+    """ml-20m shape, B = 500, bf16: properties that need no reference at this size."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.engine import RowBatch
+    I, H, L, B = 20108, 600, 200, 500
+    X = synth_interactions(2000, I, seed=5)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 31, bias_std=0.05)
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=1000, numerics="bf16")
+    smp = DataSampler(X, batch_size=B, shuffle=False)
+    rbs = list(smp.iter_rows())
+    assert len(rbs) == 4 and len(rbs[0]) == B
+    # (1) predict: exactly nnz(x) scores are -inf, everything else finite
+    pred = model.predict(smp._csr_tr.gather_dense(rbs[0].rows))[0]
+    assert int(torch.isinf(pred).sum().item()) == int(X[:B].nnz) and not torch.isnan(pred).any()
+    # (2) data-parallel identity: gradients of the full batch == sum of the two half-batches' gradients at the
+    #     same 1/B scale (what the RCCL all-reduce computes), with the same dropout mask / eps
+    st, params, m, v = model._ensure_train_state()
+    eng = net.rtx_engine("bf16", B, train_buffers=(st.grads, m, v))
+    gen = torch.Generator().manual_seed(1)
+    mask = (torch.rand(B, I, generator=gen) >= 0.5).to(torch.uint8).cuda()
+    eps = torch.randn(B, L, generator=gen).cuda()
+    kw = dict(beta=0.1, lam=0.0, inv_batch=1.0 / B, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1)
+    loss = torch.zeros(2, device="cuda")
+    eng.loss_grads(rbs[0], None, eng._step(mask=mask, noise=eps, **kw), loss[0:1])
+    full = st.flat_grads.clone()
+    full_loss = loss[0].item()
+    acc = torch.zeros_like(full)
+    half_loss = 0.0
+    for lo, hi in ((0, 250), (250, 500)):
+        rb = RowBatch(rbs[0].tr, None, rbs[0].rows[lo:hi].contiguous())
+        eng.loss_grads(rb, None, eng._step(mask=mask[lo:hi].contiguous(), noise=eps[lo:hi].contiguous(), **kw), loss[0:1])
+        acc += st.flat_grads
+        half_loss += loss[0].item()
+    assert abs(half_loss - full_loss) < 1e-4 * abs(full_loss)
+    assert float((acc - full).abs().max() / full.abs().max()) < 2e-3
+    # (3) sum_i d loss / d b_out[i] = sum_b (s_b * sum_i softmax_bi - s_b) / B = 0 (softmax rows sum to one)
+    gb_out = net._param_list()[-1].grad
+    assert abs(float(gb_out.sum())) < 2e-2 * float(gb_out.abs().sum())
+    # (4) training drives the loss down and keeps the replicas' invariants: finite params, Adam step count
+    torch.manual_seed(0)
+    losses = [model._fused_step(rbs[i % 4], None, want_loss=True) for i in range(24)]
+    assert np.isfinite(losses).all() and np.mean(losses[-4:]) < np.mean(losses[:4])
+    assert model._rtx.adam_step == 24 and model.gradient_updates == 24.0
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    # (5) determinism: same torch seed -> bit-identical loss sequence from the Philox path
+    net2, model2 = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=1000, numerics="bf16")
+    torch.manual_seed(0)
+    l2 = [model2._fused_step(rbs[i % 4], None, want_loss=True) for i in range(3)]
+    assert l2 == losses[:3]
+
+
+def test_edge_cases():
+    """empty rows, single-item rows, batch of 1, ragged last batch, dense vs resident input agree"""
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.utils import hash_state_dict
+    I, H, L = 300, 40, 10
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 5, bias_std=0.2)
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, numerics="fp32")
+    dense = np.zeros((7, I), dtype=np.float64)
+    dense[0, [3, 7, 299]] = 1
+    dense[2, 5] = 1                      # rows 1, 3 are empty
+    dense[4, :] = 1                      # a user who has every item
+    dense[5, 10:20] = 2.0
+    dense[6, 0] = 1
+    X = csr_matrix(dense)
+    smp = DataSampler(X, batch_size=3, shuffle=False)
+    batches = list(smp)
+    assert [b[0].shape[0] for b in batches] == [3, 3, 1]
+    for (d, _), lo in zip(batches, (0, 3, 6)):
+        p_res = model.predict(d)[0]                                   # resident rows (tensor carries its row ids)
+        p_dense = model.predict(torch.from_numpy(dense[lo:lo + d.shape[0]].astype(np.float32)))[0]   # dense drop-in
+        assert torch.equal(torch.isinf(p_res), torch.isinf(p_dense))
+        fin = torch.isfinite(p_res)
+        assert torch.allclose(p_res[fin], p_dense[fin], rtol=0, atol=1e-6)
+        assert not torch.isnan(p_res).any()
+    assert bool(torch.isinf(model.predict(batches[1][0])[0][1]).all())           # all items removed for user 4
+    torch.manual_seed(3)
+    l1 = model.train_batch(batches[2][0])                                         # batch of one
+    assert np.isfinite(l1)
+    empty_only = torch.zeros(2, I)
+    assert np.isfinite(model.train_batch(empty_only))                              # all-zero rows: loss is just KL
+    with pytest.raises(Exception):
+        model.predict(torch.zeros(2, I + 1))                                      # wrong width fails loudly

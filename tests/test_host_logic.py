@@ -1,0 +1,260 @@
+"""CPU tests of the host side of the path: metrics / evaluate / sampler / class API / checkpoints.
+They restate the reference's own tests (tests/test_metrics.py, test_evaluation.py, test_samplers.py,
+test_nets.py, test_models.py) for the pieces that do not compute, and pin them to golden vectors."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+from scipy.sparse import csr_matrix
+
+from conftest import load_golden, GOLDEN
+from rectorch_amd.metrics import Metrics
+from rectorch_amd.evaluation import evaluate, one_plus_random, ValidFunc
+from rectorch_amd.models import RecSysModel, TorchNNTrainer, AETrainer, VAE, MultiVAE, MultiDAE
+from rectorch_amd.nets import AE_net, MultiDAE_net, VAE_net, MultiVAE_net
+from rectorch_amd.samplers import Sampler, DataSampler
+from rectorch_amd.parallel import shard_rows
+from rectorch_amd import utils
+
+HAS_GPU = torch.cuda.is_available()
+
+
+# ------------------------------------------------------------------ metrics (reference tests/test_metrics.py:14-82)
+def test_metrics_reference_kats():
+    scores = np.array([[4., 3., 2., 1.]])
+    gt1, gt2 = np.array([[1., 1., 0., 0.]]), np.array([[0., 0., 1., 1.]])
+    assert Metrics.ndcg_at_k(scores, gt1, 2) == np.array([1.])
+    assert Metrics.ndcg_at_k(scores, gt2, 2) == np.array([0.])
+    assert np.abs(Metrics.ndcg_at_k(scores, gt2, 3) - 0.3065735964) < 1e-5
+    assert Metrics.recall_at_k(scores, gt1, 2) == np.array([1.])
+    assert Metrics.recall_at_k(scores, gt2, 2) == np.array([0.])
+    s5, g5 = np.array([[4., 3., 2., 1., 0.]]), np.array([[1., 1., 0., 0., 1.]])
+    assert np.abs(Metrics.recall_at_k(s5, g5, 3) - 0.6666666) < 1e-5
+    assert Metrics.hit_at_k(scores, gt2, 3) == np.array([True])
+    assert Metrics.hit_at_k(scores, gt2, 2) == np.array([False])
+    assert np.allclose(Metrics.mrr_at_k(np.array([[4., 2., 3., 1.], [1., 2., 3., 4.]]),
+                                        np.array([[0, 0, 1., 1.], [0, 0, 1., 1.]]), 3), [0.5, 1.0])
+    res = Metrics.compute(scores, gt1, ["ndcg@2", "recall@2", "pippo@3", "ndcg_at_k"])
+    assert set(res) == {"ndcg@2", "recall@2", "ndcg_at_k"}          # unknown metric skipped
+
+
+def test_metrics_golden_g6():
+    g = load_golden("g6_metrics")
+    mets = ["ndcg@100", "ndcg@10", "recall@50", "recall@20", "hit@5", "mrr@10", "ndcg@1000"]
+    res = Metrics.compute(g["scores"], g["heldout"], mets)
+    for m in mets:
+        ref = g["res__" + m.replace("@", "_at_")]
+        assert np.allclose(np.asarray(res[m], dtype=np.float64), ref, rtol=1e-12, atol=0, equal_nan=True), m
+    assert np.array_equal(Metrics.ndcg_at_k(np.array([[4., 3., 2., 1.]]), np.array([[0., 0., 1., 1.]]), 3), g["kat_ndcg3_b"])
+
+
+# ------------------------------------------------------------------ evaluate (reference tests/test_evaluation.py)
+class FakeModel(RecSysModel):
+    def predict(self, x, *args, **kwargs):
+        return (x + torch.FloatTensor([[1] * 4]), )
+
+
+class FakeSampler(Sampler):
+    def __iter__(self):
+        scores = [torch.FloatTensor([[4., 3., 2., 1.]]), torch.FloatTensor([[4., 3., 2., 1.]])]
+        gt = [torch.FloatTensor([[1., 1., 0., 0.]]), torch.FloatTensor([[0, 0, 1., 1.]])]
+        for i in range(2):
+            yield scores[i], gt[i]
+
+
+def test_evaluate_and_validfunc():
+    res = evaluate(FakeModel(), FakeSampler(), ["ndcg@3", "recall@2"])
+    assert isinstance(res, dict) and set(res) == {"ndcg@3", "recall@2"}
+    assert res['ndcg@3'][0] == 1. and abs(res['ndcg@3'][1] - 0.3065735964) < 1e-7
+    assert res['recall@2'][0] == 1. and res['recall@2'][1] == 0.
+    res = one_plus_random(FakeModel(), FakeSampler(), ["mrr@1", "hit@1"], r=2)
+    assert len(res['hit@1']) == 4 and len(res['mrr@1']) == 4
+    assert list(res['hit@1']) == [1, 1, 0, 0] and list(res['mrr@1']) == [1, 1, 0, 0]
+    with pytest.raises(ValueError):
+        one_plus_random(FakeModel(), FakeSampler(), ["mrr@1", "hit@1"], r=3)
+    vfun = ValidFunc(one_plus_random, r=2)
+    out = vfun(FakeModel(), FakeSampler(), "mrr@1")
+    assert isinstance(out, np.ndarray) and list(out) == [1, 1, 0, 0]
+    with pytest.raises(AssertionError):
+        def addfun(a=1, b=2, c=3, d=4):
+            return a + b + c + d
+        ValidFunc(addfun, b=3)
+    ValidFunc(evaluate)
+    assert repr(vfun) == str(vfun) == "ValidFunc(fun='one_plus_random', params={'r': 2})"
+
+
+# ------------------------------------------------------------------ samplers (reference tests/test_samplers.py:14-56)
+def test_sampler_base_and_host_datasampler():
+    s = Sampler()
+    with pytest.raises(NotImplementedError):
+        len(s)
+    with pytest.raises(NotImplementedError):
+        for _ in s:
+            pass
+    train = csr_matrix((np.ones(4), (np.array([0, 0, 1, 1]), np.array([0, 1, 1, 2]))))
+    val_tr = csr_matrix((np.array([1.]), (np.array([0]), np.array([0]))), shape=(1, 3))
+    val_te = csr_matrix((np.array([1.]), (np.array([0]), np.array([1]))), shape=(1, 3))
+    sampler = DataSampler(train, batch_size=1, shuffle=False, device="cpu")
+    assert len(sampler) == 2
+    for attr in ("sparse_data_tr", "sparse_data_te", "batch_size", "shuffle"):
+        assert hasattr(sampler, attr)
+    for i, (t, none) in enumerate(sampler):
+        assert none is None and isinstance(t, torch.FloatTensor)
+        assert np.all(t.numpy() == (np.array([1, 1, 0]) if i == 0 else np.array([0, 1, 1])))
+    sampler = DataSampler(val_tr, val_te, batch_size=1, shuffle=True, device="cpu")
+    assert len(sampler) == 1
+    for tr, te in sampler:
+        assert np.all(tr.numpy() == np.array([1, 0, 0])) and np.all(te.numpy() == np.array([0, 1, 0]))
+
+
+def test_sampler_host_golden_g5():
+    """same global-numpy-RNG permutation, same ragged last batch, fresh permutation per iter()"""
+    g = load_golden("g5_sampler_batches")
+    tr, te = csr_matrix(g["dense_tr"]), csr_matrix(g["dense_te"])
+    for tag, (shuffle, with_te) in {"ns": (False, False), "s": (True, False), "ste": (True, True)}.items():
+        np.random.seed(int(g["np_seed"]))
+        smp = DataSampler(tr, te if with_te else None, batch_size=8, shuffle=shuffle, device="cpu")
+        assert len(smp) == int(g["len_" + tag]) == 5
+        for e in range(2):
+            nb = 0
+            for b, (dtr, dte) in enumerate(smp):
+                assert np.array_equal(dtr.numpy(), g["%s_e%d_b%d_tr" % (tag, e, b)])
+                if with_te:
+                    assert np.array_equal(dte.numpy(), g["%s_e%d_b%d_te" % (tag, e, b)])
+                else:
+                    assert dte is None
+                nb += 1
+            assert nb == 5 and dtr.shape[0] == 5         # ragged last batch: 37 = 4*8 + 5
+
+
+# ------------------------------------------------------------------ nets: structure (reference tests/test_nets.py:27-75)
+def test_net_structure_and_init_rule():
+    with pytest.raises(NotImplementedError):
+        AE_net([1, 2], [2, 1]).encode(torch.zeros(1, 2))
+    net = MultiVAE_net([1, 2], [2, 1], .1)
+    for attr in ("enc_dims", "dec_dims", "dropout", "dec_layers", "enc_layers"):
+        assert hasattr(net, attr)
+    assert isinstance(net.dropout, torch.nn.Dropout) and net.dropout.p == .1
+    assert net.enc_dims == [2, 1] and net.dec_dims == [1, 2]
+    assert [tuple(p.shape) for p in net.parameters()] == [(2, 2), (2,), (2, 1), (2,)]     # last enc layer: 2*latent
+    dnet = MultiDAE_net([1, 2], [2, 1], dropout=.1)
+    assert [tuple(p.shape) for p in dnet.parameters()] == [(1, 2), (1,), (2, 1), (2,)]
+    assert dnet.dropout.p == .1
+    net = MultiVAE_net([200, 600, 2000])
+    assert net.enc_dims == [2000, 600, 200] and net.dropout.p == 0.5
+    assert list(net.state_dict().keys()) == ["enc_layers.0.weight", "enc_layers.0.bias", "enc_layers.1.weight",
+                                             "enc_layers.1.bias", "dec_layers.0.weight", "dec_layers.0.bias",
+                                             "dec_layers.1.weight", "dec_layers.1.bias"]
+    w = net.enc_layers[0].weight.detach()
+    a = np.sqrt(6.0 / (2000 + 600))
+    assert float(w.abs().max()) <= a + 1e-6 and float(w.abs().max()) > 0.9 * a       # xavier_uniform
+    b = torch.cat([l.bias.detach() for l in list(net.enc_layers) + list(net.dec_layers)])
+    assert 0.9 < float(b.std()) < 1.1                                                  # N(0,1) biases
+    with pytest.raises(NotImplementedError):
+        VAE_net([1, 2]).encode(torch.zeros(1, 2))
+
+
+# ------------------------------------------------------------------ models: API surface (reference tests/test_models.py:190-290)
+def test_model_api_surface():
+    with pytest.raises(NotImplementedError):
+        RecSysModel().train(None)
+    with pytest.raises(NotImplementedError):
+        RecSysModel().predict(None)
+    net = MultiVAE_net([1, 2], [2, 1], .1)
+    model = MultiVAE(net)
+    for attr in ("network", "device", "learning_rate", "optimizer", "anneal_steps", "annealing", "gradient_updates", "beta"):
+        assert hasattr(model, attr)
+    assert model.learning_rate == 1e-3 and model.network == net
+    assert isinstance(model.optimizer, torch.optim.Adam)
+    assert model.optimizer.param_groups[0]["weight_decay"] == 0.0
+    assert model.annealing is False and model.gradient_updates == 0 and isinstance(model.gradient_updates, float)
+    assert str(model) == repr(model) and str(model).startswith("MultiVAE(")
+    assert model.device == torch.device("cuda" if HAS_GPU else "cpu")
+    m2 = MultiVAE(MultiVAE_net([1, 2], [2, 1], .1), 1., 5)
+    assert m2.annealing is True and m2.anneal_steps == 5
+    dae = MultiDAE(MultiDAE_net([1, 2], [2, 1], dropout=.1))
+    assert dae.lam == 0.2 and dae.optimizer.param_groups[0]["weight_decay"] == 0.001
+    assert isinstance(dae, AETrainer) and isinstance(model, VAE) and isinstance(model, TorchNNTrainer)
+    import inspect
+    assert list(inspect.signature(MultiVAE.train).parameters) == ["self", "train_data", "valid_data", "valid_metric",
+                                                                  "valid_func", "num_epochs", "best_path", "verbose"]
+    assert inspect.signature(MultiVAE.train).parameters["num_epochs"].default == 200
+    assert inspect.signature(MultiVAE.train).parameters["best_path"].default == "chkpt_best.pth"
+    assert list(inspect.signature(MultiDAE.train).parameters) == ["self", "train_data", "valid_data", "valid_metric",
+                                                                  "valid_func", "num_epochs", "verbose"]
+    assert list(inspect.signature(MultiVAE.__init__).parameters)[:5] == ["self", "mvae_net", "beta", "anneal_steps", "learning_rate"]
+    assert list(inspect.signature(MultiDAE.__init__).parameters)[:4] == ["self", "mdae_net", "lam", "learning_rate"]
+    assert list(inspect.signature(DataSampler.__init__).parameters)[:5] == ["self", "sparse_data_tr", "sparse_data_te", "batch_size", "shuffle"]
+
+
+@pytest.mark.skipif(HAS_GPU, reason="only meaningful without a HIP device")
+def test_compute_fails_loudly_without_gpu():
+    from rectorch_amd._lib import RtxError
+    net = MultiVAE_net([2, 4, 6])
+    model = MultiVAE(net)
+    x = torch.ones(2, 6)
+    for call in (lambda: net(x), lambda: net.encode(x), lambda: model.predict(x), lambda: model.train_batch(x),
+                 lambda: model.loss_function(x, x, x[:, :2], x[:, :2])):
+        with pytest.raises(RtxError):
+            call()
+
+
+def test_checkpoint_layout_and_reference_checkpoint_loads():
+    """G9: the reference's checkpoint (written by rectorch itself) loads; ours has the same layout."""
+    g = load_golden("g9_checkpoint_layout")
+    I, H, L = 12, 6, 3
+    model = MultiVAE(MultiVAE_net([L, H, I], dropout=0.5), beta=0.2, anneal_steps=5)
+    ck = model.load_model(os.path.join(GOLDEN, "g9_reference_checkpoint.pth"))
+    assert sorted(ck.keys()) == list(g["top_keys"])
+    assert model.gradient_updates == float(g["gradient_updates"]) == 1.0
+    assert model._rtx.adam_step == int(g["state_step"]) == 1
+    assert list(model.network.state_dict().keys()) == list(g["sd_keys"])
+    ref_sd = ck["state_dict"]
+    for k, v in model.network.state_dict().items():
+        assert torch.equal(v.cpu(), ref_sd[k].cpu())
+    st = model.optimizer.state[next(model.network.parameters())]
+    assert sorted(st.keys()) == list(g["state_keys"])
+    # save -> same top-level layout, same optimizer param_group keys, loads back
+    tmp = tempfile.NamedTemporaryFile(suffix=".pth")
+    model.save_model(tmp.name, 7)
+    ck2 = torch.load(tmp.name, map_location="cpu")
+    assert sorted(ck2.keys()) == list(g["top_keys"]) and ck2["epoch"] == 7
+    pg = {k: v for k, v in ck2["optimizer"]["param_groups"][0].items() if k != "params"}
+    assert sorted(pg.keys()) == list(g["pg_keys"])
+    assert float(ck2["optimizer"]["state"][0]["step"]) == 1.0
+    model2 = MultiVAE(MultiVAE_net([L, H, I], dropout=0.5), beta=0.2, anneal_steps=5)
+    assert model2.gradient_updates == 0
+    model2.load_model(tmp.name)
+    assert model2.gradient_updates == 1.0
+    for a, b in zip(model.network.parameters(), model2.network.parameters()):
+        assert torch.equal(a, b)
+    with pytest.raises(AssertionError):
+        model2.load_model("/nonexistent/file.pth")
+
+
+# ------------------------------------------------------------------ utilities
+def test_shard_rows_partition():
+    for n in (0, 1, 7, 500, 4096):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_rows(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                assert a[1] == b[0]
+            sizes = [e - s for s, e in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_hashinit_and_synth_are_deterministic():
+    a = utils.hash_uniform((3, 5), 7, 0.5)
+    b = utils.hash_uniform((3, 5), 7, 0.5)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and np.abs(a).max() <= 0.5
+    assert not np.array_equal(a, utils.hash_uniform((3, 5), 8, 0.5))
+    n = utils.hash_normal((20000,), 3)
+    assert abs(float(n.mean())) < 0.03 and abs(float(n.std()) - 1) < 0.03
+    X = utils.synth_interactions(300, 200, seed=5)
+    Y = utils.synth_interactions(300, 200, seed=5)
+    assert (X != Y).nnz == 0 and X.shape == (300, 200) and X.has_sorted_indices
+    d = np.diff(X.indptr)
+    assert d.min() >= 5 and np.all(X.data == 1)
