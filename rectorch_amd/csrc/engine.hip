@@ -19,6 +19,7 @@
 #include "rtx_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -78,6 +79,10 @@ struct rtx_engine {
     std::vector<float*> params, grads, m, v;
     bool bound = false, can_train = false, shadows_valid = false;
     TempCsr tmp_in, tmp_tg;
+    // per-layer Adam on a side stream, overlapped with the rest of the backward pass (single-GPU fused step)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool overlap_adam = false;  // measured slower on MI355X (see loss_grads_impl); RTX_OVERLAP_ADAM=1 re-enables
     // timing
     bool timing_all = false;
     std::map<std::string, bool> timing_sites;
@@ -171,15 +176,45 @@ struct ScopedTimer {
 #define TIMED(name) ScopedTimer RTX_CAT(_timer_, __LINE__)(e, name, st)
 
 // ---- GEMM helper -------------------------------------------------------------------------------------
-static int choose_splits(const rtx_engine* e, int tiles, int k_slices)
+static int choose_splits(const rtx_engine* e, int tiles, int k_slices, int tile_shape)
 {
-    if (tiles >= 192) return 1;
-    int s = (512 + tiles - 1) / tiles;
+    // Few output tiles (the skinny [B,n_items]x[n_items,hidden] contractions): split K so that one wave of
+    // workgroups fills the chip (2 per CU for 4-wave tiles, 1 per CU for 8-wave tiles), in multiples of 8 so
+    // every XCD owns whole splits (gemm.hip).
+    const int resident = tile_shape == RTX_TILE_128x128 ? 512 : 256;
+    if (tiles * 2 > resident) return 1;
+    int s = resident / tiles;
+    if (s >= 8) s &= ~7;
     if (k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
-    const int max_s = k_slices / 4 > 0 ? k_slices / 4 : 1;
+    const int max_s = k_slices / 2 > 0 ? k_slices / 2 : 1;  // at least two 128-byte K slices per workgroup
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     return s;
+}
+
+// Tile shape for an Mp x Np output.  Measured on MI355X at the ml-20m shapes (tests/native/test_gemm perf): the
+// 8-wave 256x128 / 128x256 tiles are no faster than 128x128 here (logits 31 vs 27 us, dW 30 vs 30, split-K 23.5
+// vs 23.8) -- these GEMMs are bound by their output/partial-sum stores and short K loops, not by L1 -- so the
+// engine uses 128x128 and keeps 2 workgroups per CU.  RTX_FORCE_TILE (0..2) overrides for experiments.
+static int choose_tile(int Mp, int Np, int k_slices)
+{
+    (void)k_slices;
+    static int forced = -2;
+    if (forced == -2) {
+        const char* v = getenv("RTX_FORCE_TILE");
+        forced = v ? atoi(v) : -1;
+    }
+    if (forced == RTX_TILE_256x128 && Mp % 256 == 0) return RTX_TILE_256x128;
+    if (forced == RTX_TILE_128x256 && Np % 256 == 0) return RTX_TILE_128x256;
+    return RTX_TILE_128x128;
+}
+
+static void set_tiles(RtxGemm& g, int Mp, int Np)
+{
+    int bm, bn;
+    rtx_gemm_tile_dims(g.tile_shape, &bm, &bn);
+    g.m_tiles = Mp / bm;
+    g.n_tiles = Np / bn;
 }
 
 // C[Mp][Np] (+slabs) = A[Mp][Kp] * B[Np][Kp]^T into e->Cacc; returns the split count used
@@ -188,13 +223,13 @@ static int gemm_to_cacc(rtx_engine* e, const void* A, long lda, const void* B, l
 {
     RtxGemm g = {};
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
-    g.m_tiles = Mp / 128; g.n_tiles = Np / 128;
     g.k_slices = (int)((size_t)Kp * e->esz / 128);
-    g.splits = choose_splits(e, g.m_tiles * g.n_tiles, g.k_slices);
+    g.tile_shape = choose_tile(Mp, Np, g.k_slices);
+    set_tiles(g, Mp, Np);
+    g.splits = choose_splits(e, g.m_tiles * g.n_tiles, g.k_slices, g.tile_shape);
     g.C = e->Cacc; g.ldc = Np; g.slab_stride = (long)Mp * Np;
     while (g.splits > 1 && (size_t)g.splits * Mp * Np > e->cacc_elems) --g.splits;  // smaller batches: fewer tiles, same scratch
     RTX_CHECK((size_t)g.splits * Mp * Np <= e->cacc_elems, RTX_ESTATE, "internal: Cacc too small (%d x %d x %d)", g.splits, Mp, Np);
-    g.n_major = 0;
     *splits_out = g.splits;
     return rtx_gemm_launch(g, e->bf16, RTX_EPI_STORE, st);
 }
@@ -284,10 +319,11 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
         if (li == e->NL - 1) {
             RtxGemm g = {};
             g.A = l.A; g.B = l.Wsh; g.lda = l.inp; g.ldb = l.inp;
-            g.m_tiles = Bp / 128; g.n_tiles = l.outp / 128;
             g.k_slices = (int)((size_t)l.inp * e->esz / 128);
+            g.tile_shape = choose_tile(Bp, l.outp, g.k_slices);
+            set_tiles(g, Bp, l.outp);
             g.splits = 1; g.C = logits; g.ldc = ldlog; g.bias = e->params[2 * li + 1];
-            g.M_real = B; g.N_real = l.out; g.n_major = 0;
+            g.M_real = B; g.N_real = l.out;
             TIMED("gemm_logits");
             RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_BIAS_ROWS, st));
             break;
@@ -336,24 +372,40 @@ static int ensure_shadows(rtx_engine* e, hipStream_t st)
     return rtx_engine_sync_shadows(e, st);
 }
 
-static void fill_adam_tensors(rtx_engine* e, RtxAdamArgs& a)
+// tensors of layers [l0, l1) into a (W and b per layer)
+static void fill_adam_tensors(rtx_engine* e, RtxAdamArgs& a, int l0 = 0, int l1 = -1)
 {
-    a.n = 2 * e->NL;
-    for (int li = 0; li < e->NL; ++li) {
+    if (l1 < 0) l1 = e->NL;
+    a.n = 0;
+    for (int li = l0; li < l1; ++li) {
         Layer& l = e->L[li];
-        RtxAdamTensor& w = a.t[2 * li];
+        RtxAdamTensor& w = a.t[a.n++];
         w.p = e->params[2 * li];
         w.g = e->can_train ? e->grads[2 * li] : nullptr;
         w.m = e->can_train ? e->m[2 * li] : nullptr;
         w.v = e->can_train ? e->v[2 * li] : nullptr;
         w.sh = l.Wsh; w.shT = l.WshT; w.rows = l.out; w.cols = l.in; w.ld_sh = l.inp; w.ld_shT = l.outp;
-        RtxAdamTensor& b = a.t[2 * li + 1];
+        RtxAdamTensor& b = a.t[a.n++];
         b.p = e->params[2 * li + 1];
         b.g = e->can_train ? e->grads[2 * li + 1] : nullptr;
         b.m = e->can_train ? e->m[2 * li + 1] : nullptr;
         b.v = e->can_train ? e->v[2 * li + 1] : nullptr;
         b.sh = nullptr; b.shT = nullptr; b.rows = 1; b.cols = l.out; b.ld_sh = 0; b.ld_shT = 0;
     }
+}
+
+// torch.optim.Adam's scalars for update `step` (computed in double like torch does on the host)
+static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& a, int l0)
+{
+    a.update = 1;
+    const double bc1 = 1.0 - pow((double)step->beta1, (double)step->step);
+    const double bc2 = 1.0 - pow((double)step->beta2, (double)step->step);
+    a.step_size = (float)((double)step->lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
+    a.grad_scale = 1.f;
+    a.lam = 0.f; a.sumsq = nullptr;
+    if (!e->vae && step->lam != 0.f) { a.lam = step->lam; a.sumsq = e->sumsq + 2 * l0; }
 }
 
 static int launch_sumsq(rtx_engine* e, hipStream_t st)
@@ -468,6 +520,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     e->vae = cfg->variant == RTX_VAE;
     e->esz = e->bf16 ? 2 : 4;
     e->Bp_alloc = rtx_pad_batch(cfg->max_batch);
+    if (const char* v = getenv("RTX_OVERLAP_ADAM")) e->overlap_adam = atoi(v) != 0;
     const size_t Bp = e->Bp_alloc, es = e->esz;
     size_t cacc = 0;
 #define ALLOC(ptr, bytes)                                  \
@@ -488,12 +541,12 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
         const int m_tiles = (int)(Bp / 128);
         if (li < e->NL - 1) {
             const int ks = (int)((size_t)l.inp * es / 128);
-            const size_t s = choose_splits(e, m_tiles * (l.outp / 128), ks);
+            const size_t s = choose_splits(e, m_tiles * (l.outp / 128), ks, RTX_TILE_128x128);
             cacc = std::max(cacc, s * Bp * l.outp);
         }
         if (li > 0) {
             const int ks = (int)((size_t)l.outp * es / 128);
-            const size_t s = choose_splits(e, m_tiles * (l.inp / 128), ks);
+            const size_t s = choose_splits(e, m_tiles * (l.inp / 128), ks, RTX_TILE_128x128);
             cacc = std::max(cacc, s * Bp * l.inp);
         }
     }
@@ -521,6 +574,9 @@ int rtx_engine_destroy(rtx_engine* e)
     for (auto& kv : e->sites)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+    if (e->ev_side) (void)hipEventDestroy(e->ev_side);
+    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
 }
@@ -632,12 +688,17 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 }
 
 // ---- training --------------------------------------------------------------------------------------
-int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
-                          rtx_layer_cb cb, void* user, void* stream)
+// forward + loss + backward.  With adam_side, layer l's fused Adam is launched on the engine's side stream as soon
+// as nothing on the main stream still needs that layer's compute copies (after its data-gradient GEMM), so the
+// HBM-bound optimizer pass of the big decoder layer could run under the remaining backward kernels.
+// MEASURED NEGATIVE on MI355X (ml-20m shape, B=500, bf16): 506 us/step with the overlap vs 477 us without, and
+// 495 us with the side stream at the lowest priority -- the 3160 Adam workgroups flood the CUs and the small
+// hidden-layer GEMMs behind them go from 12 to 43 us each.  Kept behind RTX_OVERLAP_ADAM=1 for later rounds.
+static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
+                           rtx_layer_cb cb, void* user, hipStream_t st, bool adam_side)
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
-    hipStream_t st = (hipStream_t)stream;
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
@@ -680,20 +741,31 @@ int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step*
         {   // weight + bias gradient: gW[out][in] = DT[outp][Bp] x AT[inp][Bp]^T ; column `in` = bias gradient
             RtxGemm g = {};
             g.A = l.DT; g.B = l.AT; g.lda = ldt; g.ldb = ldt;
-            g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
             g.k_slices = (int)((size_t)Bp * e->esz / 128);
+            g.tile_shape = choose_tile(l.outp, l.inp, g.k_slices);
+            set_tiles(g, l.outp, l.inp);
             g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
-            g.M_real = l.out; g.N_real = l.in; g.n_major = (l.outp >= l.inp) ? 0 : 1;
+            g.M_real = l.out; g.N_real = l.in;
             TIMED(li == NL - 1 ? "gemm_dW_out" : (li == 0 ? "gemm_dW_in" : "gemm_dW_hidden"));
             RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_GRAD, st));
         }
         if (cb) cb(li, user);
-        if (li == 0) break;
         int splits = 1;
-        {   // data gradient: dA[Bp][inp] = D[Bp][outp] x WshT[inp][outp]^T
+        if (li > 0) {   // data gradient: dA[Bp][inp] = D[Bp][outp] x WshT[inp][outp]^T
             TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
             RTX_TRY(gemm_to_cacc(e, l.D, l.outp, l.WshT, l.outp, Bp, l.inp, l.outp, &splits, st));
         }
+        if (adam_side) {
+            // layer li's gradients are complete and its shadows have no reader left in this step
+            RTX_HIP(hipEventRecord(e->ev_main, st));
+            RTX_HIP(hipStreamWaitEvent(e->side, e->ev_main, 0));
+            RtxAdamArgs a = {};
+            fill_adam_tensors(e, a, li, li + 1);
+            fill_adam_scalars(e, step, a, li);
+            ScopedTimer tm_adam(e, "adam", e->side);
+            RTX_TRY(rtx_launch_adam(a, e->bf16, e->side));
+        }
+        if (li == 0) break;
         Layer& pv = e->L[li - 1];
         if (e->vae && li == e->cfg.n_enc) {
             RtxVaeBwdArgs a = {};
@@ -712,7 +784,18 @@ int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step*
             RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
         }
     }
+    if (adam_side) {   // the next forward (or anything else on the caller's stream) sees the updated weights
+        RTX_HIP(hipEventRecord(e->ev_side, e->side));
+        RTX_HIP(hipStreamWaitEvent(st, e->ev_side, 0));
+        e->shadows_valid = true;
+    }
     return RTX_OK;
+}
+
+int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
+                          rtx_layer_cb cb, void* user, void* stream)
+{
+    return loss_grads_impl(e, batch, step, loss_out, loss_accum, cb, user, (hipStream_t)stream, false);
 }
 
 int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
@@ -722,14 +805,7 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
     hipStream_t st = (hipStream_t)stream;
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
-    a.update = 1;
-    const double bc1 = 1.0 - pow((double)step->beta1, (double)step->step);
-    const double bc2 = 1.0 - pow((double)step->beta2, (double)step->step);
-    a.step_size = (float)((double)step->lr / bc1);
-    a.bc2_sqrt = (float)sqrt(bc2);
-    a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
-    a.grad_scale = 1.f;
-    if (!e->vae && step->lam != 0.f) { a.lam = step->lam; a.sumsq = e->sumsq; }
+    fill_adam_scalars(e, step, a, 0);
     TIMED("adam");
     RTX_TRY(rtx_launch_adam(a, e->bf16, st));
     e->shadows_valid = true;
@@ -739,7 +815,20 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                           void* stream)
 {
-    RTX_TRY(rtx_engine_loss_grads(e, batch, step, loss_out, loss_accum, nullptr, nullptr, stream));
+    RTX_TRY(check_ready(e, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "train_step: step count must be >= 1");
+    if (e->overlap_adam) {
+        if (!e->side) {
+            // lowest priority: the optimizer pass only soaks up the slots the backward kernels leave free
+            int prio_least = 0, prio_greatest = 0;
+            RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least));
+            RTX_HIP(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+            RTX_HIP(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+        }
+        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, true);
+    }
+    RTX_TRY(loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false));
     return rtx_engine_apply_adam(e, step, stream);
 }
 

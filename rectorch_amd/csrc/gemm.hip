@@ -1,11 +1,17 @@
 // gemm.hip -- MFMA NT GEMM for gfx950 (see rtx_gemm.h for the design notes).
+//
+// Why several tile shapes.  Everything a workgroup multiplies passes through its CU's vector L1 at 64 B/clk,
+// while the CU's four matrix pipes retire ~4650 bf16 flop/clk.  A 128x128 tile moves (128+128)*128 B per
+// 128-byte K slice = 512 clk of L1 time for 451 clk of MFMA time: L1-bound below half of the MFMA rate
+// (measured: SQ_VALU_MFMA_BUSY 11 % of wave-cycles, L2 hit traffic = the predicted 202 MB on the logits GEMM).
+// 256x128 / 128x256 (8 waves) need 768 clk of L1 per 902 clk of MFMA, so the big contractions of the step use
+// those; 128x128 (4 waves) stays for the small hidden-layer GEMMs.
 #include "rtx_gemm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-#define RTX_LDS_ROW 144                  // 128 B of K + 16 B pad
-#define RTX_LDS_TILE (128 * RTX_LDS_ROW) // one operand, one stage
+#define RTX_LDS_ROW 144  // 128 B of K + 16 B pad: conflict-free ds_read_b128 fragment reads
 
 template <typename T> struct Mma;
 
@@ -31,26 +37,62 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void rtx_gemm_nt(const RtxGemm p)
+// WM x WN waves; every wave owns a 64 x (32*NB) block of C (2 x NB MFMA 32x32 accumulators).
+// 128x128 = 2x2 waves, 256x128 = 4x2, 128x256 = 2x4.  (256x256 was tried as 4x2 waves of 64x128 and as 4x4 waves of
+// 64x64: both spill accumulators at their VGPR budgets with this source structure, so it is not shipped.)
+template <int WM, int WN, int NB> struct TileCfg {
+    static constexpr int NT = WM * WN * 64;       // threads
+    static constexpr int BM = WM * 64;            // tile rows
+    static constexpr int BN = WN * NB * 32;       // tile columns
+    static constexpr int RPP = NT / 8;            // rows staged per pass (8 lanes x 16 B cover one 128-B row slice)
+    static constexpr int PA = BM / RPP;           // staging passes for A (2 or 4)
+    static constexpr int PB = BN / RPP;           // staging passes for B (2 or 4)
+    static constexpr int STAGE = (BM + BN) * RTX_LDS_ROW;
+    static_assert(PA == 2 || PA == 4, "PA");
+    static_assert(PB == 2 || PB == 4, "PB");
+};
+
+template <typename T, int EPI, int WM, int WN, int NB>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2) void rtx_gemm_nt(const RtxGemm p)
 {
-    // [stage][operand] tiles; all LDS in one array (cdna guide: a second __shared__ object de-pipelines)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * RTX_LDS_TILE];
+    using Cfg = TileCfg<WM, WN, NB>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, RPP = Cfg::RPP, PA = Cfg::PA, PB = Cfg::PB, STAGE = Cfg::STAGE;
+    // [stage][A rows | B rows]; all LDS in one array (a second __shared__ object de-pipelines, cdna guide)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, g = lane >> 5;
 
-    int tm, tn;
-    if (p.n_major) {
-        tn = blockIdx.x % p.n_tiles;
-        tm = blockIdx.x / p.n_tiles;
-    } else {
-        tm = blockIdx.x % p.m_tiles;
-        tn = blockIdx.x / p.m_tiles;
+    // XCD-aware work mapping.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed only), and each
+    // XCD has a private 4 MB L2.  Workgroups that read the same operand panel are therefore placed on ONE
+    // XCD, back to back in its dispatch sequence:
+    //   split-K   : all output tiles of one K-split share that split's A and B K-slices
+    //   otherwise : the (few) tiles along the short dimension share the long dimension's operand tile
+    // (rocprof: TCC misses dropped to the compulsory bytes with this mapping.)
+    int tm, tn, split;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        if (p.splits > 1) {
+            const int tiles = p.m_tiles * p.n_tiles;
+            split = xcd + 8 * (j / tiles);
+            if (split >= p.splits) return;
+            const int t = j % tiles;
+            tm = t % p.m_tiles;
+            tn = t / p.m_tiles;
+        } else if (p.m_tiles <= p.n_tiles) {
+            split = 0;
+            tn = xcd + 8 * (j / p.m_tiles);
+            tm = j % p.m_tiles;
+            if (tn >= p.n_tiles) return;
+        } else {
+            split = 0;
+            tm = xcd + 8 * (j / p.n_tiles);
+            tn = j % p.n_tiles;
+            if (tm >= p.m_tiles) return;
+        }
     }
-    const int split = blockIdx.y;
     const int per = (p.k_slices + p.splits - 1) / p.splits;
     const int ks0 = split * per;
     const int ks1 = min(ks0 + per, p.k_slices);
@@ -58,79 +100,149 @@ __global__ __launch_bounds__(256, 2) void rtx_gemm_nt(const RtxGemm p)
 
     const size_t rowA = (size_t)p.lda * sizeof(T), rowB = (size_t)p.ldb * sizeof(T);
     const int st_row = tid >> 3, st_ch = tid & 7;  // staging: 8 lanes x 16 B = one 128-B row slice
-    const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * 128 + st_row) * rowA + st_ch * 16;
-    const unsigned char* gB = (const unsigned char*)p.B + ((size_t)tn * 128 + st_row) * rowB + st_ch * 16;
-    const int lds_st = st_row * RTX_LDS_ROW + st_ch * 16;
+    const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * BM + st_row) * rowA + st_ch * 16;
+    const unsigned char* gB = (const unsigned char*)p.B + ((size_t)tn * BN + st_row) * rowB + st_ch * 16;
+    const int lds_a = st_row * RTX_LDS_ROW + st_ch * 16;
+    const int lds_b = (BM + st_row) * RTX_LDS_ROW + st_ch * 16;
 
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;  // named (not an array): keeps the prefetch in VGPRs
-    f32x16_t acc[2][2];
+    // two register sets (named, so they stay in VGPRs): K-slices t+1 and t+2 are in flight while slice t is
+    // multiplied -- the loop is latency-bound otherwise (one slice of MFMA work is shorter than an L2 round trip)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    f32x16_t acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#define RTX_GLOAD1(q, ks)                                                                          \
-    ra##q = *(const uint4*)(gA + (size_t)(q) * 32 * rowA + (size_t)(ks) * 128);                    \
-    rb##q = *(const uint4*)(gB + (size_t)(q) * 32 * rowB + (size_t)(ks) * 128);
-#define RTX_GLOAD(ks) RTX_GLOAD1(0, ks) RTX_GLOAD1(1, ks) RTX_GLOAD1(2, ks) RTX_GLOAD1(3, ks)
-#define RTX_LSTORE1(q, s)                                                                          \
-    *(uint4*)(smem + (2 * (s)) * RTX_LDS_TILE + lds_st + (q) * 32 * RTX_LDS_ROW) = ra##q;          \
-    *(uint4*)(smem + (2 * (s) + 1) * RTX_LDS_TILE + lds_st + (q) * 32 * RTX_LDS_ROW) = rb##q;
-#define RTX_LSTORE(s) RTX_LSTORE1(0, s) RTX_LSTORE1(1, s) RTX_LSTORE1(2, s) RTX_LSTORE1(3, s)
-
-    if (nk > 0) {
-        RTX_GLOAD(ks0);
-        RTX_LSTORE(0);
+#define RTX_GL(R, X, q, base, row, ks) R##X##q = *(const uint4*)((base) + (size_t)(q) * RPP * (row) + (size_t)(ks) * 128);
+#define RTX_GLOAD(R, ks)                                                    \
+    RTX_GL(R, a, 0, gA, rowA, ks) RTX_GL(R, a, 1, gA, rowA, ks)             \
+    if (PA == 4) { RTX_GL(R, a, 2, gA, rowA, ks) RTX_GL(R, a, 3, gA, rowA, ks) } \
+    RTX_GL(R, b, 0, gB, rowB, ks) RTX_GL(R, b, 1, gB, rowB, ks)             \
+    if (PB == 4) { RTX_GL(R, b, 2, gB, rowB, ks) RTX_GL(R, b, 3, gB, rowB, ks) }
+#define RTX_LS(R, X, q, off, st) *(uint4*)(smem + (st) * STAGE + (off) + (q) * RPP * RTX_LDS_ROW) = R##X##q;
+#define RTX_LSTORE(R, st)                                                   \
+    RTX_LS(R, a, 0, lds_a, st) RTX_LS(R, a, 1, lds_a, st)                   \
+    if (PA == 4) { RTX_LS(R, a, 2, lds_a, st) RTX_LS(R, a, 3, lds_a, st) }  \
+    RTX_LS(R, b, 0, lds_b, st) RTX_LS(R, b, 1, lds_b, st)                   \
+    if (PB == 4) { RTX_LS(R, b, 2, lds_b, st) RTX_LS(R, b, 3, lds_b, st) }
+#define RTX_COMPUTE(st)                                                                                       \
+    {                                                                                                         \
+        const unsigned char* sA = smem + (st) * STAGE + (wm * 64 + r) * RTX_LDS_ROW + g * 16;                 \
+        const unsigned char* sB = smem + (st) * STAGE + (BM + wn * (NB * 32) + r) * RTX_LDS_ROW + g * 16;     \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+            const uint4 a0 = *(const uint4*)(sA + kk * 32);                                                   \
+            const uint4 a1 = *(const uint4*)(sA + 32 * RTX_LDS_ROW + kk * 32);                                \
+            _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                  \
+                const uint4 b = *(const uint4*)(sB + j * 32 * RTX_LDS_ROW + kk * 32);                         \
+                Mma<T>::run(acc[0][j], a0, b);                                                                \
+                Mma<T>::run(acc[1][j], a1, b);                                                                \
+            }                                                                                                 \
+        }                                                                                                     \
     }
-    __syncthreads();
 
-    for (int t = 0; t < nk; ++t) {
-        const int s = t & 1;
-        if (t + 1 < nk) { RTX_GLOAD(ks0 + t + 1); }
-        const unsigned char* sA = smem + (2 * s) * RTX_LDS_TILE + (wm * 64 + r) * RTX_LDS_ROW + g * 16;
-        const unsigned char* sB = smem + (2 * s + 1) * RTX_LDS_TILE + (wn * 64 + r) * RTX_LDS_ROW + g * 16;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const uint4 a0 = *(const uint4*)(sA + kk * 32);
-            const uint4 a1 = *(const uint4*)(sA + 32 * RTX_LDS_ROW + kk * 32);
-            const uint4 b0 = *(const uint4*)(sB + kk * 32);
-            const uint4 b1 = *(const uint4*)(sB + 32 * RTX_LDS_ROW + kk * 32);
-            Mma<T>::run(acc[0][0], a0, b0);
-            Mma<T>::run(acc[0][1], a0, b1);
-            Mma<T>::run(acc[1][0], a1, b0);
-            Mma<T>::run(acc[1][1], a1, b1);
-        }
-        if (t + 1 < nk) { RTX_LSTORE(s ^ 1); }
+    // Software pipeline, depth 2: while slice t is multiplied out of LDS, slices t+1 and t+2 are in flight in the
+    // two register sets.  The steady-state loop issues its loads UNCONDITIONALLY: with a branch around a load,
+    // hipcc's waitcnt pass merges the "issued" and "not issued" states and falls back to vmcnt(0) before the LDS
+    // stores, which drains the younger prefetch every slice (seen in the .s; it cost the whole second stage).
+    if (nk == 1) {
+        RTX_GLOAD(r, ks0)
+        RTX_LSTORE(r, 0)
         __syncthreads();
+        RTX_COMPUTE(0)
+    } else if (nk > 1) {
+        RTX_GLOAD(r, ks0)
+        RTX_LSTORE(r, 0)
+        RTX_GLOAD(r, ks0 + 1)
+        __syncthreads();
+        int t = 0;
+        for (; t + 3 < nk; t += 2) {
+            // LDS stage 0 = slice t, set r = slice t+1 (in flight)
+            RTX_GLOAD(s, ks0 + t + 2)
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler sinks it otherwise)
+            RTX_COMPUTE(0)
+            RTX_LSTORE(r, 1)
+            __syncthreads();
+            // LDS stage 1 = slice t+1, set s = slice t+2 (in flight)
+            RTX_GLOAD(r, ks0 + t + 3)
+            __builtin_amdgcn_sched_barrier(0);
+            RTX_COMPUTE(1)
+            RTX_LSTORE(s, 0)
+            __syncthreads();
+        }
+        // 2 or 3 slices left: stage 0 = slice t, set r = slice t+1
+        const bool three = (nk - t) == 3;
+        if (three) { RTX_GLOAD(s, ks0 + t + 2) }
+        RTX_COMPUTE(0)
+        RTX_LSTORE(r, 1)
+        __syncthreads();
+        RTX_COMPUTE(1)
+        if (three) {
+            RTX_LSTORE(s, 0)
+            __syncthreads();
+            RTX_COMPUTE(0)
+        }
     }
+#undef RTX_GL
 #undef RTX_GLOAD
-#undef RTX_GLOAD1
+#undef RTX_LS
 #undef RTX_LSTORE
-#undef RTX_LSTORE1
+#undef RTX_COMPUTE
 
-    // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int row_base = tm * 128 + wm * 64 + 4 * g;
-    const int col_base = tn * 128 + wn * 64 + r;
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Per-column values (bias, column validity) are fetched ONCE before the store loop: a load inside the loop
+    // makes hipcc wait vmcnt(0) per element, which also drains the stores (CDNA counts them in vmcnt) and
+    // serialised the whole epilogue (12 us of the logits GEMM).
+    const int row_base = tm * BM + wm * 64 + 4 * g;
+    const int col_base = tn * BN + wn * (NB * 32) + r;
+    float bj[NB];
+    bool cok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = col_base + j * 32;
+        cok[j] = col < p.N_real;
+        bj[j] = 0.f;
+        if (EPI == RTX_EPI_BIAS_ROWS && p.bias) bj[j] = p.bias[cok[j] ? col : 0];
+    }
+    if (EPI == RTX_EPI_BIAS_ROWS) {
+        // add the bias to every accumulator up front (unconditional VALU): the single wait for the bias load sits
+        // here, not in front of each guarded store
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float t = acc[i][j][e] + bj[j];
+                    asm volatile("" : "+v"(t));   // keep the add here: hipcc sinks it back into the guarded blocks
+                    acc[i][j][e] = t;
+                }
+    }
+    // one 64-bit base per lane; every element offset is (compile-time constant) * ld + constant -> scalar math
+    const long ld = (EPI == RTX_EPI_GRAD) ? (long)p.N_real : p.ldc;
+    float* cp = p.C + (EPI == RTX_EPI_STORE ? (size_t)split * p.slab_stride : (size_t)0) + (size_t)row_base * ld + col_base;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int col = col_base + j * 32;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
+                const int dr = i * 32 + (e & 3) + 8 * (e >> 2);
+                const int row = row_base + dr;
                 const float v = acc[i][j][e];
+                float* dst = cp + (long)dr * ld + j * 32;
                 if (EPI == RTX_EPI_STORE) {
-                    p.C[(size_t)split * p.slab_stride + (size_t)row * p.ldc + col] = v;
+                    *dst = v;
                 } else if (EPI == RTX_EPI_BIAS_ROWS) {
-                    if (row < p.M_real && col < p.N_real)
-                        p.C[(size_t)row * p.ldc + col] = v + (p.bias ? p.bias[col] : 0.f);
+                    if (row < p.M_real && cok[j]) *dst = v;
                 } else {  // RTX_EPI_GRAD
                     if (row < p.M_real) {
-                        if (col < p.N_real)
-                            p.C[(size_t)row * p.N_real + col] = v;
+                        if (cok[j])
+                            *dst = v;
                         else if (col == p.N_real && p.gbias)
                             p.gbias[row] = v;
                     }
@@ -140,29 +252,50 @@ __global__ __launch_bounds__(256, 2) void rtx_gemm_nt(const RtxGemm p)
     }
 }
 
+void rtx_gemm_tile_dims(int shape, int* bm, int* bn)
+{
+    switch (shape) {
+    case RTX_TILE_256x128: *bm = 256; *bn = 128; break;
+    case RTX_TILE_128x256: *bm = 128; *bn = 256; break;
+    default: *bm = 128; *bn = 128; break;
+    }
+}
+
+template <typename T, int WM, int WN, int NB>
+static void launch_shape(const RtxGemm& g, int epilogue, dim3 grid, hipStream_t stream)
+{
+    const dim3 block(WM * WN * 64);
+    switch (epilogue) {
+    case RTX_EPI_STORE: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_STORE, WM, WN, NB>), grid, block, 0, stream, g); break;
+    case RTX_EPI_BIAS_ROWS: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_BIAS_ROWS, WM, WN, NB>), grid, block, 0, stream, g); break;
+    default: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_GRAD, WM, WN, NB>), grid, block, 0, stream, g); break;
+    }
+}
+
+template <typename T> static void launch_type(const RtxGemm& g, int epilogue, dim3 grid, hipStream_t stream)
+{
+    switch (g.tile_shape) {
+    case RTX_TILE_256x128: launch_shape<T, 4, 2, 2>(g, epilogue, grid, stream); break;
+    case RTX_TILE_128x256: launch_shape<T, 2, 4, 2>(g, epilogue, grid, stream); break;
+    default: launch_shape<T, 2, 2, 2>(g, epilogue, grid, stream); break;
+    }
+}
+
 int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t stream)
 {
     RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm: empty problem");
     RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm: split-K only with EPI_STORE");
-    RTX_CHECK(g.splits <= 65535, RTX_EINVAL, "gemm: too many splits");
-    const dim3 grid((unsigned)(g.m_tiles * g.n_tiles), (unsigned)g.splits), block(256);
-#define RTX_LAUNCH(T, E) hipLaunchKernelGGL((rtx_gemm_nt<T, E>), grid, block, 0, stream, g)
-    if (is_bf16) {
-        switch (epilogue) {
-        case RTX_EPI_STORE: RTX_LAUNCH(bf16_t, RTX_EPI_STORE); break;
-        case RTX_EPI_BIAS_ROWS: RTX_LAUNCH(bf16_t, RTX_EPI_BIAS_ROWS); break;
-        case RTX_EPI_GRAD: RTX_LAUNCH(bf16_t, RTX_EPI_GRAD); break;
-        default: RTX_CHECK(false, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
-        }
-    } else {
-        switch (epilogue) {
-        case RTX_EPI_STORE: RTX_LAUNCH(float, RTX_EPI_STORE); break;
-        case RTX_EPI_BIAS_ROWS: RTX_LAUNCH(float, RTX_EPI_BIAS_ROWS); break;
-        case RTX_EPI_GRAD: RTX_LAUNCH(float, RTX_EPI_GRAD); break;
-        default: RTX_CHECK(false, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
-        }
-    }
-#undef RTX_LAUNCH
+    RTX_CHECK(epilogue >= RTX_EPI_STORE && epilogue <= RTX_EPI_GRAD, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
+    RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x256, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
+    // 1-D grid laid out for the XCD-aware mapping in the kernel: 8 * ceil(groups / 8) * group_size workgroups
+    const int tiles = g.m_tiles * g.n_tiles;
+    int groups, gsize;
+    if (g.splits > 1) { groups = g.splits; gsize = tiles; }
+    else if (g.m_tiles <= g.n_tiles) { groups = g.n_tiles; gsize = g.m_tiles; }
+    else { groups = g.m_tiles; gsize = g.n_tiles; }
+    const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * gsize));
+    if (is_bf16) launch_type<bf16_t>(g, epilogue, grid, stream);
+    else launch_type<float>(g, epilogue, grid, stream);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

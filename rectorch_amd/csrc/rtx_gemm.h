@@ -7,7 +7,7 @@
 // weight gradient  dOut^T[out,B] x Act^T[in,B].  Operand buffers are zero-padded to multiples of the
 // 128x128 tile (rtx_pad), so the main loop carries no bounds checks.
 //
-// Tile: 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA 32x32 blocks).
+// Tile: 128x128 (4 waves), 256x128 / 128x256 (8 waves); 64x64 or 64x128 of C per wave as 32x32 MFMA blocks.
 // K is consumed in 128-BYTE slices per row (64 bf16 / 32 f32): global -> registers (16 B per lane,
 // 8 lanes cover one 128-B row segment) -> LDS (144-B row stride: 16-B pad makes the ds_read_b128
 // fragment reads conflict-free) -> MFMA.  Double-buffered LDS, one barrier per slice.
@@ -22,10 +22,18 @@ enum RtxEpilogue {
     RTX_EPI_GRAD = 2,    // gW[m * N_real + n] = acc (m < M_real, n < N_real); gb[m] = acc at n == N_real
 };
 
+enum RtxTileShape {     // workgroup tile of C; 128x128 runs 4 waves, the others 8 waves (64x64 or 64x128 per wave)
+    RTX_TILE_128x128 = 0,
+    RTX_TILE_256x128 = 1,
+    RTX_TILE_128x256 = 2,
+};
+void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
+
 struct RtxGemm {
     const void* A;       // [M_pad][lda] elements of T
     const void* B;       // [N_pad][ldb]
     long lda, ldb;       // leading dimensions in elements
+    int tile_shape;      // RtxTileShape; M_pad / N_pad must be multiples of the tile
     int m_tiles, n_tiles;
     int k_slices;        // total 128-byte K slices  (= K_pad * sizeof(T) / 128)
     int splits;          // split-K factor (grid.y); only with RTX_EPI_STORE
@@ -35,7 +43,6 @@ struct RtxGemm {
     const float* bias;   // RTX_EPI_BIAS_ROWS
     float* gbias;        // RTX_EPI_GRAD (nullable)
     int M_real, N_real;
-    int n_major;         // 0: blockIdx.x walks m fastest, 1: n fastest
 };
 
 int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t stream);

@@ -441,6 +441,8 @@ int main(int argc, char** argv)
         parity_case("small-dae", make_net({64, 16, 8}, {8, 16, 64}, ORC_DAE, 0.5f, 1.0f), numerics, 5, 9, 0.2f, false, false, false, 0.f, 0.2f);
         parity_case("dense-api-vae-te", make_net({130, 40, 12}, {12, 40, 130}, ORC_VAE, 0.5f, 0.5f), numerics, 33, 40, 0.1f, true, true, true, 0.5f, 0.f);
         parity_case("mid-vae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_VAE, 0.5f, 0.3f), numerics, 300, 400, 0.02f, false, false, false, 0.2f, 0.f);
+        // wide enough that the engine picks the 8-wave tiles (256x128 / 128x256) and split-K in multiples of 8
+        parity_case("wide-vae", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), numerics, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
     }
     philox_case();
     if (argc > 1 && !strcmp(argv[1], "perf")) {

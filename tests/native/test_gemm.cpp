@@ -26,7 +26,7 @@ static float frand()
     } while (0)
 
 template <typename T>
-static int run_case(const char* name, int M, int N, int K, int splits, int epi, int M_real, int N_real, int n_major)
+static int run_case(const char* name, int M, int N, int K, int splits, int epi, int M_real, int N_real, int shape)
 {
     // padded operand buffers
     std::vector<T> hA((size_t)M * K), hB((size_t)N * K);
@@ -51,10 +51,12 @@ static int run_case(const char* name, int M, int N, int K, int splits, int epi, 
     CK(hipMemset(gb, 0xff, M * sizeof(float)));
     RtxGemm g = {};
     g.A = A; g.B = B; g.lda = K; g.ldb = K;
-    g.m_tiles = M / 128; g.n_tiles = N / 128;
+    int bm, bn;
+    rtx_gemm_tile_dims(shape, &bm, &bn);
+    g.tile_shape = shape; g.m_tiles = M / bm; g.n_tiles = N / bn;
     g.k_slices = (int)((size_t)K * sizeof(T) / 128);
     g.splits = splits; g.C = C; g.ldc = ldc; g.slab_stride = (long)M * N;
-    g.bias = bias; g.gbias = gb; g.M_real = M_real; g.N_real = N_real; g.n_major = n_major;
+    g.bias = bias; g.gbias = gb; g.M_real = M_real; g.N_real = N_real;
     int rc = rtx_gemm_launch(g, sizeof(T) == 2, epi, 0);
     if (rc) { printf("[%s] launch failed rc=%d\n", name, rc); return 1; }
     CK(hipDeviceSynchronize());
@@ -88,14 +90,14 @@ static int run_case(const char* name, int M, int N, int K, int splits, int epi, 
             if (err > max_err) max_err = err;
             if (fabs(ref) > max_ref) max_ref = fabs(ref);
         }
-    printf("[%s] %s M=%d N=%d K=%d splits=%d epi=%d  max_err=%.3e (max|ref|=%.2f) bad=%ld -> %s\n", name,
-           sizeof(T) == 2 ? "bf16" : "f32 ", M, N, K, splits, epi, max_err, max_ref, bad, bad ? "FAIL" : "ok");
+    printf("[%s] %s tile%d M=%d N=%d K=%d splits=%d epi=%d  max_err=%.3e (max|ref|=%.2f) bad=%ld -> %s\n", name,
+           sizeof(T) == 2 ? "bf16" : "f32 ", shape, M, N, K, splits, epi, max_err, max_ref, bad, bad ? "FAIL" : "ok");
     hipFree(A); hipFree(B); hipFree(C); hipFree(bias); hipFree(gb);
     return bad != 0;
 }
 
 template <typename T>
-static void perf_case(const char* name, int M, int N, int K, int splits, int epi, int n_major)
+static void perf_case(const char* name, int M, int N, int K, int splits, int epi, int shape)
 {
     T *A, *B;
     float* C;
@@ -109,10 +111,12 @@ static void perf_case(const char* name, int M, int N, int K, int splits, int epi
     CK(hipMemcpy(B, hB.data(), hB.size() * sizeof(T), hipMemcpyHostToDevice));
     RtxGemm g = {};
     g.A = A; g.B = B; g.lda = K; g.ldb = K;
-    g.m_tiles = M / 128; g.n_tiles = N / 128;
+    int bm, bn;
+    rtx_gemm_tile_dims(shape, &bm, &bn);
+    g.tile_shape = shape; g.m_tiles = M / bm; g.n_tiles = N / bn;
     g.k_slices = (int)((size_t)K * sizeof(T) / 128);
     g.splits = splits; g.C = C; g.ldc = N; g.slab_stride = (long)M * N;
-    g.M_real = M; g.N_real = (epi == RTX_EPI_GRAD) ? N - 1 : N; g.n_major = n_major;
+    g.M_real = M; g.N_real = (epi == RTX_EPI_GRAD) ? N - 1 : N;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) rtx_gemm_launch(g, sizeof(T) == 2, epi, 0);
@@ -124,8 +128,8 @@ static void perf_case(const char* name, int M, int N, int K, int splits, int epi
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     double us = ms * 1000.0 / it;
-    printf("[perf %s] %s M=%d N=%d K=%d splits=%d n_major=%d: %.1f us  %.1f TFLOP/s\n", name, sizeof(T) == 2 ? "bf16" : "f32 ", M, N, K,
-           splits, n_major, us, 2.0 * M * N * K / us * 1e-6);
+    printf("[perf %s] %s M=%d N=%d K=%d splits=%d tile%d: %.1f us  %.1f TFLOP/s\n", name, sizeof(T) == 2 ? "bf16" : "f32 ", M, N, K,
+           splits, shape, us, 2.0 * M * N * K / us * 1e-6);
     hipFree(A); hipFree(B); hipFree(C);
 }
 
@@ -135,31 +139,37 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  gcnArch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
-    fails += run_case<bf16_t>("store", 256, 384, 704, 1, RTX_EPI_STORE, 256, 384, 0);
-    fails += run_case<bf16_t>("store-nmaj", 256, 384, 704, 1, RTX_EPI_STORE, 256, 384, 1);
-    fails += run_case<bf16_t>("splitk3", 256, 384, 704, 3, RTX_EPI_STORE, 256, 384, 0);
-    fails += run_case<bf16_t>("splitk5", 128, 256, 704, 5, RTX_EPI_STORE, 128, 256, 0);
-    fails += run_case<bf16_t>("bias", 256, 384, 640, 1, RTX_EPI_BIAS_ROWS, 200, 333, 0);
-    fails += run_case<bf16_t>("grad", 256, 384, 512, 1, RTX_EPI_GRAD, 250, 300, 1);
-    fails += run_case<float>("store", 256, 384, 352, 1, RTX_EPI_STORE, 256, 384, 0);
-    fails += run_case<float>("splitk3", 256, 384, 352, 3, RTX_EPI_STORE, 256, 384, 1);
-    fails += run_case<float>("bias", 256, 384, 320, 1, RTX_EPI_BIAS_ROWS, 200, 333, 0);
-    fails += run_case<float>("grad", 256, 384, 256, 1, RTX_EPI_GRAD, 250, 300, 0);
+    for (int shape = 0; shape < 3; ++shape) {   // 128x128, 256x128, 128x256
+        fails += run_case<bf16_t>("store", 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, shape);
+        fails += run_case<bf16_t>("splitk3", 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, shape);
+        fails += run_case<bf16_t>("splitk5", 256, 256, 704, 5, RTX_EPI_STORE, 256, 256, shape);
+        fails += run_case<bf16_t>("splitk11", 256, 512, 1408, 11, RTX_EPI_STORE, 256, 512, shape);
+        fails += run_case<bf16_t>("bias", 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, shape);
+        fails += run_case<bf16_t>("grad", 768, 512, 512, 1, RTX_EPI_GRAD, 700, 300, shape);
+        fails += run_case<bf16_t>("grad-tall", 2304, 256, 128, 1, RTX_EPI_GRAD, 2300, 200, shape);
+        fails += run_case<bf16_t>("bias-wide", 256, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 250, 2300, shape);
+        fails += run_case<float>("store", 512, 768, 352, 1, RTX_EPI_STORE, 512, 768, shape);
+        fails += run_case<float>("splitk3", 512, 768, 352, 3, RTX_EPI_STORE, 512, 768, shape);
+        fails += run_case<float>("bias", 512, 768, 320, 1, RTX_EPI_BIAS_ROWS, 410, 701, shape);
+        fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
+    }
     if (argc > 1) {
         // ml-20m step shapes: fwd-1 / dH3 (skinny, split-K), logits, dW4 / dW1
-        for (int s : {8, 13, 26, 40}) perf_case<bf16_t>("fwd1", 512, 640, 20224, s, RTX_EPI_STORE, 0);
-        perf_case<bf16_t>("logits", 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS, 0);
-        perf_case<bf16_t>("logits", 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS, 1);
-        perf_case<bf16_t>("dW4", 20224, 640, 512, 1, RTX_EPI_GRAD, 0);
-        perf_case<bf16_t>("dW4", 20224, 640, 512, 1, RTX_EPI_GRAD, 1);
-        perf_case<bf16_t>("dW1", 640, 20224, 512, 1, RTX_EPI_GRAD, 0);
-        perf_case<bf16_t>("dW1", 640, 20224, 512, 1, RTX_EPI_GRAD, 1);
+        perf_case<bf16_t>("fwd1", 512, 640, 20224, 24, RTX_EPI_STORE, 0);
+        for (int s : {8, 16, 24, 32}) perf_case<bf16_t>("fwd1", 512, 640, 20224, s, RTX_EPI_STORE, 1);
+        for (int shape : {0, 1, 2}) perf_case<bf16_t>("logits", 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS, shape);
+        for (int shape : {0, 1}) perf_case<bf16_t>("dW4", 20224, 640, 512, 1, RTX_EPI_GRAD, shape);
+        for (int shape : {0, 2}) perf_case<bf16_t>("dW1", 640, 20224, 512, 1, RTX_EPI_GRAD, shape);
+        for (int K : {64, 128, 320, 640, 1280, 2560}) perf_case<bf16_t>("logitsK", 512, 20224, K, 1, RTX_EPI_BIAS_ROWS, 0);
+        for (int K : {64, 640, 2560}) perf_case<bf16_t>("logitsK-store", 512, 20224, K, 1, RTX_EPI_STORE, 0);
+        for (int K : {64, 512, 2048}) perf_case<bf16_t>("dW4K", 20224, 640, K, 1, RTX_EPI_GRAD, 0);
         perf_case<bf16_t>("small", 512, 512, 640, 1, RTX_EPI_STORE, 0);
-        perf_case<bf16_t>("sq4k", 4096, 4096, 4096, 1, RTX_EPI_STORE, 0);
-        perf_case<float>("fwd1", 512, 640, 20224, 26, RTX_EPI_STORE, 0);
-        perf_case<float>("logits", 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS, 0);
-        perf_case<float>("dW4", 20224, 640, 512, 1, RTX_EPI_GRAD, 0);
-        perf_case<float>("sq4k", 4096, 4096, 4096, 1, RTX_EPI_STORE, 0);
+        perf_case<bf16_t>("small-s5", 512, 512, 640, 5, RTX_EPI_STORE, 0);
+        for (int shape : {0, 1, 2}) perf_case<bf16_t>("sq4k", 4096, 4096, 4096, 1, RTX_EPI_STORE, shape);
+        perf_case<float>("fwd1", 512, 640, 20224, 24, RTX_EPI_STORE, 1);
+        for (int shape : {0, 1}) perf_case<float>("logits", 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS, shape);
+        perf_case<float>("dW4", 20224, 640, 512, 1, RTX_EPI_GRAD, 1);
+        for (int shape : {0, 1}) perf_case<float>("sq4k", 4096, 4096, 4096, 1, RTX_EPI_STORE, shape);
     }
     printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
     return fails ? 1 : 0;

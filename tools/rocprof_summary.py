@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Turn rocprofv3's rocpd sqlite output (<name>_results.db) into the text summaries kept under profiles/.
+
+    python tools/rocprof_summary.py stats  gpurun_out/prof/stats/bench_results.db   > profiles/rNN_kernel_stats.txt
+    python tools/rocprof_summary.py pmc    gpurun_out/prof/pmc_fetch/eng_results.db > profiles/rNN_pmc_fetch.txt
+"""
+import sqlite3
+import sys
+
+
+def stats(path):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                       "group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    print("# rocprofv3 --kernel-trace --stats : per-kernel summary (durations in us)")
+    print("%-64s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+    for n, c, s, a, mn, mx in rows:
+        print("%-64s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (n[:64], c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+
+
+def pmc(path):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select kernel_name, counter_name, grid_size, count(*), avg(value), avg(duration) from counters_collection "
+                       "group by kernel_name, counter_name, grid_size order by avg(value)*count(*) desc").fetchall()
+    print("# rocprofv3 --pmc : per (kernel, grid) average counter value per launch; duration in us (profiled run)")
+    print("%-56s %-12s %10s %6s %16s %10s" % ("kernel", "counter", "grid", "calls", "avg_value", "avg_us"))
+    for k, c, g, n, v, d in rows:
+        print("%-56s %-12s %10d %6d %16.1f %10.2f" % (k[:56], c, g, n, v, d / 1e3))
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
