@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--items", type=int, default=20108)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--force-dp", action="store_true",
+                    help="exercise the data-parallel code path (RCCL all-reduce + split step) even with one rank")
     return ap.parse_args()
 
 
@@ -94,7 +96,9 @@ def main():
     net = MultiVAE_net([L, H, I], dropout=0.5)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in hash_state_dict([I, H, L], [L, H, I], "vae", 1234).items()})
     model = MultiVAE(net, beta=0.2, anneal_steps=100000, learning_rate=1e-3, numerics=args.numerics)
-    if world > 1:
+    if world == 1 and args.force_dp:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    if world > 1 or args.force_dp:
         parallel.attach(model, fixed_global_batch=B * world)
     # resident sampler over the global batch; each rank takes its slice of every global batch
     np.random.seed(20240927)
@@ -133,8 +137,7 @@ def main():
     loss_mean = model._read_loss_sum() / (args.steps + args.warmup)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     ms_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
@@ -174,7 +177,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(X, (I, H, L), B, args.cpu_seconds)
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

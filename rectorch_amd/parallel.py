@@ -133,10 +133,7 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None)
     st, params, m, v = model._ensure_train_state()
     for p in params:
         dist.broadcast(p.data, src=0, group=group)
-    for p in params:        # parameters changed under the engine: bump the version so shadows are refreshed
-        p.data.add_(0)
-        p._version  # noqa: B018
-    model.network._rtx_shadow_versions.clear()
+    model.network._rtx_shadow_versions.clear()      # parameters changed under the engines: refresh the shadows
     red = GradAllReducer(st.flat_grads, st.layer_ranges, group, min_bucket_bytes)
     if fixed_global_batch is not None:
         red.global_batch = lambda local, _g=int(fixed_global_batch): _g
