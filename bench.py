@@ -48,34 +48,46 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(X, dims, batch, seconds):
-    """the reference trainer's op sequence on this box's host cores (oracle/rectorch_cpu.py), bounded sample"""
+def _cpu_run(X, dims, batch, seconds, threads):
     from oracle.rectorch_cpu import CpuNet, CpuTrainer, densify_batch
-    import psutil
-    cores = psutil.cpu_count(logical=False) or os.cpu_count()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     I, H, L = dims
     net = CpuNet([I, H, L], [L, H, I], "vae", 0.5)
     tr = CpuTrainer(net, beta=0.2, anneal_steps=100000, lr=1e-3)
     rng = np.random.default_rng(0)
     perm = rng.permutation(X.shape[0])
-    times, t_start, i = [], time.time(), 0
+    t_all, t_smp, t_start, i = [], [], time.time(), 0
     while True:
         idx = perm[(i * batch) % (len(perm) - batch):][:batch]
         t0 = time.time()
         x = densify_batch(X, list(idx))           # DataSampler.__iter__ work (samplers.py:99-100)
+        t1 = time.time()
         tr.train_batch(x)                         # MultiVAE.train_batch (models.py:817-835)
-        dt = time.time() - t0
+        t2 = time.time()
         if i >= 2:                                # 2 warm-up steps
-            times.append(dt)
+            t_all.append(t2 - t0)
+            t_smp.append(t1 - t0)
         i += 1
-        if (time.time() - t_start > seconds and len(times) >= 3) or len(times) >= 40:
+        if (time.time() - t_start > seconds and len(t_all) >= 3) or len(t_all) >= 40:
             break
-    per = float(np.median(times))
-    return {"value": batch / per, "unit": "users/s", "cores": int(cores), "kind": "port",
-            "sample": "%d steps of B=%d (sampler densify + train_batch) after 2 warm-up, median; torch %s CPU, %d threads"
-                      % (len(times), batch, torch.__version__, cores),
-            "ms_per_step": per * 1e3}
+    return float(np.median(t_all)), float(np.median(t_smp)), len(t_all)
+
+
+def cpu_baseline(X, dims, batch, seconds):
+    """the reference trainer's op sequence on this box's host cores (oracle/rectorch_cpu.py), bounded sample:
+    all physical cores (the reported baseline) and 8 threads (comparable with the survey container's probe)"""
+    import psutil
+    cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    per, smp, n = _cpu_run(X, dims, batch, seconds, cores)
+    per8, smp8, n8 = _cpu_run(X, dims, batch, seconds * 0.6, 8)
+    best = min(per, per8)
+    return {"value": batch / best, "unit": "users/s", "cores": int(cores if per <= per8 else 8), "kind": "port",
+            "sample": "%d steps (all %d physical cores) + %d steps (8 threads) of B=%d, sampler densify + train_batch, "
+                      "2 warm-up, median; torch %s CPU; faster of the two reported" % (n, cores, n8, batch, torch.__version__),
+            "all_cores": {"threads": int(cores), "users_per_s": batch / per, "ms_sampler_plus_step": per * 1e3,
+                          "ms_sampler": smp * 1e3, "ms_step_only": (per - smp) * 1e3},
+            "threads_8": {"threads": 8, "users_per_s": batch / per8, "ms_sampler_plus_step": per8 * 1e3,
+                          "ms_sampler": smp8 * 1e3, "ms_step_only": (per8 - smp8) * 1e3}}
 
 
 def main():

@@ -74,6 +74,8 @@ struct rtx_engine {
     float* Cacc = nullptr;
     size_t cacc_elems = 0;
     float *mu32 = nullptr, *lv32 = nullptr, *eps32 = nullptr;
+    float2* lse_part = nullptr;
+    int lse_strips = 0;
     float *tsum = nullptr, *lse = nullptr, *row_loss = nullptr, *sumsq = nullptr, *scratch_loss = nullptr;
     // bound tensors
     std::vector<float*> params, grads, m, v;
@@ -82,6 +84,8 @@ struct rtx_engine {
     // per-layer Adam on a side stream, overlapped with the rest of the backward pass (single-GPU fused step)
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool no_lse_fuse = true;    // LSE partials in the logits-GEMM epilogue: measured 8 us/step SLOWER (A/B, same box:
+                                // +12 us of shuffles in the GEMM vs -8 us in k_lse_loss); RTX_LSE_FUSE=1 enables it
     bool overlap_adam = false;  // measured slower on MI355X (see loss_grads_impl); RTX_OVERLAP_ADAM=1 re-enables
     // timing
     bool timing_all = false;
@@ -324,6 +328,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             set_tiles(g, Bp, l.outp);
             g.splits = 1; g.C = logits; g.ldc = ldlog; g.bias = e->params[2 * li + 1];
             g.M_real = B; g.N_real = l.out;
+            if (logits == e->Y && g.tile_shape == RTX_TILE_128x128 && !e->no_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }
             TIMED("gemm_logits");
             RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_BIAS_ROWS, st));
             break;
@@ -521,6 +526,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     e->esz = e->bf16 ? 2 : 4;
     e->Bp_alloc = rtx_pad_batch(cfg->max_batch);
     if (const char* v = getenv("RTX_OVERLAP_ADAM")) e->overlap_adam = atoi(v) != 0;
+    if (const char* v = getenv("RTX_LSE_FUSE")) e->no_lse_fuse = atoi(v) == 0;
     const size_t Bp = e->Bp_alloc, es = e->esz;
     size_t cacc = 0;
 #define ALLOC(ptr, bytes)                                  \
@@ -556,6 +562,8 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     ALLOC(e->mu32, Bp * e->Z * sizeof(float));
     ALLOC(e->lv32, Bp * e->Z * sizeof(float));
     ALLOC(e->eps32, Bp * e->Z * sizeof(float));
+    e->lse_strips = e->Ip / 64;
+    ALLOC(e->lse_part, Bp * e->lse_strips * sizeof(float2));
     ALLOC(e->tsum, Bp * sizeof(float));
     ALLOC(e->lse, Bp * sizeof(float));
     ALLOC(e->row_loss, Bp * sizeof(float));
@@ -709,6 +717,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RtxLossArgs a = {};
         a.Y = e->Y; a.ldy = e->Ip; a.B = B; a.I = e->I; a.target = tg; a.tsum = e->tsum;
         a.lse = e->lse; a.row_loss = e->row_loss; a.inv_batch = step->inv_batch;
+        if (!e->no_lse_fuse && choose_tile(Bp, e->Ip, 0) == RTX_TILE_128x128) { a.part = e->lse_part; a.n_strips = e->lse_strips; a.part_ld = e->lse_strips; }
         if (e->vae) { a.mu32 = e->mu32; a.lv32 = e->lv32; a.Z = e->Z; a.beta = step->beta; }
         TIMED("lse_loss");
         RTX_TRY(rtx_launch_lse_loss(a, st));

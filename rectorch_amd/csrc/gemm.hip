@@ -221,6 +221,55 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
                     acc[i][j][e] = t;
                 }
     }
+    if (EPI == RTX_EPI_BIAS_ROWS && p.lse_part) {
+        // online-softmax partials of this wave's 64-column strip: (max, sum exp(y - max)) per row, reduced over the
+        // 32 lanes that hold one row (xor-shuffles stay inside a half-wave), written by lane 0 of each half.
+        // All 32 rows advance through each shuffle step together (32 independent ds_bpermute in flight) instead of
+        // one dependent 10-shuffle chain per row.
+        const int strip = tn * WN + wn;
+        float mx[2][16], sm[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (cok[j]) m = fmaxf(m, acc[i][j][e]);
+                mx[i][e] = m;
+            }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx[i][e] = fmaxf(mx[i][e], __shfl_xor(mx[i][e], o, 64));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (cok[j]) sum += __expf(acc[i][j][e] - mx[i][e]);
+                sm[i][e] = sum;
+            }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sm[i][e] += __shfl_xor(sm[i][e], o, 64);
+        if (r == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
+                    if (row < p.M_real) p.lse_part[(size_t)row * p.lse_ld + strip] = make_float2(mx[i][e], sm[i][e]);
+                }
+        }
+    }
     // one 64-bit base per lane; every element offset is (compile-time constant) * ld + constant -> scalar math
     const long ld = (EPI == RTX_EPI_GRAD) ? (long)p.N_real : p.ldc;
     float* cp = p.C + (EPI == RTX_EPI_STORE ? (size_t)split * p.slab_stride : (size_t)0) + (size_t)row_base * ld + col_base;

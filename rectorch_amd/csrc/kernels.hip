@@ -2,6 +2,7 @@
 // sparse-row gather (K1), activation/transposition post kernels, VAE head, multinomial loss, dlogits,
 // fused multi-tensor Adam with shadow refresh, dense<->CSR conversions.  Wave = 64 lanes throughout.
 #include "rtx_kernels.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -429,7 +430,31 @@ __global__ __launch_bounds__(256) void k_lse_loss(const RtxLossArgs a)
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* y = a.Y + (size_t)b * a.ldy;
-    const float lse = block_lse(y, a.I, red);
+    float lse;
+    if (a.part) {
+        // combine the strip partials the logits GEMM left behind (n_strips * 8 bytes instead of 4 * n_items)
+        float m = -INFINITY, s = 0.f;
+        for (int k = tid; k < a.n_strips; k += 256) {
+            const float2 pr = a.part[(size_t)b * a.part_ld + k];
+            online_merge(m, s, pr.x, pr.y);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            online_merge(m, s, m2, s2);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = s; }
+        __syncthreads();
+        float M = red[0], S = red[4];
+        online_merge(M, S, red[1], red[5]);
+        online_merge(M, S, red[2], red[6]);
+        online_merge(M, S, red[3], red[7]);
+        lse = M + logf(S);
+        __syncthreads();
+    } else {
+        lse = block_lse(y, a.I, red);
+    }
     const int64_t u = csr_row(a.target, b);
     float dot = 0.f;
     for (int64_t k = a.target.indptr[u] + tid; k < a.target.indptr[u + 1]; k += 256)
@@ -664,12 +689,19 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
 {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
+    // XCD-aware order: workgroup b runs on XCD b % 8; give every XCD one CONTIGUOUS run of tiles so that the
+    // 128-byte lines straddling two neighbouring column tiles (rows are not line-aligned: 2400-B and 80432-B
+    // strides) are re-read from that XCD's L2 instead of being fetched from HBM by two different L2s
+    // (PMC: FETCH_SIZE was 1.37x the algorithmic read bytes with the plain order).
+    const int per_xcd = (a.total_tiles + 7) / 8;
+    const int tile_id = a.plain_order ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile_id >= a.total_tiles) return;
     int ti = 0;
 #pragma unroll 1
     for (int k = 1; k < a.n; ++k)
-        if ((int)blockIdx.x >= a.t[k].tile_start) ti = k;
+        if (tile_id >= a.t[k].tile_start) ti = k;
     const RtxAdamTensor& t = a.t[ti];
-    const int local = blockIdx.x - t.tile_start;
+    const int local = tile_id - t.tile_start;
     const int tiles_c = (t.cols + 63) / 64;
     const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
     float reg = 0.f;
@@ -763,10 +795,15 @@ int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
         tiles += ((a.t[k].rows + 63) / 64) * ((a.t[k].cols + 63) / 64);
     }
     if (tiles == 0) return RTX_OK;
+    a.total_tiles = tiles;
+    static int plain = -1;
+    if (plain < 0) { const char* v = getenv("RTX_ADAM_PLAIN_ORDER"); plain = v ? atoi(v) : 0; }
+    a.plain_order = plain;
+    const int grid = 8 * ((tiles + 7) / 8);
     if (is_bf16)
-        hipLaunchKernelGGL(k_adam<bf16_t>, dim3(tiles), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_adam<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(k_adam<float>, dim3(tiles), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_adam<float>, dim3(grid), dim3(256), 0, stream, a);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

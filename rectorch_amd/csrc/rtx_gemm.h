@@ -43,6 +43,8 @@ struct RtxGemm {
     const float* bias;   // RTX_EPI_BIAS_ROWS
     float* gbias;        // RTX_EPI_GRAD (nullable)
     int M_real, N_real;
+    float2* lse_part;    // RTX_EPI_BIAS_ROWS (nullable): per row, per 64-column strip (running max, sum exp) of the
+    int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
 };
 
 int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t stream);

@@ -97,6 +97,8 @@ int rtx_launch_vae_bwd(const RtxVaeBwdArgs& a, int is_bf16, hipStream_t stream);
 struct RtxLossArgs {
     const float* Y;  // logits [Bp][ldy]
     int ldy, B, I;
+    const float2* part;  // per-row, per-strip (max, sumexp) partials from the logits GEMM epilogue (nullable)
+    int n_strips, part_ld;
     RtxCsrView target;
     const float* tsum;
     float* lse;       // [Bp] out
@@ -142,6 +144,8 @@ struct RtxAdamTensor {
 struct RtxAdamArgs {
     RtxAdamTensor t[RTX_MAX_TENSORS];
     int n;
+    int total_tiles;   // filled by rtx_launch_adam
+    int plain_order;   // experiments: 1 = tile b handled by workgroup b (no XCD-contiguous order)
     int update;        // 0: only refresh the shadows from the master parameters
     float step_size;   // lr / (1 - beta1^t)
     float bc2_sqrt;    // sqrt(1 - beta2^t)

@@ -38,6 +38,12 @@ class CsrMatrix:
                                    C.c_int64(m.shape[0]), C.c_int32(m.shape[1]), C.byref(h)))
         self.handle = h
 
+    @property
+    def op_handle(self):
+        """integer handle for the ``torch.ops.rectorch_hip`` custom ops (rectorch_amd/ops.py)"""
+        from . import ops
+        return ops.register_handle(self)
+
     def gather_dense(self, row_ids, out=None):
         """float32 [len(row_ids), n_cols] device tensor holding the given rows (K1 in dense form)."""
         n = int(row_ids.numel())
@@ -130,6 +136,12 @@ class Engine:
         self.n_tensors = lib().rtx_engine_n_tensors(h)
         self._bound = None
         self._keep = []
+
+    @property
+    def op_handle(self):
+        """integer handle for the ``torch.ops.rectorch_hip`` custom ops (rectorch_amd/ops.py)"""
+        from . import ops
+        return ops.register_handle(self)
 
     # ---- binding --------------------------------------------------------------------------------
     def bind(self, params, grads=None, exp_avg=None, exp_avg_sq=None):

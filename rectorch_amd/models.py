@@ -293,6 +293,12 @@ class AETrainer(TorchNNTrainer):
         self.network.eval()
         x_in = self.network._as_input(x)
         eng = self.network.rtx_engine(self.predict_numerics, x_in.shape[0])
+        if getattr(x_in, "_rtx_rows", None) is None:
+            # dense input: through the PyTorch-ROCm custom op (torch.ops.rectorch_hip.*, rectorch_amd/ops.py)
+            from . import ops  # noqa: F401  (registers the ops)
+            if self._variant == "vae":
+                return torch.ops.rectorch_hip.mvae_forward(eng.op_handle, x_in, False, bool(remove_train), 0)
+            return (torch.ops.rectorch_hip.mdae_forward(eng.op_handle, x_in, False, bool(remove_train), 0), None, None)
         return eng.forward(x_in, training=False, remove_train=remove_train)
 
     def predict(self, x, remove_train=True):

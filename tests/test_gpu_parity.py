@@ -452,3 +452,89 @@ def test_edge_cases():
     assert np.isfinite(model.train_batch(empty_only))                              # all-zero rows: loss is just KL
     with pytest.raises(Exception):
         model.predict(torch.zeros(2, I + 1))                                      # wrong width fails loudly
+
+
+def test_custom_ops_match_the_direct_calls():
+    """torch.ops.rectorch_hip.* (rectorch_amd/ops.py) are thin adapters over the same C entry points"""
+    from rectorch_amd import ops  # noqa: F401
+    from rectorch_amd.engine import CsrMatrix
+    from rectorch_amd.utils import hash_state_dict
+    I, H, L = 200, 32, 8
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 9, bias_std=0.2)
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, numerics="fp32")
+    rng = np.random.default_rng(1)
+    dense = (rng.random((12, I)) < 0.1).astype(np.float32)
+    x = dev(dense)
+    eng = net.rtx_engine("fp32", 12)
+    a = eng.forward(x, remove_train=True)
+    b = torch.ops.rectorch_hip.mvae_forward(eng.op_handle, x, False, True, 0)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.equal(model.predict(x)[0], a[0])                  # predict() goes through the op
+    loss_op = torch.ops.rectorch_hip.multinomial_loss(a[0].nan_to_num(neginf=0.0), x, a[1], a[2], 0.3)
+    loss_fn = model.loss_function(a[0].nan_to_num(neginf=0.0), x, a[1], a[2], 0.3)
+    assert torch.equal(loss_op, loss_fn)
+    csr = CsrMatrix(csr_matrix(dense.astype(np.float64)))
+    rows = torch.tensor([3, 0, 11], dtype=torch.int32, device="cuda")
+    assert np.array_equal(torch.ops.rectorch_hip.csr_gather_dense(csr.op_handle, rows).cpu().numpy(), dense[[3, 0, 11]])
+
+
+def test_config0_multidae_ml100k_shape_vs_oracle():
+    """BASELINE.json configs[0]: MultiDAE on ml-100k-shaped data (740 x 1450, ~60 nnz/user), dims [I,600,200],
+    lam 0.2, lr 1e-3, batch 250 (config/config_dae.json) and 100: 6 steps with injected dropout masks vs the CPU oracle
+    (loss curve + parameters), then nDCG@100 of predict() on held-out users vs the oracle's predict."""
+    from oracle import c_oracle
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.metrics import Metrics
+    U, I, H, L = 740, 1450, 600, 200
+    X = synth_interactions(U, I, mu=3.8, sigma=0.7, dmin=3, dmax=400, seed=100)
+    dense = np.asarray(X.toarray(), dtype=np.float32)
+    for B in (250, 100):
+        sd = hash_state_dict([I, H, L], [L, H, I], "dae", 55, bias_std=0.1)
+        net, model = make_dae([I, H, L], [L, H, I], 0.5, sd, lam=0.2, numerics="fp32")
+        params, keys = params_in_order(sd)
+        ref = c_oracle.OracleTrainer([I, H, L], [L, H, I], params, "dae", 0.5, lam=0.2, lr=1e-3)
+        rng = np.random.default_rng(B)
+        for t in range(6):
+            rows = rng.choice(U, B, replace=False)
+            mask = (rng.random((B, I)) >= 0.5).astype(np.uint8)
+            model._rtx.inject = (dev(mask, torch.uint8), None)
+            loss = model.train_batch(torch.from_numpy(dense[rows]))
+            ref_loss = ref.train_batch(dense[rows], None, mask, None)
+            assert abs(loss - ref_loss) < 2e-5 * abs(ref_loss), (B, t, loss, ref_loss)
+        for p, r, k in zip(net._param_list(), ref.params, keys):
+            # 6 Adam steps: an entry whose gradient is ~1e-8 moves by O(lr) on a 1e-9 gradient difference
+            # (update = lr*g/(|g|+eps)); 1e-4 = a tenth of ONE lr-sized step
+            assert float(np.max(np.abs(p.detach().cpu().numpy() - r))) < 1e-4, (B, k)
+        held = dense[:100].copy()
+        te = np.zeros_like(held)
+        for u in range(100):                      # hold out every 5th item of each user
+            nz = np.flatnonzero(held[u])[::5]
+            te[u, nz] = 1
+            held[u, nz] = 0
+        pred = model.predict(torch.from_numpy(held))[0].cpu().numpy()
+        (pref,) = ref.predict(held, True)
+        a = Metrics.ndcg_at_k(pred, te, 100)
+        b = Metrics.ndcg_at_k(pref, te, 100)
+        assert abs(np.nanmean(a) - np.nanmean(b)) < 1e-4
+
+
+def test_config3_netflix_shape_step_is_finite_and_consistent():
+    """BASELINE.json configs[3] shape on one GPU: I = 17769, 512 users per GPU, bf16; the fp32 and bf16 engines see
+    the same batch and must agree on the loss to bf16 accuracy; gradients all finite."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L, B = 17769, 600, 200, 512
+    X = synth_interactions(1024, I, mu=4.3, sigma=1.0, dmax=5000, seed=17)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 3, bias_std=0.05)
+    losses = {}
+    for numerics in ("fp32", "bf16"):
+        net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, numerics=numerics)
+        (rb, _) = list(DataSampler(X, batch_size=B, shuffle=False).iter_rows())
+        gen = torch.Generator().manual_seed(5)
+        mask = (torch.rand(B, I, generator=gen) >= 0.5).to(torch.uint8).cuda()
+        eps = torch.randn(B, L, generator=gen).cuda()
+        model._rtx.inject = (mask, eps)
+        losses[numerics] = model._fused_step(rb, None, want_loss=True)
+        assert all(torch.isfinite(p.grad).all() for p in net._param_list())
+    assert abs(losses["bf16"] - losses["fp32"]) < 3e-3 * abs(losses["fp32"]), losses
