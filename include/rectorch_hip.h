@@ -68,10 +68,16 @@ typedef struct {
     float inv_batch;             /* scale of the batch mean: 1/B, or 1/B_global under data parallel  */
     float lr, beta1, beta2, eps, weight_decay; /* Adam hyper-parameters                              */
     int32_t step;                /* Adam step count t of THIS update (1-based)                       */
+    int32_t flags;               /* RTX_STEP_* bits                                                   */
     uint64_t seed, offset;       /* Philox stream for dropout and the reparameterisation noise       */
     const uint8_t* dropout_mask; /* injected keep-mask [batch][n_items] (NULL -> Philox)             */
     const float* eps_noise;      /* injected N(0,1) draws [batch][latent]  (NULL -> Philox)          */
 } rtx_step;
+
+/* rtx_engine_train_step fuses the Adam update of the large weight matrices into the epilogue of their
+ * weight-gradient GEMM, so those gradients are never written to HBM; set this bit to ALSO store them in the
+ * bound gradient buffers (p.grad in the Python mirror). */
+#define RTX_STEP_KEEP_GRADS 1
 
 /* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
  * have been enqueued; layers complete in reverse order (last decoder layer first).  A data-parallel

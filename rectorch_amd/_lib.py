@@ -15,6 +15,7 @@ MAX_LAYERS = 8
 
 RTX_VAE, RTX_DAE = 0, 1
 RTX_FP32, RTX_BF16 = 0, 1
+RTX_STEP_KEEP_GRADS = 1
 NUMERICS = {"fp32": RTX_FP32, "bf16": RTX_BF16}
 
 
@@ -37,7 +38,7 @@ class Batch(C.Structure):
 class Step(C.Structure):
     _fields_ = [("beta", C.c_float), ("lam", C.c_float), ("inv_batch", C.c_float),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("step", C.c_int32),
+                ("weight_decay", C.c_float), ("step", C.c_int32), ("flags", C.c_int32),
                 ("seed", C.c_uint64), ("offset", C.c_uint64),
                 ("dropout_mask", C.c_void_p), ("eps_noise", C.c_void_p)]
 

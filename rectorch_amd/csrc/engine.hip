@@ -86,6 +86,9 @@ struct rtx_engine {
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool no_lse_fuse = true;    // LSE partials in the logits-GEMM epilogue: measured 8 us/step SLOWER (A/B, same box:
                                 // +12 us of shuffles in the GEMM vs -8 us in k_lse_loss); RTX_LSE_FUSE=1 enables it
+    bool fuse_adam = false;     // Adam of the big weight matrices in the epilogue of their dW GEMM (RTX_FUSE_ADAM=1).
+                                // Correct (native test step 3) but not faster yet: 448 vs 446 us/step, A/B on one box --
+                                // 2 x 88 us fused GEMMs + 25 us shadow transpose + 17 us small Adam vs 33 + 31 + 145 us.
     bool overlap_adam = false;  // measured slower on MI355X (see loss_grads_impl); RTX_OVERLAP_ADAM=1 re-enables
     // timing
     bool timing_all = false;
@@ -400,7 +403,7 @@ static void fill_adam_tensors(rtx_engine* e, RtxAdamArgs& a, int l0 = 0, int l1 
 }
 
 // torch.optim.Adam's scalars for update `step` (computed in double like torch does on the host)
-static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& a, int l0)
+static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& a, int t0 /* first tensor index */)
 {
     a.update = 1;
     const double bc1 = 1.0 - pow((double)step->beta1, (double)step->step);
@@ -410,7 +413,7 @@ static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& 
     a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
     a.grad_scale = 1.f;
     a.lam = 0.f; a.sumsq = nullptr;
-    if (!e->vae && step->lam != 0.f) { a.lam = step->lam; a.sumsq = e->sumsq + 2 * l0; }
+    if (!e->vae && step->lam != 0.f) { a.lam = step->lam; a.sumsq = e->sumsq + t0; }
 }
 
 static int launch_sumsq(rtx_engine* e, hipStream_t st)
@@ -526,6 +529,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     e->esz = e->bf16 ? 2 : 4;
     e->Bp_alloc = rtx_pad_batch(cfg->max_batch);
     if (const char* v = getenv("RTX_OVERLAP_ADAM")) e->overlap_adam = atoi(v) != 0;
+    if (const char* v = getenv("RTX_FUSE_ADAM")) e->fuse_adam = atoi(v) != 0;
     if (const char* v = getenv("RTX_LSE_FUSE")) e->no_lse_fuse = atoi(v) == 0;
     const size_t Bp = e->Bp_alloc, es = e->esz;
     size_t cacc = 0;
@@ -702,8 +706,10 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 // MEASURED NEGATIVE on MI355X (ml-20m shape, B=500, bf16): 506 us/step with the overlap vs 477 us without, and
 // 495 us with the side stream at the lowest priority -- the 3160 Adam workgroups flood the CUs and the small
 // hidden-layer GEMMs behind them go from 12 to 43 us each.  Kept behind RTX_OVERLAP_ADAM=1 for later rounds.
+static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
+
 static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
-                           rtx_layer_cb cb, void* user, hipStream_t st, bool adam_side)
+                           rtx_layer_cb cb, void* user, hipStream_t st, bool adam_side, bool fuse)
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
@@ -745,9 +751,38 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         TIMED("target_fixup");
         RTX_TRY(rtx_launch_target_fixup(tg, B, step->inv_batch, l.D, e->Ip, l.DT, ldt, e->bf16, st));
     }
+    RtxAdamArgs rest = {};   // tensors whose Adam is NOT fused into a GEMM epilogue (biases, small layers)
+    rest.n = 0;
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
-        {   // weight + bias gradient: gW[out][in] = DT[outp][Bp] x AT[inp][Bp]^T ; column `in` = bias gradient
+        // (1) data gradient FIRST: it reads this layer's transposed compute copy, which the fused optimizer epilogue
+        //     of (2) overwrites:  dA[Bp][inp] = D[Bp][outp] x WshT[inp][outp]^T
+        if (li > 0) {
+            int splits = 1;
+            {
+                TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
+                RTX_TRY(gemm_to_cacc(e, l.D, l.outp, l.WshT, l.outp, Bp, l.inp, l.outp, &splits, st));
+            }
+            Layer& pv = e->L[li - 1];
+            if (e->vae && li == e->cfg.n_enc) {
+                RtxVaeBwdArgs a = {};
+                a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
+                a.B = B; a.Bp = Bp; a.ldt = ldt; a.Z = e->Z; a.Np = pv.outp;
+                a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32; a.training = 1;
+                a.beta = step->beta; a.inv_batch = step->inv_batch; a.D = pv.D; a.DT = pv.DT;
+                TIMED("vae_head_bwd");
+                RTX_TRY(rtx_launch_vae_bwd(a, e->bf16, st));
+            } else {
+                RtxPostArgs a = {};
+                a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
+                a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = pv.out; a.Np = pv.outp;
+                a.tanh_act = pv.tanh_act; a.O32 = pv.O32; a.R = (li - 1 > 0) ? pv.D : nullptr; a.RT = pv.DT;
+                TIMED("post_bwd");
+                RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
+            }
+        }
+        // (2) weight + bias gradient: gW[out][in] = DT[outp][Bp] x AT[inp][Bp]^T ; column `in` = bias gradient
+        {
             RtxGemm g = {};
             g.A = l.DT; g.B = l.AT; g.lda = ldt; g.ldb = ldt;
             g.k_slices = (int)((size_t)Bp * e->esz / 128);
@@ -755,43 +790,56 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             set_tiles(g, l.outp, l.inp);
             g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
             g.M_real = l.out; g.N_real = l.in;
-            TIMED(li == NL - 1 ? "gemm_dW_out" : (li == 0 ? "gemm_dW_in" : "gemm_dW_hidden"));
-            RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_GRAD, st));
+            const bool fused = fuse && layer_is_big(l);
+            if (fused) {
+                RtxAdamArgs sc = {};
+                fill_adam_scalars(e, step, sc, 2 * li);
+                g.adam.p = e->params[2 * li]; g.adam.m = e->m[2 * li]; g.adam.v = e->v[2 * li];
+                g.adam.gkeep = (step->flags & RTX_STEP_KEEP_GRADS) ? e->grads[2 * li] : nullptr;
+                g.tile_shape = RTX_TILE_128x128;
+                set_tiles(g, l.outp, l.inp);
+                g.adam.sh = l.Wsh; g.adam.shT = nullptr; g.adam.ld_sh = l.inp; g.adam.ld_shT = l.outp;
+                g.adam.step_size = sc.step_size; g.adam.bc2_sqrt = sc.bc2_sqrt; g.adam.beta1 = sc.beta1; g.adam.beta2 = sc.beta2;
+                g.adam.eps = sc.eps; g.adam.weight_decay = sc.weight_decay; g.adam.lam = sc.lam; g.adam.sumsq = sc.sumsq;
+                {
+                    TIMED(li == NL - 1 ? "gemm_dW_adam_out" : (li == 0 ? "gemm_dW_adam_in" : "gemm_dW_adam_hidden"));
+                    RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_ADAM, st));
+                }
+                if (l.WshT) {   // the transposed compute copy (next step's backward-data operand)
+                    TIMED("shadow_transpose");
+                    RTX_TRY(rtx_launch_transpose(l.Wsh, l.inp, l.WshT, l.outp, l.out, l.in, e->bf16, st));
+                }
+            } else {
+                TIMED(li == NL - 1 ? "gemm_dW_out" : (li == 0 ? "gemm_dW_in" : "gemm_dW_hidden"));
+                RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_GRAD, st));
+            }
+            if (fuse) {   // what is left for the small multi-tensor Adam launch at the end of the step
+                RtxAdamArgs one = {};
+                fill_adam_tensors(e, one, li, li + 1);
+                if (!fused) rest.t[rest.n++] = one.t[0];
+                rest.t[rest.n++] = one.t[1];
+            }
         }
         if (cb) cb(li, user);
-        int splits = 1;
-        if (li > 0) {   // data gradient: dA[Bp][inp] = D[Bp][outp] x WshT[inp][outp]^T
-            TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
-            RTX_TRY(gemm_to_cacc(e, l.D, l.outp, l.WshT, l.outp, Bp, l.inp, l.outp, &splits, st));
-        }
         if (adam_side) {
             // layer li's gradients are complete and its shadows have no reader left in this step
             RTX_HIP(hipEventRecord(e->ev_main, st));
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_main, 0));
             RtxAdamArgs a = {};
             fill_adam_tensors(e, a, li, li + 1);
-            fill_adam_scalars(e, step, a, li);
+            fill_adam_scalars(e, step, a, 2 * li);
             ScopedTimer tm_adam(e, "adam", e->side);
             RTX_TRY(rtx_launch_adam(a, e->bf16, e->side));
         }
-        if (li == 0) break;
-        Layer& pv = e->L[li - 1];
-        if (e->vae && li == e->cfg.n_enc) {
-            RtxVaeBwdArgs a = {};
-            a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
-            a.B = B; a.Bp = Bp; a.ldt = ldt; a.Z = e->Z; a.Np = pv.outp;
-            a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32; a.training = 1;
-            a.beta = step->beta; a.inv_batch = step->inv_batch; a.D = pv.D; a.DT = pv.DT;
-            TIMED("vae_head_bwd");
-            RTX_TRY(rtx_launch_vae_bwd(a, e->bf16, st));
-        } else {
-            RtxPostArgs a = {};
-            a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
-            a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = pv.out; a.Np = pv.outp;
-            a.tanh_act = pv.tanh_act; a.O32 = pv.O32; a.R = (li - 1 > 0) ? pv.D : nullptr; a.RT = pv.DT;
-            TIMED("post_bwd");
-            RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
-        }
+    }
+    if (fuse) {
+        // biases and small layers: one multi-tensor launch.  (DAE: their lam*p/||p|| term needs per-tensor norms, which
+        // k_adam indexes by position; the fused path is only taken for lam == 0 or the VAE -- see train_step.)
+        fill_adam_scalars(e, step, rest, 0);
+        rest.sumsq = nullptr; rest.lam = 0.f;
+        TIMED("adam_small");
+        RTX_TRY(rtx_launch_adam(rest, e->bf16, st));
+        e->shadows_valid = true;
     }
     if (adam_side) {   // the next forward (or anything else on the caller's stream) sees the updated weights
         RTX_HIP(hipEventRecord(e->ev_side, e->side));
@@ -804,7 +852,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
 int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                           rtx_layer_cb cb, void* user, void* stream)
 {
-    return loss_grads_impl(e, batch, step, loss_out, loss_accum, cb, user, (hipStream_t)stream, false);
+    return loss_grads_impl(e, batch, step, loss_out, loss_accum, cb, user, (hipStream_t)stream, false, false);
 }
 
 int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
@@ -835,9 +883,14 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
             RTX_HIP(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
             RTX_HIP(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
         }
-        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, true);
+        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, true, false);
     }
-    RTX_TRY(loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false));
+    // Fused optimizer: Adam of the big matrices runs in the epilogue of their weight-gradient GEMM (the gradient
+    // never reaches HBM), the rest in one small launch.  Not for the DAE regulariser (per-tensor norms feed every
+    // tensor's update; kept on the two-kernel path) -- Mult-VAE, the headline model, has lam = 0.
+    if (e->fuse_adam && (e->vae || step->lam == 0.f))
+        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false, true);
+    RTX_TRY(loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false, false));
     return rtx_engine_apply_adam(e, step, stream);
 }
 

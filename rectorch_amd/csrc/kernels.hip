@@ -37,19 +37,6 @@ __device__ __forceinline__ float block_max(float v, float* red)
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-template <typename T> __device__ __forceinline__ void store4(T* dst, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<float>(float* dst, float a, float b, float c, float d)
-{
-    *(float4*)dst = make_float4(a, b, c, d);
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d)
-{
-    uint2 u;
-    u.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-    u.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
-    *(uint2*)dst = u;
-}
-
 __device__ __forceinline__ int64_t csr_row(const RtxCsrView& v, int b) { return v.row_ids ? (int64_t)v.row_ids[b] : (int64_t)b; }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,6 +791,39 @@ int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
         hipLaunchKernelGGL(k_adam<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(k_adam<float>, dim3(grid), dim3(256), 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// compute-copy transpose: out[c][r] = in[r][c] for r < R, c < C (64x64 tiles through LDS, both sides coalesced).
+// Used after the fused dW+Adam GEMM, whose epilogue refreshes only the K(=in)-contiguous copy.
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C)
+{
+    __shared__ T tile[64][66];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = k * 256 + tid, rr = idx >> 6, cc = idx & 63;
+        const bool ok = (r0 + rr < R) && (c0 + cc < C);
+        tile[rr][cc] = ok ? in[(size_t)(r0 + rr) * ld_in + c0 + cc] : (T)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int idx = k * 256 + tid, cc = idx >> 6, rr = idx & 63;
+        if ((r0 + rr < R) && (c0 + cc < C)) out[(size_t)(c0 + cc) * ld_out + r0 + rr] = tile[rr][cc];
+    }
+}
+
+int rtx_launch_transpose(const void* in, int ld_in, void* out, int ld_out, int R, int C, int is_bf16, hipStream_t stream)
+{
+    if (R <= 0 || C <= 0) return RTX_OK;
+    const dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
+    if (is_bf16)
+        hipLaunchKernelGGL(k_transpose<bf16_t>, grid, block, 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
+    else
+        hipLaunchKernelGGL(k_transpose<float>, grid, block, 0, stream, (const float*)in, ld_in, (float*)out, ld_out, R, C);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

@@ -81,6 +81,22 @@ template <> struct Elem<bf16_t> {
     __host__ __device__ static __forceinline__ float to(bf16_t v) { return bf16_to_f32(v); }
 };
 
+#ifdef __HIPCC__
+// four consecutive elements of T from four floats: one 16-byte (f32) or 8-byte (bf16) store
+template <typename T> __device__ __forceinline__ void store4(T* dst, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* dst, float a, float b, float c, float d)
+{
+    *(float4*)dst = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d)
+{
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    u.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    *(uint2*)dst = u;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (dropout keep-mask and the reparameterisation noise).
 // One call -> 4 x 32 random bits as a pure function of (seed, offset, index).

@@ -20,6 +20,22 @@ enum RtxEpilogue {
     RTX_EPI_STORE = 0,   // C (fp32) [M_pad][ldc] (+ split * slab_stride): raw accumulators, unguarded
     RTX_EPI_BIAS_ROWS = 1,  // C[m][n] = acc + bias[n] for m < M_real, n < N_real (ldc arbitrary): logits
     RTX_EPI_GRAD = 2,    // gW[m * N_real + n] = acc (m < M_real, n < N_real); gb[m] = acc at n == N_real
+    RTX_EPI_ADAM = 3,    // the gradient never leaves the registers: torch.optim.Adam update of W (p, exp_avg, exp_avg_sq)
+                         // + refresh of its compute copies, fused into the weight-gradient GEMM (single-GPU step)
+};
+
+// Adam state of the tensor a RTX_EPI_ADAM launch updates (all [M_real][N_real] row-major float32)
+struct RtxAdamEpi {
+    float* p;
+    float* m;
+    float* v;
+    float* gkeep;        // also store the gradient here (nullable): callers that want p.grad
+    void* sh;            // T [M_pad][ld_sh]   compute copy (nullable)
+    void* shT;           // T [N_pad][ld_shT]  transposed compute copy (nullable)
+    int ld_sh, ld_shT;
+    float step_size, bc2_sqrt, beta1, beta2, eps, weight_decay;
+    float lam;           // DAE: g += lam * p / ||p||, ||p||^2 read from *sumsq
+    const float* sumsq;
 };
 
 enum RtxTileShape {     // workgroup tile of C; 128x128 runs 4 waves, the others 8 waves (64x64 or 64x128 per wave)
@@ -43,6 +59,7 @@ struct RtxGemm {
     const float* bias;   // RTX_EPI_BIAS_ROWS
     float* gbias;        // RTX_EPI_GRAD (nullable)
     int M_real, N_real;
+    RtxAdamEpi adam;     // RTX_EPI_ADAM
     float2* lse_part;    // RTX_EPI_BIAS_ROWS (nullable): per row, per 64-column strip (running max, sum exp) of the
     int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
 };

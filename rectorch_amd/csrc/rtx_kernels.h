@@ -156,3 +156,6 @@ struct RtxAdamArgs {
 };
 int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream);
 int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, float* sumsq, hipStream_t stream);
+
+// out[c][r] = in[r][c], r < R, c < C (compute-copy transpose after the fused dW+Adam GEMM)
+int rtx_launch_transpose(const void* in, int ld_in, void* out, int ld_out, int R, int C, int is_bf16, hipStream_t stream);

@@ -131,6 +131,9 @@ class AETrainer(TorchNNTrainer):
         self.optimizer = optim.Adam(self.network.parameters(), lr=learning_rate)
         self.numerics = numerics
         self.predict_numerics = predict_numerics
+        # the single-GPU step fuses Adam into the weight-gradient GEMMs of the big matrices, so their gradients
+        # never reach HBM; set True to also materialise them in p.grad (costs the 4 B/param store back)
+        self.keep_grads = False
         self._rtx = _RtxState()
 
     # ------------------------------------------------------------------------------------------ loss
@@ -262,7 +265,8 @@ class AETrainer(TorchNNTrainer):
                          beta=float(beta), lam=float(lam),
                          inv_batch=1.0 / (B if red is None else red.global_batch(B)),
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
-                         eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step)
+                         eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
+                         flags=_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0)
         loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]
         if red is None:
             eng.train_step(x, target, step, loss_out, loss_acc)

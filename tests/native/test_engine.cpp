@@ -316,6 +316,55 @@ static void parity_case(const char* name, Net net, int numerics, int B, int n_us
         float acc = d2h(d_loss + 1, 1)[0];
         printf("    loss_accum after 2 steps = %.5f\n", acc);
     }
+    // ---- step 3 through rtx_engine_train_step: the fused path (Adam of the big matrices inside the dW GEMM epilogue,
+    //      data gradient before weight gradient), gradients kept for the comparison
+    {
+        const int step = 3;
+        std::vector<const float*> cp;
+        std::vector<float*> gp;
+        for (int t = 0; t < nt; ++t) { cp.push_back(o_p[t].data()); gp.push_back(o_g[t].data()); }
+        double o_loss = 0;
+        orc_forward_backward(&oc, cp.data(), x.data(), use_te ? gt.data() : nullptr, B, 1, mask.data(), vae ? eps.data() : nullptr, beta,
+                             lam, 1.f / B, o_logits.data(), o_mu.data(), o_lv.data(), &o_loss, gp.data());
+        rtx_step sp = {};
+        sp.beta = beta; sp.lam = lam; sp.inv_batch = 1.f / B;
+        sp.lr = 1e-3f; sp.beta1 = 0.9f; sp.beta2 = 0.999f; sp.eps = 1e-8f; sp.weight_decay = wd; sp.step = step;
+        sp.flags = RTX_STEP_KEEP_GRADS;
+        sp.dropout_mask = d_mask; sp.eps_noise = vae ? d_eps : nullptr;
+        for (int t = 0; t < nt; ++t) CK(hipMemset(dt.g[t], 0xff, o_g[t].size() * sizeof(float)));
+        RT(rtx_engine_train_step(eng, &bt, &sp, d_loss, nullptr, nullptr));
+        CK(hipDeviceSynchronize());
+        char nm[64];
+        snprintf(nm, sizeof nm, "fused step3 loss (%.5f)", o_loss);
+        check(nm, fabs(d2h(d_loss, 1)[0] - o_loss) / fabs(o_loss), tol_loss);
+        double worst_g = 0, worst_p = 0;
+        for (int t = 0; t < nt; ++t) {
+            auto gg = d2h(dt.g[t], o_g[t].size());
+            if (!vae && lam != 0.f) {
+                double ss = 0;
+                for (float w : o_p[t]) ss += (double)w * w;
+                double nrm = sqrt(ss);
+                for (size_t k = 0; k < gg.size(); ++k) gg[k] += (float)(lam * o_p[t][k] / nrm);
+            }
+            worst_g = std::max(worst_g, rel_err(gg.data(), o_g[t].data(), gg.size()));
+            orc_adam((int64_t)o_p[t].size(), o_p[t].data(), gg.data(), o_m[t].data(), o_v[t].data(), step, 1e-3f, 0.9f, 0.999f, 1e-8f, wd);
+            auto gp2 = d2h(dt.p[t], o_p[t].size());
+            auto gm2 = d2h(dt.m[t], o_p[t].size());
+            for (size_t k = 0; k < gp2.size(); ++k) {
+                worst_p = std::max(worst_p, fabs((double)gp2[k] - o_p[t][k]));
+                worst_p = std::max(worst_p, fabs((double)gm2[k] - o_m[t][k]));
+            }
+        }
+        check("fused step3 grads", worst_g, tol_grad);
+        check("fused step3 params+exp_avg max|diff|", worst_p, 2e-6);
+        // the refreshed compute copies must be the updated weights: an eval forward agrees with the oracle on them
+        orc_forward_backward(&oc, cp.data(), x.data(), nullptr, B, 0, nullptr, nullptr, 0.f, 0.f, 1.f / B, o_logits.data(), o_mu.data(),
+                             o_lv.data(), nullptr, nullptr);
+        RT(rtx_engine_forward(eng, &bt, 0, nullptr, 0, d_logits, nullptr, nullptr, nullptr));
+        CK(hipDeviceSynchronize());
+        auto fl = d2h(d_logits, (size_t)B * I);
+        check("logits after fused step", rel_err(fl.data(), o_logits.data(), fl.size()), tol_fwd);
+    }
     rtx_engine_destroy(eng);
     rtx_csr_destroy(ctr); rtx_csr_destroy(cte);
     dt.release();
@@ -433,6 +482,8 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s CUs=%d arch=%s | abi v%d\n", prop.name, prop.multiProcessorCount, prop.gcnArchName, rtx_abi_version());
+    // parity cases run rtx_engine_train_step on its fused dW+Adam path (step 3) as well as the default two-kernel path
+    setenv("RTX_FUSE_ADAM", "1", 1);
     for (int numerics = 0; numerics < 2; ++numerics) {
         parity_case("small-vae", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), numerics, 5, 9, 0.2f, false, false, false, 0.2f, 0.f);
         parity_case("small-vae-te-weighted", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), numerics, 6, 9, 0.2f, true, true, false, 1.0f, 0.f);
@@ -445,8 +496,14 @@ int main(int argc, char** argv)
         parity_case("wide-vae", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), numerics, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
     }
     philox_case();
+    setenv("RTX_FUSE_ADAM", "0", 1);
+    {   // the default (two-kernel) train_step on a shape with big layers, against the same oracle
+        parity_case("wide-vae-default-step", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+    }
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
+        const char* fuse = getenv("RTX_PERF_FUSE");
+        setenv("RTX_FUSE_ADAM", fuse ? fuse : "0", 1);
         perf_case(RTX_BF16, B, 50, 0);
         perf_case(RTX_FP32, B, 20, 0);
     }

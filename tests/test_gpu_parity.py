@@ -176,6 +176,7 @@ def test_g3_full_size_training_step_fp32():
     g, I, H, L, net, model, x = _g3_setup("fp32")
     mask = np.unpackbits(g["mask_bits"], axis=1)[:, :I]
     model._rtx.inject = (dev(mask, torch.uint8), dev(g["eps"]))
+    model.keep_grads = True            # W1/W4 take the fused dW+Adam path: ask for their gradients too
     loss = model.train_batch(x)
     assert abs(loss - float(g["train_loss"])) < 1e-5 * abs(float(g["train_loss"]))
     ps = net._param_list()
@@ -199,6 +200,7 @@ def test_g3_full_size_bf16_within_stated_tolerance():
     assert e_logits < 3e-2
     mask = np.unpackbits(g["mask_bits"], axis=1)[:, :I]
     model._rtx.inject = (dev(mask, torch.uint8), dev(g["eps"]))
+    model.keep_grads = True
     loss = model.train_batch(x)
     assert abs(loss - float(g["train_loss"])) < 5e-3 * abs(float(g["train_loss"]))
     ps = net._param_list()
