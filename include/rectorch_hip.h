@@ -142,6 +142,14 @@ int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int3
  * `tensors` is a HOST array of n device pointers, `sizes` a HOST array of element counts. */
 int rtx_sum_l2_norms(const float* const* tensors, const int64_t* sizes, int32_t n, float* out, void* stream);
 
+/* Device-side consumer of predict() for evaluation.evaluate (rectorch/evaluation.py:100-106 + rectorch/metrics.py:
+ * 136-147, 187-196): per user the exact top-max(ks) of the score row, then nDCG@k and Recall@k for every cut-off
+ * against that user's held-out CSR row (column ids sorted).  ndcg / recall: device double [n_k][batch] (nullable);
+ * topk_idx: device int32 [batch][max(ks, kmax)] sorted by descending score (nullable).  ks_host is a HOST array. */
+int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_items, const rtx_csr* heldout,
+                     const int32_t* row_ids, const int32_t* ks_host, int32_t n_k, double* ndcg, double* recall,
+                     int32_t* topk_idx, int32_t kmax, void* stream);
+
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
 int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);
 /* synchronises, returns up to `cap` entries (name, total ms, launches) and clears the counters */

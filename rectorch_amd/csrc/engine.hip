@@ -921,6 +921,19 @@ int rtx_sum_l2_norms(const float* const* tensors, const int64_t* sizes, int32_t 
     return rc;
 }
 
+int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_items, const rtx_csr* heldout,
+                     const int32_t* row_ids, const int32_t* ks_host, int32_t n_k, double* ndcg, double* recall,
+                     int32_t* topk_idx, int32_t kmax, void* stream)
+{
+    RTX_CHECK(scores && heldout && ks_host, RTX_EINVAL, "topk_metrics: NULL argument");
+    RTX_CHECK(heldout->n_cols == n_items, RTX_EINVAL, "topk_metrics: held-out matrix has %d columns, scores have %d", heldout->n_cols, n_items);
+    RTX_CHECK(row_ids || batch <= heldout->n_rows, RTX_EINVAL, "topk_metrics: batch larger than the held-out matrix");
+    int km = kmax;
+    for (int q = 0; q < n_k; ++q) km = std::max(km, (int)ks_host[q]);
+    RtxCsrView v = {heldout->indptr, heldout->indices, heldout->values, row_ids};
+    return rtx_launch_topk_metrics(scores, (long)ld, batch, n_items, v, ks_host, n_k, km, ndcg, recall, topk_idx, (hipStream_t)stream);
+}
+
 // ---- instrumentation -------------------------------------------------------------------------------
 int rtx_engine_set_timing(rtx_engine* e, const char* site, int32_t enable)
 {

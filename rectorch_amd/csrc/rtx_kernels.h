@@ -159,3 +159,7 @@ int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, 
 
 // out[c][r] = in[r][c], r < R, c < C (compute-copy transpose after the fused dW+Adam GEMM)
 int rtx_launch_transpose(const void* in, int ld_in, void* out, int ld_out, int R, int C, int is_bf16, hipStream_t stream);
+
+// evaluate() on the device: exact top-kmax per score row + nDCG@k / Recall@k for each cut-off in ks (host array)
+int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, const RtxCsrView& held, const int* ks, int n_k,
+                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream);

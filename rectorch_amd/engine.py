@@ -25,6 +25,7 @@ class CsrMatrix:
         _lib.require_gpu()
         m = sparse.tocsr().copy()
         m.sum_duplicates()
+        m.sort_indices()          # the device metrics binary-search the held-out rows
         self.shape = m.shape
         self.nnz = int(m.nnz)
         indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
@@ -277,3 +278,21 @@ def sum_l2_norms(tensors):
     out = torch.empty((), dtype=torch.float32, device=ts[0].device)
     check(lib().rtx_sum_l2_norms(ptrs, sizes, n, _ptr(out), stream_ptr()))
     return out
+
+
+def topk_metrics(scores, heldout, rows, ks, want_topk=False):
+    """nDCG@k and Recall@k for every k in ``ks`` (reference rectorch/metrics.py:136-147, 187-196) computed on the
+    device from a score tensor ``[B, n_items]`` and the users' held-out rows of a resident :class:`CsrMatrix`.
+    Returns ``(ndcg [len(ks), B], recall [len(ks), B])`` as float64 device tensors (+ the sorted top-k item ids)."""
+    _lib.require_gpu()
+    scores = scores.contiguous()
+    B, n_items = scores.shape
+    ks = [int(k) for k in ks]
+    arr = (C.c_int32 * len(ks))(*ks)
+    ndcg = torch.empty((len(ks), B), dtype=torch.float64, device=scores.device)
+    recall = torch.empty_like(ndcg)
+    kmax = min(max(ks), n_items)
+    topk = torch.empty((B, kmax), dtype=torch.int32, device=scores.device) if want_topk else None
+    check(lib().rtx_topk_metrics(_ptr(scores), n_items, B, n_items, heldout.handle, _ptr(rows), arr, len(ks),
+                                 _ptr(ndcg), _ptr(recall), _ptr(topk), 0, stream_ptr()))
+    return (ndcg, recall, topk) if want_topk else (ndcg, recall)

@@ -13,7 +13,9 @@ import numpy as np
 
 from .metrics import Metrics
 
-__all__ = ['ValidFunc', 'evaluate', 'one_plus_random']
+__all__ = ['ValidFunc', 'evaluate', 'evaluate_device', 'one_plus_random']
+
+DEVICE_TOPK_MAX = 1024
 
 
 class ValidFunc():
@@ -63,6 +65,41 @@ def evaluate(model, test_loader, metric_list):
         res = Metrics.compute(recon_batch, heldout, metric_list)
         for m in res:
             results[m].append(res[m])
+    for m in results:
+        results[m] = np.concatenate(results[m])
+    return results
+
+
+def evaluate_device(model, test_loader, metric_list):
+    r"""Same contract and same values as :func:`evaluate`, computed on the MI355X.
+
+    With a device-resident :class:`rectorch_amd.samplers.DataSampler` holding the ``(tr, heldout)`` matrices,
+    ``predict`` takes the sparse rows directly and the ``ndcg@k`` / ``recall@k`` metrics are computed by a top-k
+    kernel on the GPU, so per batch only ``len(metric_list) x B`` doubles cross PCIe instead of the ``[B, n_items]``
+    score matrix (40 MB per 500 users at the ml-20m shape) followed by a host ``argpartition``.  Usable as a
+    validation function: ``model.train(..., valid_func=ValidFunc(evaluate_device))``.  Anything it cannot do on the
+    device (other metrics, k > 1024, a host sampler) goes through :func:`evaluate`.
+    """
+    from .samplers import DataSampler
+    from .engine import topk_metrics
+    parsed = []
+    for m in metric_list:
+        name, _, k = m.partition("@")
+        if name.lower() not in ("ndcg", "recall") or not k.isdigit() or not 1 <= int(k) <= DEVICE_TOPK_MAX:
+            parsed = None
+            break
+        parsed.append((m, name.lower(), int(k)))
+    resident = isinstance(test_loader, DataSampler) and test_loader.resident and test_loader.sparse_data_te is not None
+    if not parsed or not resident:
+        return evaluate(model, test_loader, metric_list)
+    ks = sorted({k for _, _, k in parsed})
+    results = {m: [] for m in metric_list}
+    for rb in test_loader.iter_rows():
+        scores = model.predict(rb)[0]                    # HIP forward on the sparse rows, -inf at the train items
+        ndcg, recall = topk_metrics(scores, rb.te, rb.rows, ks)
+        ndcg, recall = ndcg.cpu().numpy(), recall.cpu().numpy()
+        for m, name, k in parsed:
+            results[m].append((ndcg if name == "ndcg" else recall)[ks.index(k)])
     for m in results:
         results[m] = np.concatenate(results[m])
     return results

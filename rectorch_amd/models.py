@@ -296,8 +296,9 @@ class AETrainer(TorchNNTrainer):
         _lib.require_gpu()
         self.network.eval()
         x_in = self.network._as_input(x)
-        eng = self.network.rtx_engine(self.predict_numerics, x_in.shape[0])
-        if getattr(x_in, "_rtx_rows", None) is None:
+        n = len(x_in) if isinstance(x_in, RowBatch) else x_in.shape[0]
+        eng = self.network.rtx_engine(self.predict_numerics, n)
+        if not isinstance(x_in, RowBatch) and getattr(x_in, "_rtx_rows", None) is None:
             # dense input: through the PyTorch-ROCm custom op (torch.ops.rectorch_hip.*, rectorch_amd/ops.py)
             from . import ops  # noqa: F401  (registers the ops)
             if self._variant == "vae":
