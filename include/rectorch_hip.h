@@ -150,6 +150,25 @@ int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_i
                      const int32_t* row_ids, const int32_t* ks_host, int32_t n_k, double* ndcg, double* recall,
                      int32_t* topk_idx, int32_t kmax, void* stream);
 
+/* ---- EASE closed-form model (rectorch/models.py:1003-1069) ------------------------------------------
+ * rtx_ease_fit replaces EASE.train (models.py:1015-1025: G = X^T X; G[diag] += lam; P = inv(G); B = P / (-diag P);
+ * B[diag] = 0) with the Gram matrix, a blocked f64 Cholesky, the triangular inverse and P = W^T W all on f64 MFMA
+ * (Gram matrix on bf16 MFMA when that is exact: integer-valued data, max|x|^2 * n_users < 2^24).  The item-item
+ * matrix B stays in HBM as double [n_items][n_items]; rtx_ease_scores replaces `model = X.dot(B)` + the look-up of
+ * EASE.predict (models.py:1025, 1054-1057): rows `row_ids` (nullable = 0..batch-1) of X times B into out (device
+ * double [batch][n_items]), with -inf at the non-zero entries of row b (or mask_row_ids[b]) of `mask` when given.
+ * Returns RTX_EINVAL when X^T X + lam I is not positive definite (lam <= 0 on rank-deficient data). */
+typedef struct rtx_ease rtx_ease;
+int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream);
+int rtx_ease_destroy(rtx_ease* h);
+int rtx_ease_weights(const rtx_ease* h, double** B_dev, int32_t* n_items);
+/* device-to-device copy of B into a caller buffer of n_items * n_items doubles */
+int rtx_ease_copy_weights(const rtx_ease* h, double* dst_dev, void* stream);
+int rtx_ease_scores(const rtx_ease* h, const rtx_csr* X, const int32_t* row_ids, int32_t batch, const rtx_csr* mask,
+                    const int32_t* mask_row_ids, double* out, void* stream);
+/* HIP-event durations of the last fit: whole fit, Gram matrix, Cholesky, inverse (ms; any pointer nullable) */
+int rtx_ease_timings(const rtx_ease* h, double* fit_ms, double* gram_ms, double* chol_ms, double* inv_ms);
+
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
 int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);
 /* synchronises, returns up to `cap` entries (name, total ms, launches) and clears the counters */

@@ -1,0 +1,26 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's EASE solver (rectorch/models.py:1015-1025 train,
+:1054-1057 predict).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+Pinned by tests/golden/g10_ease.npz (outputs of the reference's own EASE class run in the build container by
+tests/golden/make_golden.py)."""
+import numpy as np
+
+
+def ease_fit(X, lam):
+    """B of models.py:1016-1024: G = X^T X; G[diag] += lam; P = inv(G); B = P / (-diag P); B[diag] = 0."""
+    X = np.asarray(X, dtype=np.float64)
+    G = X.T @ X
+    idx = np.diag_indices(G.shape[0])
+    G[idx] += lam
+    P = np.linalg.inv(G)
+    B = P / (-np.diag(P))
+    B[idx] = 0
+    return B
+
+
+def ease_scores(X, B, ids, mask=None):
+    """model[ids] with model = X B (models.py:1025, 1054) and -inf at mask.nonzero() (models.py:1055-1056)."""
+    pred = np.asarray(X, dtype=np.float64)[ids] @ B
+    if mask is not None:
+        pred[np.asarray(mask).nonzero()] = -np.inf
+    return pred

@@ -69,6 +69,12 @@ SIGNATURES = {
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "rtx_sum_l2_norms": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rtx_topk_metrics": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
+    "rtx_ease_fit": (C.c_int, [_P, C.c_double, C.POINTER(_P), _P]),
+    "rtx_ease_destroy": (C.c_int, [_P]),
+    "rtx_ease_weights": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),
+    "rtx_ease_copy_weights": (C.c_int, [_P, _P, _P]),
+    "rtx_ease_scores": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "rtx_ease_timings": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rtx_engine_set_timing": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rtx_engine_get_timings": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     "rtx_engine_step_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

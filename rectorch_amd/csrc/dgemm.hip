@@ -1,0 +1,104 @@
+// dgemm.hip -- f64 MFMA NT GEMM for the EASE solver (see rtx_dgemm.h).
+#include "rtx_dgemm.h"
+
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+
+#define RTX_DROW 144                   // 128 B of K (16 doubles) + 16 B pad
+#define RTX_DSTAGE (256 * RTX_DROW)    // A rows | B rows of one stage
+
+__global__ __launch_bounds__(256, 2) void rtx_dgemm_nt(const RtxDgemm p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RTX_DSTAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tn = blockIdx.x, tm = blockIdx.y;
+    if (p.lower_only && tn > tm) return;
+
+    int ks0 = 0;
+    int ks1 = p.k_slices;
+    if (p.k_from_tile) ks0 = 8 * max(tm, tn);
+    if (p.k_to_tile) ks1 = min(ks1, 8 * (tm + 1));   // A lower triangular: row tile tm is zero beyond its diagonal block   // 128 rows of K per tile = 8 slices of 16 doubles
+    const int nk = ks1 - ks0;
+
+    const size_t rowA = (size_t)p.lda * 8, rowB = (size_t)p.ldb * 8;
+    const int st_row = tid >> 3, st_ch = tid & 7;
+    const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * 128 + st_row) * rowA + st_ch * 16;
+    const unsigned char* gB = (const unsigned char*)p.B + ((size_t)tn * 128 + st_row) * rowB + st_ch * 16;
+    const int lds_a = st_row * RTX_DROW + st_ch * 16;
+    const int lds_b = (128 + st_row) * RTX_DROW + st_ch * 16;
+
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    f64x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+#define RTX_DGL(X, q, base, row, ks) r##X##q = *(const uint4*)((base) + (size_t)(q) * 32 * (row) + (size_t)(ks) * 128);
+#define RTX_DGLOAD(ks)                                                                                   \
+    RTX_DGL(a, 0, gA, rowA, ks) RTX_DGL(a, 1, gA, rowA, ks) RTX_DGL(a, 2, gA, rowA, ks) RTX_DGL(a, 3, gA, rowA, ks) \
+    RTX_DGL(b, 0, gB, rowB, ks) RTX_DGL(b, 1, gB, rowB, ks) RTX_DGL(b, 2, gB, rowB, ks) RTX_DGL(b, 3, gB, rowB, ks)
+#define RTX_DLS(X, q, off, st) *(uint4*)(smem + (st) * RTX_DSTAGE + (off) + (q) * 32 * RTX_DROW) = r##X##q;
+#define RTX_DLSTORE(st)                                                                                  \
+    RTX_DLS(a, 0, lds_a, st) RTX_DLS(a, 1, lds_a, st) RTX_DLS(a, 2, lds_a, st) RTX_DLS(a, 3, lds_a, st)  \
+    RTX_DLS(b, 0, lds_b, st) RTX_DLS(b, 1, lds_b, st) RTX_DLS(b, 2, lds_b, st) RTX_DLS(b, 3, lds_b, st)
+
+    if (nk > 0) {
+        RTX_DGLOAD(ks0)
+        RTX_DLSTORE(0)
+    }
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int st = t & 1;
+        if (t + 1 < nk) { RTX_DGLOAD(ks0 + t + 1) }
+        // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] of each 16x16x4 product
+        const unsigned char* sA = smem + st * RTX_DSTAGE + (wm * 64 + li) * RTX_DROW + kq * 8;
+        const unsigned char* sB = smem + st * RTX_DSTAGE + (128 + wn * 64 + li) * RTX_DROW + kq * 8;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *(const double*)(sA + i * 16 * RTX_DROW + s4 * 32);
+                b[i] = *(const double*)(sB + i * 16 * RTX_DROW + s4 * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) {
+            if (st) { RTX_DLSTORE(0) } else { RTX_DLSTORE(1) }
+        }
+        __syncthreads();
+    }
+#undef RTX_DGL
+#undef RTX_DGLOAD
+#undef RTX_DLS
+#undef RTX_DLSTORE
+
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg   (NOT the f32 map)
+    double* cp = p.C + ((size_t)tm * 128 + wm * 64 + kq) * p.ldc + (size_t)tn * 128 + wn * 64 + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double* dst = cp + (size_t)(i * 16 + 4 * e) * p.ldc + j * 16;
+                const double v = p.alpha * acc[i][j][e];
+                *dst = (p.beta == 0.0) ? v : p.beta * (*dst) + v;
+            }
+}
+
+int rtx_dgemm_launch(const RtxDgemm& g, hipStream_t stream)
+{
+    RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices >= 0, RTX_EINVAL, "dgemm: empty problem");
+    hipLaunchKernelGGL(rtx_dgemm_nt, dim3(g.n_tiles, g.m_tiles), dim3(256), 0, stream, g);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}

@@ -28,13 +28,6 @@
 
 const char* rtx_last_error_str();
 
-struct rtx_csr {
-    int64_t* indptr = nullptr;
-    int32_t* indices = nullptr;
-    float* values = nullptr;  // nullptr -> all ones
-    int64_t n_rows = 0, nnz = 0;
-    int32_t n_cols = 0;
-};
 
 struct Layer {
     int in = 0, out = 0, inp = 0, outp = 0;

@@ -12,6 +12,15 @@ struct RtxCsrView {
     const int32_t* row_ids;
 };
 
+// the opaque rtx_csr of include/rectorch_hip.h: a scipy-style CSR matrix resident in HBM
+struct rtx_csr {
+    int64_t* indptr = nullptr;
+    int32_t* indices = nullptr;
+    float* values = nullptr;  // nullptr -> all ones
+    int64_t n_rows = 0, nnz = 0;
+    int32_t n_cols = 0;
+};
+
 // ---- K1: sparse user rows -> dense normalised (+dropout) input, both orientations ------------------
 //   X  [Bp][ldx]  row-major   (forward A operand; rows >= B are written as zeros)
 //   XT [P(I)][ldt] transposed (weight-gradient B operand; caller memsets it, the kernel scatters the

@@ -296,3 +296,54 @@ def topk_metrics(scores, heldout, rows, ks, want_topk=False):
     check(lib().rtx_topk_metrics(_ptr(scores), n_items, B, n_items, heldout.handle, _ptr(rows), arr, len(ks),
                                  _ptr(ndcg), _ptr(recall), _ptr(topk), 0, stream_ptr()))
     return (ndcg, recall, topk) if want_topk else (ndcg, recall)
+
+
+class EaseSolver:
+    """Device-resident EASE model: the item-item matrix ``B`` of reference ``EASE.train`` (rectorch/models.py:
+    1015-1024) computed by ``rtx_ease_fit`` (Gram matrix, f64 Cholesky, inverse -- all MFMA) and kept in HBM."""
+
+    def __init__(self, train, lam):
+        _lib.require_gpu()
+        self.train = train if isinstance(train, CsrMatrix) else CsrMatrix(train)
+        self.lam = float(lam)
+        h = C.c_void_p()
+        check(lib().rtx_ease_fit(self.train.handle, C.c_double(self.lam), C.byref(h), stream_ptr()))
+        self.handle = h
+        self.n_items = int(self.train.shape[1])
+
+    def timings(self):
+        """HIP-event durations (ms) of the fit: total, Gram matrix, Cholesky, inverse + P = W^T W."""
+        v = [C.c_double() for _ in range(4)]
+        check(lib().rtx_ease_timings(self.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("fit_ms", "gram_ms", "chol_ms", "inv_ms"), (x.value for x in v)))
+
+    def weights(self):
+        """``B`` as a float64 device tensor [n_items, n_items] (a copy)."""
+        out = torch.empty((self.n_items, self.n_items), dtype=torch.float64, device="cuda")
+        check(lib().rtx_ease_copy_weights(self.handle, _ptr(out), stream_ptr()))
+        return out
+
+    def scores(self, row_ids, mask=None, out=None):
+        """``(X B)[row_ids]`` (reference models.py:1025 + 1054) as a float64 device tensor, ``-inf`` at the non-zero
+        entries of ``mask`` (a :class:`CsrMatrix` whose row b belongs to ``row_ids[b]``; models.py:1055-1056)."""
+        row_ids = torch.as_tensor(row_ids, dtype=torch.int32).to("cuda").contiguous()
+        n = int(row_ids.numel())
+        if n and (int(row_ids.min()) < 0 or int(row_ids.max()) >= self.train.shape[0]):
+            raise IndexError("user index out of range for the training matrix (%d users)" % self.train.shape[0])
+        if mask is not None and (mask.shape[0] != n or mask.shape[1] != self.n_items):
+            raise ValueError("mask matrix has shape %s, expected (%d, %d)" % (mask.shape, n, self.n_items))
+        if out is None:
+            out = torch.empty((n, self.n_items), dtype=torch.float64, device="cuda")
+        if n:
+            check(lib().rtx_ease_scores(self.handle, self.train.handle, _ptr(row_ids), n,
+                                        None if mask is None else mask.handle, None, _ptr(out), stream_ptr()))
+        return out
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                lib().rtx_ease_destroy(h)
+            except Exception:
+                pass
+            self.handle = None

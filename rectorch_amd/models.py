@@ -19,11 +19,11 @@ import torch
 import torch.optim as optim
 
 from . import _lib
-from .engine import RowBatch, multinomial_loss
+from .engine import CsrMatrix, EaseSolver, RowBatch, multinomial_loss
 from .evaluation import ValidFunc, evaluate
 from .samplers import DataSampler
 
-__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE']
+__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE', 'EASE']
 
 logger = logging.getLogger(__name__)
 
@@ -499,3 +499,116 @@ class MultiVAE(VAE):
         checkpoint = super().load_model(filepath)
         self.gradient_updates = checkpoint['gradient_updates']
         return checkpoint
+
+
+class EASE(RecSysModel):
+    r"""Embarrassingly Shallow AutoEncoder (reference rectorch/models.py:959-1069) solved on the MI355X.
+
+    Same constructor, attributes and methods as the reference.  ``train`` computes the closed form
+    :math:`B = P / (-\operatorname{diag} P),\ P = (X^\top X + \lambda I)^{-1},\ B_{ii} = 0` in float64 on the
+    device (``rtx_ease_fit``: MFMA Gram matrix, blocked Cholesky, triangular inverse) and keeps ``B`` in HBM;
+    ``predict`` multiplies the requested users' training rows by ``B`` on the device instead of looking them up
+    in a materialised ``n_users x n_items`` score matrix.  ``model`` -- the reference's score matrix
+    ``X B`` -- is materialised on the host only when it is read (``save_model`` does, to keep the file format).
+
+    Parameters
+    ----------
+    lam : :obj:`float` [optional]
+        The regularization hyper-parameter, by default 100.
+    """
+    def __init__(self, lam=100.):
+        self.lam = lam
+        self._solver = None
+        self._model = None      # host score matrix: only after ``model`` was read or ``load_model``
+
+    @property
+    def model(self):
+        """The score matrix **S** = X B as a :class:`numpy.ndarray` (``None`` before training)."""
+        if self._model is None and self._solver is not None:
+            n_users = self._solver.train.shape[0]
+            out = np.empty((n_users, self._solver.n_items), dtype=np.float64)
+            step = 8192
+            for lo in range(0, n_users, step):
+                hi = min(lo + step, n_users)
+                out[lo:hi] = self._solver.scores(torch.arange(lo, hi, dtype=torch.int32)).cpu().numpy()
+            self._model = out
+        return self._model
+
+    @model.setter
+    def model(self, value):
+        self._model = value
+        self._solver = None
+
+    def train(self, train_data):
+        """Training of the EASE model (reference models.py:1006-1026).
+
+        Parameters
+        ----------
+        train_data : :class:`scipy.sparse.csr_matrix`
+            The training data.
+        """
+        logger.info("EASE - start tarining (lam=%.4f)", self.lam)
+        self._model = None
+        self._solver = EaseSolver(train_data, self.lam)
+        logger.info("EASE - training complete")
+
+    def predict(self, ids_te_users, test_tr, remove_train=True, as_tensor=False):
+        r"""Prediction using the EASE model, :math:`S_{u}=\mathbf{X}_{u,:} \cdot \mathbf{B}` (reference
+        models.py:1028-1057).
+
+        Parameters
+        ----------
+        ids_te_users : array_like
+            List of the test user indexes.
+        test_tr : :class:`scipy.sparse.csr_matrix`
+            Training portion of the test users.
+        remove_train : :obj:`bool` [optional]
+            Whether to set the scores of the items in ``test_tr`` to :math:`-\infty`, by default True.
+        as_tensor : :obj:`bool` [optional]
+            Return the float64 device tensor instead of copying it to a numpy array, by default False.
+
+        Returns
+        -------
+        pred, : :obj:`tuple` with a single element
+            The items' score (on the columns) for each user (on the rows).
+        """
+        if self._solver is None:
+            if self._model is None:
+                raise RuntimeError("EASE.predict called before train / load_model")
+            pred = self._model[ids_te_users, :]         # a loaded score matrix is a pure look-up, as in the reference
+            if remove_train:
+                pred[test_tr.nonzero()] = -np.inf
+            return (torch.from_numpy(pred).to("cuda"), ) if as_tensor else (pred, )
+        mask = CsrMatrix(test_tr) if remove_train else None
+        pred = self._solver.scores(ids_te_users, mask)
+        return (pred, ) if as_tensor else (pred.cpu().numpy(), )
+
+    def save_model(self, filepath):
+        state = {'lambda': self.lam,
+                 'model': self.model
+                }
+        logger.info("Saving EASE model to %s...", filepath)
+        np.save(filepath, state)
+        logger.info("Model saved!")
+
+    def load_model(self, filepath):
+        assert os.path.isfile(filepath), "The model file %s does not exist." %filepath
+        logger.info("Loading EASE model from %s...", filepath)
+        state = np.load(filepath, allow_pickle=True)[()]
+        self.lam = state["lambda"]
+        self.model = state["model"]
+        logger.info("Model loaded!")
+        return state
+
+    def __str__(self):
+        s = "EASE(lambda=%.4f" % self.lam
+        if self._solver is not None:
+            s += ", model size=(%d, %d))" % tuple(self._solver.train.shape)
+        elif self._model is not None:
+            s += ", model size=(%d, %d))" % self._model.shape
+        else:
+            s += ") - not trained yet!"
+        return s
+
+    def __repr__(self):
+        return str(self)

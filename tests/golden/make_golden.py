@@ -27,7 +27,7 @@ import torch.nn.functional as F          # noqa: E402
 from scipy.sparse import csr_matrix      # noqa: E402
 
 from rectorch.nets import MultiVAE_net, MultiDAE_net            # noqa: E402
-from rectorch.models import MultiVAE, MultiDAE                  # noqa: E402
+from rectorch.models import MultiVAE, MultiDAE, EASE            # noqa: E402
 from rectorch.samplers import DataSampler                       # noqa: E402
 from rectorch.evaluation import evaluate                        # noqa: E402
 from rectorch.metrics import Metrics                            # noqa: E402
@@ -382,7 +382,36 @@ def g9():
     save("g9_checkpoint_predict", x=x, pred=pred, dims=np.array([I, H, L]))
 
 
+def g10():
+    """EASE (reference models.py:1003-1069): closed-form fit, predict with/without remove_train, saved model file."""
+    rng = np.random.RandomState(10)
+    # (a) implicit feedback, fewer users than items (rank-deficient Gram matrix, lam makes it SPD); 3 blocks of 128
+    U, I = 200, 300
+    Xa = (rng.rand(U, I) < 0.08).astype(np.float64)
+    ease = EASE(200.)
+    ease.train(csr_matrix(Xa))
+    ids = np.array([3, 17, 17, 199, 0, 42])
+    te = Xa[ids].copy()
+    te[1, :] = 0                      # a user with an empty fold-in row
+    pr_rm = ease.predict(ids, csr_matrix(te))[0].copy()
+    pr_keep = ease.predict(ids, csr_matrix(te), remove_train=False)[0].copy()
+    tmp = tempfile.NamedTemporaryFile()
+    ease.save_model(tmp.name)
+    import shutil
+    shutil.copy(tmp.name + ".npy", os.path.join(HERE, "g10_reference_ease_model.npy"))
+    os.remove(tmp.name + ".npy")
+    save("g10_ease_binary", X=Xa.astype(np.uint8), lam=np.float64(200.), model=ease.model, ids=ids, te=te.astype(np.uint8),
+         pred_remove=pr_rm, pred_keep=pr_keep, str_trained=np.array(str(ease)), str_new=np.array(str(EASE(200.))))
+    # (b) explicit ratings 1..5 (f64 Gram path), one block
+    U, I = 90, 70
+    Xb = (rng.rand(U, I) < 0.2) * rng.randint(1, 6, size=(U, I))
+    Xb = Xb.astype(np.float64) * 0.5          # half stars: not integers -> no exact bf16 path
+    ease = EASE(50.)
+    ease.train(csr_matrix(Xb))
+    save("g10_ease_ratings", X=Xb, lam=np.float64(50.), model=ease.model)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
     for w in which:
-        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9}[w]()
+        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10}[w]()

@@ -588,3 +588,93 @@ def test_evaluate_device_equals_host_evaluate():
     # unsupported metric -> falls back to the host path and still answers
     mixed = evaluate_device(model, smp, ["mrr@10", "ndcg@10"])
     assert set(mixed) == {"mrr@10", "ndcg@10"} and np.allclose(mixed["ndcg@10"], host_res["ndcg@10"], equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------ EASE
+# Tolerance: the reference computes in float64 with LAPACK's LU inverse, the device in float64 with a Cholesky
+# inverse; both are backward stable on the SPD matrix X^T X + lam I (condition number <= (|X|_2^2 + lam) / lam), so
+# the score matrices agree to ~1e-12 absolute on these fixtures.  Asserted: 1e-10.
+def test_ease_binary_g10():
+    from rectorch_amd.models import EASE
+    g = load_golden("g10_ease_binary")
+    X = g["X"].astype(np.float64)
+    ease = EASE(float(g["lam"]))
+    assert ease.model is None and str(ease) == str(g["str_new"])
+    ease.train(csr_matrix(X))
+    assert str(ease) == str(g["str_trained"]) and repr(ease) == str(ease)
+    pr = ease.predict(g["ids"], csr_matrix(g["te"].astype(np.float64)))[0]
+    assert pr.shape == g["pred_remove"].shape and pr.dtype == np.float64
+    assert np.array_equal(np.isneginf(pr), np.isneginf(g["pred_remove"]))
+    fin = np.isfinite(pr)
+    np.testing.assert_allclose(pr[fin], g["pred_remove"][fin], rtol=0, atol=1e-10)
+    pk = ease.predict(g["ids"], csr_matrix(g["te"].astype(np.float64)), remove_train=False)[0]
+    np.testing.assert_allclose(pk, g["pred_keep"], rtol=0, atol=1e-10)
+    assert isinstance(ease.model, np.ndarray)
+    np.testing.assert_allclose(ease.model, g["model"], rtol=0, atol=1e-10)
+    B = ease._solver.weights().cpu().numpy()
+    assert np.all(np.diag(B) == 0)
+
+
+def test_ease_ratings_f64_gram_g10():
+    from rectorch_amd.models import EASE
+    g = load_golden("g10_ease_ratings")
+    ease = EASE(float(g["lam"]))
+    ease.train(csr_matrix(g["X"]))
+    np.testing.assert_allclose(ease.model, g["model"], rtol=0, atol=1e-10)
+
+
+def test_ease_reference_api_and_model_file():
+    """the reference's own test_EASE (tests/test_models.py:359-381) + loading a model file the reference wrote"""
+    from rectorch_amd.models import EASE
+    ease = EASE(200.)
+    assert hasattr(ease, "lam") and hasattr(ease, "model")
+    assert ease.lam == 200 and ease.model is None and repr(ease) == str(ease)
+    X = csr_matrix(np.random.RandomState(0).randint(2, size=(10, 5)), dtype="float64")
+    ease.train(X)
+    assert isinstance(ease.model, np.ndarray)
+    pr = ease.predict([2, 4, 5], X[[2, 4, 5]])[0]
+    assert pr.shape == (3, 5)
+    tmp = tempfile.NamedTemporaryFile()
+    ease.save_model(tmp.name)
+    ease2 = EASE(200.)
+    ease2.load_model(tmp.name + ".npy")
+    assert np.all(ease2.model == ease.model)
+    os.remove(tmp.name + ".npy")
+    g = load_golden("g10_ease_binary")
+    ease3 = EASE()
+    state = ease3.load_model(os.path.join(ROOT, "tests", "golden", "g10_reference_ease_model.npy"))
+    assert ease3.lam == 200. and set(state.keys()) == {"lambda", "model"}
+    pr = ease3.predict(g["ids"], csr_matrix(g["te"].astype(np.float64)))[0]
+    assert np.array_equal(pr, g["pred_remove"])
+
+
+@pytest.mark.parametrize("U,I,lam,density", [(3000, 1000, 100., 0.03), (700, 1500, 10., 0.01), (129, 129, 1., 0.3)])
+def test_ease_vs_oracle_mid_size(U, I, lam, density):
+    from oracle.ease_oracle import ease_fit
+    from rectorch_amd.engine import EaseSolver
+    rng = np.random.RandomState(U + I)
+    X = (rng.rand(U, I) < density).astype(np.float64)
+    s = EaseSolver(csr_matrix(X), lam)
+    B = s.weights().cpu().numpy()
+    Bo = ease_fit(X, lam)
+    assert np.all(np.diag(B) == 0)
+    assert np.max(np.abs(B - Bo)) <= 1e-10 * max(1.0, np.max(np.abs(Bo)))
+    ids = rng.randint(0, U, size=50)
+    sc = s.scores(ids).cpu().numpy()
+    np.testing.assert_allclose(sc, X[ids] @ Bo, rtol=0, atol=1e-9)
+    # size-independent property: (G + lam I) P = I  <=>  G B_j + lam B_j = -e_j / P_jj off the constraint; check the
+    # KKT condition of the EASE problem instead: (G + lam I) B has constant columns off the diagonal = 0, i.e.
+    # R = (G + lam I) B + diag(1/P_jj) - G  vanishes ... restated: (G + lam I)(I - B) is diagonal.
+    G = X.T @ X + lam * np.eye(I)
+    R = G @ (np.eye(I) - B)
+    off = R - np.diag(np.diag(R))
+    assert np.max(np.abs(off)) <= 1e-8 * np.max(np.abs(np.diag(R)))
+
+
+def test_ease_not_positive_definite_is_an_error():
+    from rectorch_amd._lib import RtxError
+    from rectorch_amd.engine import EaseSolver
+    X = np.zeros((4, 6))
+    X[0, 0] = X[1, 1] = 1.0
+    with pytest.raises(RtxError, match="positive definite"):
+        EaseSolver(csr_matrix(X), 0.0)
