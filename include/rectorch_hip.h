@@ -166,7 +166,8 @@ int rtx_ease_weights(const rtx_ease* h, double** B_dev, int32_t* n_items);
 int rtx_ease_copy_weights(const rtx_ease* h, double* dst_dev, void* stream);
 int rtx_ease_scores(const rtx_ease* h, const rtx_csr* X, const int32_t* row_ids, int32_t batch, const rtx_csr* mask,
                     const int32_t* mask_row_ids, double* out, void* stream);
-/* HIP-event durations of the last fit: whole fit, Gram matrix, Cholesky, inverse (ms; any pointer nullable) */
+/* HIP-event durations of the last fit (ms; any pointer nullable): whole fit, Gram matrix, chol_ms = Cholesky +
+ * inverse of the factor, inv_ms = P = W^T W */
 int rtx_ease_timings(const rtx_ease* h, double* fit_ms, double* gram_ms, double* chol_ms, double* inv_ms);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */

@@ -16,10 +16,12 @@ __global__ __launch_bounds__(256, 2) void rtx_dgemm_nt(const RtxDgemm p)
     const int tn = blockIdx.x, tm = blockIdx.y;
     if (p.lower_only && tn > tm) return;
 
-    int ks0 = 0;
-    int ks1 = p.k_slices;
-    if (p.k_from_tile) ks0 = 8 * max(tm, tn);
-    if (p.k_to_tile) ks1 = min(ks1, 8 * (tm + 1));   // A lower triangular: row tile tm is zero beyond its diagonal block   // 128 rows of K per tile = 8 slices of 16 doubles
+    int ks0 = 0, ks1 = p.k_slices;   // 128 rows of K per tile = 8 slices of 16 doubles
+    if (p.k_lo == RTX_DK_TM) ks0 = 8 * tm;
+    else if (p.k_lo == RTX_DK_TN) ks0 = 8 * tn;
+    else if (p.k_lo == RTX_DK_MAX) ks0 = 8 * max(tm, tn);
+    if (p.k_hi == RTX_DK_TM) ks1 = min(ks1, 8 * (tm + 1));
+    else if (p.k_hi == RTX_DK_TN) ks1 = min(ks1, 8 * (tn + 1));
     const int nk = ks1 - ks0;
 
     const size_t rowA = (size_t)p.lda * 8, rowB = (size_t)p.ldb * 8;
@@ -90,9 +92,20 @@ __global__ __launch_bounds__(256, 2) void rtx_dgemm_nt(const RtxDgemm p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 double* dst = cp + (size_t)(i * 16 + 4 * e) * p.ldc + j * 16;
-                const double v = p.alpha * acc[i][j][e];
-                *dst = (p.beta == 0.0) ? v : p.beta * (*dst) + v;
+                double v = p.alpha * acc[i][j][e];
+                if (p.beta != 0.0) v += p.beta * (*dst);
+                *dst = v;
+                acc[i][j][e] = v;
             }
+    if (p.CT) {   // transposed copy: 4 consecutive rows of C per register quad -> 32-byte runs along CT's rows
+        double* ct = p.CT + ((size_t)tn * 128 + wn * 64 + li) * p.ldct + (size_t)tm * 128 + wm * 64 + kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ct[(size_t)(j * 16) * p.ldct + i * 16 + 4 * e] = acc[i][j][e];
+    }
 }
 
 int rtx_dgemm_launch(const RtxDgemm& g, hipStream_t stream)

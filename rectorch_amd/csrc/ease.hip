@@ -6,11 +6,16 @@
 //   1. X^T as a dense K(=users)-contiguous operand, Gram matrix by ONE MFMA SYRK launch
 //        - integer-valued data with max|x|^2 * n_users < 2^24 (implicit feedback): bf16 operands are exact and the f32
 //          accumulators hold exact integers -> G is exact;  otherwise f64 MFMA.
-//   2. G + lam I padded to a multiple of 128 with an identity block, blocked Cholesky (nb = 128) in f64:
-//        diagonal block factor + its triangular inverse in LDS (one workgroup), panel = A21 * inv(L11)^T and the
-//        trailing update A22 -= L21 L21^T as f64 MFMA NT GEMMs (rtx_dgemm).
-//   3. W = L^-1 by blocked triangular inversion (two GEMMs per block column), P = W^T W (GEMM on W^T, summed from the
-//      diagonal block on), B = P / (-diag P) with a zero diagonal.
+//   2. G + lam I padded to a multiple of 128 with an identity block, then a RECURSIVE blocked Cholesky that carries
+//      the inverse of every factored diagonal range along (ease_factor(lo, hi), below):
+//        leaves   one 128x128 block: unscaled right-looking Cholesky + in-place triangular inverse in LDS, one
+//                 workgroup of 1024 threads, one barrier per column (k_potf2_inv)
+//        panel    L21 = A21 * inv(L11)^T          (f64 MFMA NT GEMM, K = width of the left half)
+//        update   A22 -= L21 L21^T                (lower tiles only)
+//        inverse  W21 = -W22 * (L21 * W11)        (two GEMMs; W = L^-1 is kept in both orientations)
+//      Every GEMM of the recursion has K >= half its range, so the f64 MFMA pipe -- not the read-modify-write of C --
+//      is the limit (a flat nb = 128 right-looking sweep measured 14 TFLOP/s; the big nodes of this form run at ~60).
+//   3. P = W^T W as one GEMM on W^T (K from the diagonal block on), B = P / (-diag P) with a zero diagonal.
 //   4. scores S_u = X_u B as a sparse-row x dense f64 product (k_ease_scores), -inf at the user's own items.
 #include "../../include/rectorch_hip.h"
 #include "rtx_dgemm.h"
@@ -18,6 +23,8 @@
 #include "rtx_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 struct rtx_ease {
@@ -35,6 +42,13 @@ __global__ __launch_bounds__(256) void k_ease_scatter_T16(const int64_t* indptr,
     for (int64_t k = indptr[u] + threadIdx.x; k < indptr[u + 1]; k += 256)
         XT[(size_t)indices[k] * ldu + u] = f32_to_bf16(values ? values[k] : 1.f);
 }
+// fp8 flavour: the hardware conversion produces the encoding the MFMA consumes (exact for integers |v| <= 16)
+__global__ __launch_bounds__(256) void k_ease_scatter_T8(const int64_t* indptr, const int32_t* indices, const float* values, long ldu, uint8_t* XT)
+{
+    const int64_t u = blockIdx.x;
+    for (int64_t k = indptr[u] + threadIdx.x; k < indptr[u + 1]; k += 256)
+        XT[(size_t)indices[k] * ldu + u] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(values ? values[k] : 1.f, 0.f, 0, false) & 0xff);
+}
 __global__ __launch_bounds__(256) void k_ease_scatter_T64(const int64_t* indptr, const int32_t* indices, const float* values, long ldu, double* XT)
 {
     const int64_t u = blockIdx.x;
@@ -50,95 +64,46 @@ __global__ __launch_bounds__(256) void k_ease_init(const TG* G, long ldg, double
     if (idx >= (long)np * np) return;
     const int i = (int)(idx / np), j = (int)(idx % np);
     double v = 0.0;
-    if (i < n && j < n) v = (double)G[(size_t)i * ldg + j] + (i == j ? lam : 0.0);
+    if (i < n && j < n) {   // the Gram kernels fill the lower triangle and the whole diagonal tiles
+        if (i >= j || (i >> 7) == (j >> 7)) v = (double)G[(size_t)i * ldg + j] + (i == j ? lam : 0.0);
+    }
     else if (i == j) v = 1.0;
     A[idx] = v;
 }
 
-// One 128x128 diagonal block: Cholesky factor L (lower) in place, W = L^-1 and W^T into compact [128][128] buffers.
-// LDS tile of 128 x 129 doubles: L in the lower triangle, the inverse is built transposed in the free upper triangle.
-__global__ __launch_bounds__(256) void k_potf2_inv(double* Akk, long ld, double* Winv, double* WinvT, int* status)
-{
-    extern __shared__ __attribute__((aligned(16))) double t[];   // [128][129]
-    __shared__ double dinv[128];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        t[i * 129 + j] = Akk[(size_t)i * ld + j];
-    }
-    __syncthreads();
-    for (int j = 0; j < 128; ++j) {
-        const double ajj = t[j * 129 + j];
-        if (!(ajj > 0.0)) {
-            if (tid == 0) *status = 1;
-            return;   // uniform: every thread reads the same value
-        }
-        const double d = sqrt(ajj);
-        __syncthreads();
-        for (int i = j + tid; i < 128; i += 256) t[i * 129 + j] = (i == j) ? d : t[i * 129 + j] / d;
-        __syncthreads();
-        // trailing update of the lower triangle: a[i][c] -= l[i][j] * l[c][j],  j < c <= i
-        const int m = 127 - j;   // rows / cols j+1 .. 127
-        for (int e = tid; e < m * m; e += 256) {
-            const int c = j + 1 + e / m, i = j + 1 + e % m;
-            if (i >= c) t[i * 129 + c] -= t[i * 129 + j] * t[c * 129 + j];
-        }
-        __syncthreads();
-    }
-    if (tid < 128) dinv[tid] = 1.0 / t[tid * 129 + tid];
-    __syncthreads();
-    // inverse by forward substitution, one column per thread: x_c = 1/l_cc, x_i = -(sum_{j=c}^{i-1} l_ij x_j) / l_ii
-    // x_i (i > c) is stored at t[c][i] (upper triangle)
-    if (tid < 128) {
-        const int c = tid;
-        for (int i = c + 1; i < 128; ++i) {
-            double s = t[i * 129 + c] * dinv[c];
-            for (int j = c + 1; j < i; ++j) s += t[i * 129 + j] * t[c * 129 + j];
-            t[c * 129 + i] = -s * dinv[i];
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        const double l = (i >= j) ? t[i * 129 + j] : 0.0;
-        const double w = (i > j) ? t[j * 129 + i] : (i == j ? dinv[i] : 0.0);   // W[i][j], lower triangular
-        Akk[(size_t)i * ld + j] = l;
-        Winv[i * 128 + j] = w;
-        WinvT[j * 128 + i] = w;
-    }
-}
-
-// copy the 128x128 inverse block onto the diagonal of W
-__global__ __launch_bounds__(256) void k_copy_block(const double* src, double* dst, long ld)
-{
-    for (int e = threadIdx.x; e < 128 * 128; e += 256) dst[(size_t)(e >> 7) * ld + (e & 127)] = src[e];
-}
-
-__global__ __launch_bounds__(256) void k_transpose_f64(const double* __restrict__ in, long ld_in, double* __restrict__ out, long ld_out)
+// B[i][j] = P[i][j] / (-P[j][j]), B[i][i] = 0   (P symmetric, only its lower triangle is valid).  One workgroup per
+// 64x64 tile of the lower triangle: the tile is written in place and, transposed through LDS, at its mirror position.
+__global__ __launch_bounds__(256) void k_ease_B(const double* P, long ldp, double* B, int n)
 {
     __shared__ double tile[64][65];
-    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+    __shared__ double drow[64], dcol[64];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int r0 = bi * 64, c0 = bj * 64, tid = threadIdx.x;
+    if (tid < 64) drow[tid] = (r0 + tid < n) ? -P[(size_t)(r0 + tid) * ldp + r0 + tid] : 1.0;
+    else if (tid < 128) dcol[tid - 64] = (c0 + tid - 64 < n) ? -P[(size_t)(c0 + tid - 64) * ldp + c0 + tid - 64] : 1.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int idx = k * 256 + tid, rr = idx >> 6, cc = idx & 63;
-        tile[rr][cc] = in[(size_t)(r0 + rr) * ld_in + c0 + cc];
+        const int i = r0 + rr, j = c0 + cc;
+        // inside a diagonal tile the upper half is read from its mirror
+        tile[rr][cc] = (i < n && j < n) ? ((i >= j) ? P[(size_t)i * ldp + j] : P[(size_t)j * ldp + i]) : 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int idx = k * 256 + tid, cc = idx >> 6, rr = idx & 63;
-        out[(size_t)(c0 + cc) * ld_out + r0 + rr] = tile[rr][cc];
+        const int idx = k * 256 + tid, rr = idx >> 6, cc = idx & 63;
+        const int i = r0 + rr, j = c0 + cc;
+        if (i < n && j < n) B[(size_t)i * n + j] = (i == j) ? 0.0 : tile[rr][cc] / dcol[cc];
     }
-}
-
-// B[i][j] = P[i][j] / (-P[j][j]), B[i][i] = 0   (P symmetric, only its lower triangle is valid)
-__global__ __launch_bounds__(256) void k_ease_B(const double* P, long ldp, double* B, int n)
-{
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)n * n) return;
-    const int i = (int)(idx / n), j = (int)(idx % n);
-    const double pij = (i >= j) ? P[(size_t)i * ldp + j] : P[(size_t)j * ldp + i];
-    B[idx] = (i == j) ? 0.0 : pij / (-P[(size_t)j * ldp + j]);
+    if (bi != bj) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = k * 256 + tid, cc = idx >> 6, rr = idx & 63;   // B[j][i] = P[i][j] / (-P[i][i])
+            const int i = r0 + rr, j = c0 + cc;
+            if (i < n && j < n) B[(size_t)j * n + i] = tile[rr][cc] / drow[rr];
+        }
+    }
 }
 
 // scores[b][:] = sum over the stored entries (i, v) of user row u_b of v * B[i][:]   (models.py:1025, 1054-1057)
@@ -185,14 +150,50 @@ static int dalloc(void** p, size_t bytes, std::vector<void*>& pool)
     return RTX_OK;
 }
 
+struct EaseWork {
+    double *A, *L, *W, *WT;   // [np][np] each: Gram matrix (lower, updated in place), panels of L, L^-1 and its transpose
+    int np;
+    int* status;
+    hipStream_t st;
+};
+
 static int dgemm(const double* A, long lda, const double* B, long ldb, int m_tiles, int n_tiles, int k_slices, double* C, long ldc,
-                 double alpha, double beta, int lower_only, int k_from, int k_to, hipStream_t st)
+                 double* CT, long ldct, double alpha, double beta, int lower_only, int k_lo, int k_hi, hipStream_t st)
 {
     if (m_tiles <= 0 || n_tiles <= 0) return RTX_OK;
     RtxDgemm g = {};
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.m_tiles = m_tiles; g.n_tiles = n_tiles; g.k_slices = k_slices;
-    g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.lower_only = lower_only; g.k_from_tile = k_from; g.k_to_tile = k_to;
+    g.C = C; g.ldc = ldc; g.CT = CT; g.ldct = ldct; g.alpha = alpha; g.beta = beta; g.lower_only = lower_only;
+    g.k_lo = k_lo; g.k_hi = k_hi;
     return rtx_dgemm_launch(g, st);
+}
+
+// Block rows/columns [lo, hi) of the padded matrix (units of 128).  On return W[lo:hi, lo:hi] = inv(L[lo:hi, lo:hi])
+// (W^T likewise) and the strictly-lower block panels of L inside the range are in w.L.
+static int ease_factor(const EaseWork& w, int lo, int hi)
+{
+    const long np = w.np;
+    if (hi - lo == 1) {
+        const size_t d = (size_t)lo * 128 * np + (size_t)lo * 128;
+        return rtx_potf2_inv_launch(w.A + d, np, w.W + d, w.WT + d, np, w.status, w.st);
+    }
+    const int mid = lo + (hi - lo + 1) / 2, n1 = mid - lo, n2 = hi - mid;
+    RTX_TRY(ease_factor(w, lo, mid));
+    const size_t d1 = (size_t)lo * 128 * np + (size_t)lo * 128;     // block (lo, lo)
+    const size_t d2 = (size_t)mid * 128 * np + (size_t)mid * 128;   // block (mid, mid)
+    const size_t o21 = (size_t)mid * 128 * np + (size_t)lo * 128;   // block (mid, lo)
+    const size_t o12 = (size_t)lo * 128 * np + (size_t)mid * 128;   // block (lo, mid)
+    // panel: L21[m][n] = sum_k A21[m][k] W11[n][k]   (W11 lower triangular: k < 128 (tn + 1))
+    RTX_TRY(dgemm(w.A + o21, np, w.W + d1, np, n2, n1, 8 * n1, w.L + o21, np, nullptr, 0, 1.0, 0.0, 0, RTX_DK_ALL, RTX_DK_TN, w.st));
+    // update: A22 -= L21 L21^T (lower tiles)
+    RTX_TRY(dgemm(w.L + o21, np, w.L + o21, np, n2, n2, 8 * n1, w.A + d2, np, nullptr, 0, -1.0, 1.0, 1, RTX_DK_ALL, RTX_DK_ALL, w.st));
+    RTX_TRY(ease_factor(w, mid, hi));
+    // T^T[n][m] = sum_k W11^T[n][k] L21[m][k]   (W11^T upper triangular: k >= 128 tm); scratch = the unused mirror block of A
+    double* TT = w.A + o12;
+    RTX_TRY(dgemm(w.WT + d1, np, w.L + o21, np, n1, n2, 8 * n1, TT, np, nullptr, 0, 1.0, 0.0, 0, RTX_DK_TM, RTX_DK_ALL, w.st));
+    // W21[m][n] = -sum_j W22[m][j] T^T[n][j]     (W22 lower triangular: j < 128 (tm + 1)); also stored into W^T
+    RTX_TRY(dgemm(w.W + d2, np, TT, np, n2, n1, 8 * n2, w.W + o21, np, w.WT + o12, np, -1.0, 0.0, 0, RTX_DK_ALL, RTX_DK_TM, w.st));
+    return RTX_OK;
 }
 
 static double elapsed_ms(hipEvent_t a, hipEvent_t b)
@@ -222,38 +223,49 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
 #define EASE_TRY(x) do { rc = (x); if (rc) goto done; } while (0)
 #define EASE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rtx_set_error("ease: %s -> %s", #x, hipGetErrorString(e_)); rc = RTX_EHIP; goto done; } } while (0)
     {
-        double *A = nullptr, *W = nullptr, *WT = nullptr, *T1T = nullptr, *Winv = nullptr, *WinvT = nullptr;
+        double *A = nullptr, *L = nullptr, *W = nullptr, *WT = nullptr;
         int* d_status = nullptr;
-        // ---- exactness test for the bf16 Gram path (host pass over the values; binary data has values == NULL)
-        bool use_bf16 = true;
-        if (X->values && X->nnz > 0) {
-            std::vector<float> hv((size_t)X->nnz);
-            EASE_HIP(hipMemcpy(hv.data(), X->values, sizeof(float) * X->nnz, hipMemcpyDeviceToHost));
-            double mx = 0;
-            for (float v : hv) {
-                if (v != rintf(v) || fabsf(v) > 256.f) { use_bf16 = false; break; }
-                mx = fmax(mx, fabs((double)v));
+        // ---- exactness test for the low-precision Gram paths (host pass over the values; binary data has values == NULL):
+        //      integer-valued entries whose products sum below 2^24 are exact in f32 accumulators; the operands are exact
+        //      in fp8 e4m3 up to |v| = 16 and in bf16 up to |v| = 256
+        int gram = RTX_DT_FP8;   // RTX_DT_FP8 / RTX_DT_BF16, or RTX_DT_F32 meaning "no: use the f64 path"
+        {
+            double mx = 1.0;
+            if (X->values && X->nnz > 0) {
+                std::vector<float> hv((size_t)X->nnz);
+                EASE_HIP(hipMemcpy(hv.data(), X->values, sizeof(float) * X->nnz, hipMemcpyDeviceToHost));
+                mx = 0;
+                for (float v : hv) {
+                    if (v != rintf(v) || fabsf(v) > 256.f) { gram = RTX_DT_F32; break; }
+                    mx = fmax(mx, fabs((double)v));
+                }
             }
-            if (mx * mx * (double)U >= 16777216.0) use_bf16 = false;
-        } else if ((double)U >= 16777216.0) {
-            use_bf16 = false;
+            if (gram != RTX_DT_F32 && mx * mx * (double)U >= 16777216.0) gram = RTX_DT_F32;
+            if (gram == RTX_DT_FP8 && mx > 16.0) gram = RTX_DT_BF16;
+            const char* force = getenv("RTX_EASE_GRAM");   // "bf16" / "f64": measurement switch
+            if (force && gram == RTX_DT_FP8 && !strcmp(force, "bf16")) gram = RTX_DT_BF16;
+            if (force && !strcmp(force, "f64")) gram = RTX_DT_F32;
         }
         EASE_TRY(dalloc((void**)&A, sizeof(double) * (size_t)np * np, pool));
         EASE_HIP(hipEventRecord(e0, st));
         // ---- 1. Gram matrix
-        if (use_bf16) {
+        if (gram != RTX_DT_F32) {
+            const int esz = (gram == RTX_DT_FP8) ? 1 : 2;
             const long Up = ((U + 127) / 128) * 128;
-            bf16_t* XT = nullptr;
+            void* XT = nullptr;
             float* G32 = nullptr;
-            EASE_TRY(dalloc((void**)&XT, sizeof(bf16_t) * (size_t)np * Up, pool));
+            EASE_TRY(dalloc(&XT, (size_t)esz * np * Up, pool));
             EASE_TRY(dalloc((void**)&G32, sizeof(float) * (size_t)np * np, pool));
-            EASE_HIP(hipMemsetAsync(XT, 0, sizeof(bf16_t) * (size_t)np * Up, st));
-            hipLaunchKernelGGL(k_ease_scatter_T16, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, XT);
+            EASE_HIP(hipMemsetAsync(XT, 0, (size_t)esz * np * Up, st));
+            if (gram == RTX_DT_FP8)
+                hipLaunchKernelGGL(k_ease_scatter_T8, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, (uint8_t*)XT);
+            else
+                hipLaunchKernelGGL(k_ease_scatter_T16, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, (bf16_t*)XT);
             RtxGemm g = {};
             g.A = XT; g.B = XT; g.lda = Up; g.ldb = Up; g.tile_shape = RTX_TILE_128x128;
-            g.m_tiles = KB; g.n_tiles = KB; g.k_slices = (int)(Up * 2 / 128); g.splits = 1;
+            g.m_tiles = KB; g.n_tiles = KB; g.k_slices = (int)(Up * esz / 128); g.splits = 1; g.syrk_lower = 1;
             g.C = G32; g.ldc = np; g.slab_stride = 0; g.M_real = np; g.N_real = np;
-            EASE_TRY(rtx_gemm_launch(g, 1, RTX_EPI_STORE, st));
+            EASE_TRY(rtx_gemm_launch(g, gram, RTX_EPI_STORE, st));
             hipLaunchKernelGGL(k_ease_init<float>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G32, (long)np, A, n, np, lam);
         } else {
             const long Up = ((U + 15) / 16) * 16;
@@ -263,52 +275,28 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             EASE_TRY(dalloc((void**)&G64, sizeof(double) * (size_t)np * np, pool));
             EASE_HIP(hipMemsetAsync(XT, 0, sizeof(double) * (size_t)np * Up, st));
             hipLaunchKernelGGL(k_ease_scatter_T64, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, XT);
-            EASE_TRY(dgemm(XT, Up, XT, Up, KB, KB, (int)(Up / 16), G64, np, 1.0, 0.0, 1, 0, 0, st));
+            EASE_TRY(dgemm(XT, Up, XT, Up, KB, KB, (int)(Up / 16), G64, np, nullptr, 0, 1.0, 0.0, 1, RTX_DK_ALL, RTX_DK_ALL, st));
             // mirror is not needed: only the lower triangle of A is read below; init copies what is there
             hipLaunchKernelGGL(k_ease_init<double>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G64, (long)np, A, n, np, lam);
         }
         EASE_HIP(hipGetLastError());
         EASE_HIP(hipEventRecord(e1, st));
-        // ---- 2. blocked Cholesky, nb = 128 (lower)
-        EASE_TRY(dalloc((void**)&Winv, sizeof(double) * (size_t)KB * 128 * 128, pool));
-        EASE_TRY(dalloc((void**)&WinvT, sizeof(double) * (size_t)KB * 128 * 128, pool));
+        // ---- 2. recursive Cholesky + inverse of the factor
+        EASE_TRY(dalloc((void**)&L, sizeof(double) * (size_t)np * np, pool));
+        EASE_TRY(dalloc((void**)&W, sizeof(double) * (size_t)np * np, pool));
+        EASE_TRY(dalloc((void**)&WT, sizeof(double) * (size_t)np * np, pool));
         EASE_TRY(dalloc((void**)&d_status, sizeof(int), pool));
         EASE_HIP(hipMemsetAsync(d_status, 0, sizeof(int), st));
-        EASE_HIP(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8));
-        for (int k = 0; k < KB; ++k) {
-            double* Akk = A + (size_t)k * 128 * np + (size_t)k * 128;
-            hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(256), 128 * 129 * 8, st, Akk, (long)np, Winv + (size_t)k * 16384, WinvT + (size_t)k * 16384, d_status);
-            const int r = KB - k - 1;
-            if (r == 0) break;
-            double* A21 = A + (size_t)(k + 1) * 128 * np + (size_t)k * 128;
-            // panel: L21 = A21 * inv(L11)^T  (in place: one 128-wide tile column, every workgroup owns its rows)
-            EASE_TRY(dgemm(A21, np, Winv + (size_t)k * 16384, 128, r, 1, 8, A21, np, 1.0, 0.0, 0, 0, 0, st));
-            // trailing update: A22 -= L21 L21^T  (lower tiles)
-            double* A22 = A + (size_t)(k + 1) * 128 * np + (size_t)(k + 1) * 128;
-            EASE_TRY(dgemm(A21, np, A21, np, r, r, 8, A22, np, -1.0, 1.0, 1, 0, 0, st));
+        EASE_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)np * np, st));
+        EASE_HIP(hipMemsetAsync(WT, 0, sizeof(double) * (size_t)np * np, st));
+        {
+            EaseWork w = {A, L, W, WT, np, d_status, st};
+            EASE_TRY(ease_factor(w, 0, KB));
         }
         EASE_HIP(hipGetLastError());
         EASE_HIP(hipEventRecord(e2, st));
-        // ---- 3. W = L^-1 (blocked, from the last block column up), then P = W^T W
-        EASE_TRY(dalloc((void**)&W, sizeof(double) * (size_t)np * np, pool));
-        EASE_TRY(dalloc((void**)&T1T, sizeof(double) * (size_t)128 * np, pool));
-        EASE_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)np * np, st));
-        for (int k = KB - 1; k >= 0; --k) {
-            hipLaunchKernelGGL(k_copy_block, dim3(1), dim3(256), 0, st, Winv + (size_t)k * 16384, W + (size_t)k * 128 * np + (size_t)k * 128, (long)np);
-            const int r = KB - k - 1;
-            if (r == 0) continue;
-            const double* L21 = A + (size_t)(k + 1) * 128 * np + (size_t)k * 128;
-            // T1^T [128][r*128] = W11^T-rows x L21-rows:  T1^T[n][m] = sum_j W11[j][n] L21[m][j]
-            EASE_TRY(dgemm(WinvT + (size_t)k * 16384, 128, L21, np, 1, r, 8, T1T, np, 1.0, 0.0, 0, 0, 0, st));
-            // W21 = -W22 * T1   (W22 lower triangular: row tile tm only needs k < 128 (tm + 1))
-            const double* W22 = W + (size_t)(k + 1) * 128 * np + (size_t)(k + 1) * 128;
-            double* W21 = W + (size_t)(k + 1) * 128 * np + (size_t)k * 128;
-            EASE_TRY(dgemm(W22, np, T1T, np, r, 1, r * 8, W21, np, -1.0, 0.0, 0, 0, 1, st));
-        }
-        EASE_TRY(dalloc((void**)&WT, sizeof(double) * (size_t)np * np, pool));
-        hipLaunchKernelGGL(k_transpose_f64, dim3(np / 64, np / 64), dim3(256), 0, st, W, (long)np, WT, (long)np);
-        // P (into A) = W^T W : P[i][j] = sum_{k >= max(i,j)} WT[i][k] WT[j][k]
-        EASE_TRY(dgemm(WT, np, WT, np, KB, KB, np / 16, A, np, 1.0, 0.0, 1, 1, 0, st));
+        // ---- 3. P (into the lower tiles of A) = W^T W : P[i][j] = sum_{k >= max(i,j)} WT[i][k] WT[j][k]
+        EASE_TRY(dgemm(WT, np, WT, np, KB, KB, np / 16, A, np, nullptr, 0, 1.0, 0.0, 1, RTX_DK_MAX, RTX_DK_ALL, st));
         EASE_HIP(hipGetLastError());
         EASE_HIP(hipEventRecord(e3, st));
         // ---- 4. B
@@ -316,7 +304,7 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             hipError_t e_ = hipMalloc((void**)&h->B, sizeof(double) * (size_t)n * n);
             if (e_ != hipSuccess) { rtx_set_error("ease: hipMalloc(B) failed: %s", hipGetErrorString(e_)); rc = RTX_ENOMEM; goto done; }
         }
-        hipLaunchKernelGGL(k_ease_B, dim3((unsigned)(((long)n * n + 255) / 256)), dim3(256), 0, st, A, (long)np, h->B, n);
+        hipLaunchKernelGGL(k_ease_B, dim3((n + 63) / 64, (n + 63) / 64), dim3(256), 0, st, A, (long)np, h->B, n);
         EASE_HIP(hipGetLastError());
         EASE_HIP(hipEventRecord(e4, st));
         EASE_HIP(hipStreamSynchronize(st));

@@ -24,6 +24,19 @@ template <> struct Mma<bf16_t> {
     }
 };
 
+template <> struct Mma<fp8_t> {
+    // 16 B = 16 fp8 of this lane's row = two K=16 fragments of v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 on gfx950).
+    // Which 8 of the 32 k of a 32-byte sub-slice a lane feeds to which instruction is irrelevant as long as A and B
+    // agree, and they do: both operands use the same (lane, byte) -> k map.
+    static __device__ __forceinline__ void run(f32x16_t& acc, const uint4& a, const uint4& b)
+    {
+        const long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
+        const long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc, 0, 0, 0);
+    }
+};
+
 template <> struct Mma<float> {
     // 16 B = 4 consecutive k of this lane's row; lanes 0-31 hold k = 0..3, lanes 32-63 k = 4..7 of the
     // 8-float sub-slice.  v_mfma_f32_32x32x2_f32 pairs element e of both half-waves; A and B use the same
@@ -74,7 +87,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
     int tm, tn, split;
     {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-        if (p.splits > 1) {
+        if (p.syrk_lower) {
+            // A == B, lower tiles only (Gram matrix of the EASE solver).  K is far longer than any cache, so what
+            // matters is that the 64 workgroups resident on one XCD at a time form an 8x8 PATCH of tiles: they walk K
+            // together and 16 operand row-panels feed 64 tile products out of the XCD's L2.
+            split = 0;
+            const int patch = xcd + 8 * (j >> 6), within = j & 63;
+            int pm = (int)((sqrtf(8.f * (float)patch + 1.f) - 1.f) * 0.5f);
+            while ((pm + 1) * (pm + 2) / 2 <= patch) ++pm;
+            while (pm * (pm + 1) / 2 > patch) --pm;
+            const int pn = patch - pm * (pm + 1) / 2;
+            tm = pm * 8 + (within & 7);
+            tn = pn * 8 + (within >> 3);
+            if (tm >= p.m_tiles || tn > tm) return;
+        } else if (p.splits > 1) {
             const int tiles = p.m_tiles * p.n_tiles;
             split = xcd + 8 * (j / tiles);
             if (split >= p.splits) return;
@@ -270,7 +296,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
                 }
         }
     }
-    if (EPI == RTX_EPI_ADAM) {
+    if constexpr (EPI == RTX_EPI_ADAM) {
         // Fused optimizer: the dW tile never reaches HBM.  It is parked in LDS (the operand stages are dead now), then
         // the workgroup walks it ROW-MAJOR with 16-byte accesses -- 512-byte contiguous runs of p / exp_avg /
         // exp_avg_sq per row, the same streaming pattern as k_adam -- applies torch.optim.Adam and writes p, m, v and
@@ -418,8 +444,11 @@ template <typename T> static void launch_type(const RtxGemm& g, int epilogue, di
     }
 }
 
-int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t stream)
+int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t stream)
 {
+    RTX_CHECK(dtype >= RTX_DT_F32 && dtype <= RTX_DT_FP8, RTX_EINVAL, "gemm: bad operand type %d", dtype);
+    RTX_CHECK(dtype != RTX_DT_FP8 || (epilogue == RTX_EPI_STORE && g.tile_shape == RTX_TILE_128x128), RTX_EINVAL,
+              "gemm: fp8 operands only with the plain-store epilogue and the 128x128 tile (Gram matrix of binary data)");
     RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm: empty problem");
     RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm: split-K only with EPI_STORE");
     RTX_CHECK(epilogue >= RTX_EPI_STORE && epilogue <= RTX_EPI_ADAM, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
@@ -428,11 +457,18 @@ int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t str
     // 1-D grid laid out for the XCD-aware mapping in the kernel: 8 * ceil(groups / 8) * group_size workgroups
     const int tiles = g.m_tiles * g.n_tiles;
     int groups, gsize;
-    if (g.splits > 1) { groups = g.splits; gsize = tiles; }
+    if (g.syrk_lower) {
+        RTX_CHECK(g.m_tiles == g.n_tiles && g.splits == 1 && g.tile_shape == RTX_TILE_128x128 && epilogue == RTX_EPI_STORE, RTX_EINVAL,
+                  "gemm: syrk_lower needs a square 128x128-tiled problem without split-K");
+        const int pr = (g.m_tiles + 7) / 8;
+        groups = pr * (pr + 1) / 2;   // 8x8 patches of the lower triangle
+        gsize = 64;
+    } else if (g.splits > 1) { groups = g.splits; gsize = tiles; }
     else if (g.m_tiles <= g.n_tiles) { groups = g.n_tiles; gsize = g.m_tiles; }
     else { groups = g.m_tiles; gsize = g.n_tiles; }
     const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * gsize));
-    if (is_bf16) launch_type<bf16_t>(g, epilogue, grid, stream);
+    if (dtype == RTX_DT_FP8) hipLaunchKernelGGL((rtx_gemm_nt<fp8_t, RTX_EPI_STORE, 2, 2, 2>), grid, dim3(256), 0, stream, g);
+    else if (dtype == RTX_DT_BF16) launch_type<bf16_t>(g, epilogue, grid, stream);
     else launch_type<float>(g, epilogue, grid, stream);
     RTX_HIP(hipGetLastError());
     return RTX_OK;

@@ -7,6 +7,7 @@
 #include <string>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits; arithmetic type of the throughput mode
+struct fp8_t { uint8_t v; };  // raw OCP e4m3 bits (gfx950); only the EASE Gram matrix uses it
 
 // ---------------------------------------------------------------------------------------------
 // error handling: every C-ABI entry point returns 0 or a negative RTX_E* code, message in a

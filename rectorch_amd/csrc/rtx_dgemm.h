@@ -1,6 +1,6 @@
 // rtx_dgemm.h -- f64 MFMA NT GEMM used by the EASE closed-form solver (ease.hip):
 //
-//   C[m][n] = beta * C[m][n] + alpha * sum_{k >= k0(m,n)} A[m][k] * B[n][k]
+//   C[m][n] = beta * C[m][n] + alpha * sum_{k0(m,n) <= k < k1(m,n)} A[m][k] * B[n][k]
 //
 // v_mfma_f64_16x16x4_f64; 128x128 tile, 4 waves, 64x64 of C per wave as 4x4 blocks of 16x16; K consumed in
 // 128-byte slices (16 doubles) through the same global->VGPR->LDS staging as the bf16/f32 GEMM (144-B padded rows,
@@ -8,6 +8,8 @@
 // with an identity block), so there are no bounds checks.
 #pragma once
 #include "rtx_common.h"
+
+enum { RTX_DK_ALL = 0, RTX_DK_TM = 1, RTX_DK_TN = 2, RTX_DK_MAX = 3 };
 
 struct RtxDgemm {
     const double* A;   // [M][lda]
@@ -17,10 +19,17 @@ struct RtxDgemm {
     int k_slices;      // K / 16
     double* C;
     long ldc;
+    double* CT;        // nullable: the result is also stored transposed, CT[n][m] (ldct)
+    long ldct;
     double alpha, beta;
     int lower_only;    // skip tiles strictly above the diagonal (tn > tm)
-    int k_from_tile;   // 1: the sum starts at k = 128 * max(tm, tn) (products of lower-triangular factors)
-    int k_to_tile;     // 1: the sum ends at k = 128 * (tm + 1) (A lower triangular: nothing beyond its diagonal block)
+    // triangular operands: the K range of tile (tm, tn) starts at 128 * {0, tm, tn, max(tm, tn)}  (k_lo) and ends
+    // at 128 * ({tm, tn} + 1) (k_hi: RTX_DK_TM / RTX_DK_TN) instead of covering all of K
+    int k_lo, k_hi;
 };
 
 int rtx_dgemm_launch(const RtxDgemm& g, hipStream_t stream);
+
+// leaf of the recursive Cholesky: W = inv(chol(Akk)) of one 128x128 block into Wkk (lower) and WTkk (upper), both with
+// leading dimension ldw; *status = 1 if the block is not positive definite (potf2.hip)
+int rtx_potf2_inv_launch(const double* Akk, long ld, double* Wkk, double* WTkk, long ldw, int* status, hipStream_t stream);

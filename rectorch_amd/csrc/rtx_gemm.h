@@ -13,6 +13,8 @@
 // fragment reads conflict-free) -> MFMA.  Double-buffered LDS, one barrier per slice.
 //   bf16 : v_mfma_f32_32x32x16_bf16  (8 bf16 per lane per operand = one ds_read_b128)
 //   f32  : v_mfma_f32_32x32x2_f32    (one ds_read_b128 feeds 4 MFMAs; exact f32, parity mode)
+//   fp8  : v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3; one ds_read_b128 feeds 2 MFMAs) -- only the EASE Gram matrix of
+//          small-integer data, where fp8 operands and f32 accumulation are exact
 #pragma once
 #include "rtx_common.h"
 
@@ -53,6 +55,7 @@ struct RtxGemm {
     int m_tiles, n_tiles;
     int k_slices;        // total 128-byte K slices  (= K_pad * sizeof(T) / 128)
     int splits;          // split-K factor (grid.y); only with RTX_EPI_STORE
+    int syrk_lower;      // 1: A == B, only tiles on or below the diagonal are computed (8x8-patch workgroup order)
     float* C;
     long ldc;
     long slab_stride;    // elements between split-K slabs
@@ -64,4 +67,7 @@ struct RtxGemm {
     int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
 };
 
-int rtx_gemm_launch(const RtxGemm& g, int is_bf16, int epilogue, hipStream_t stream);
+// operand element type.  RTX_DT_F32 = 0 and RTX_DT_BF16 = 1 keep the meaning of the former `is_bf16` flag.
+enum RtxDtype { RTX_DT_F32 = 0, RTX_DT_BF16 = 1, RTX_DT_FP8 = 2 };
+
+int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t stream);

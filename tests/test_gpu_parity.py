@@ -678,3 +678,16 @@ def test_ease_not_positive_definite_is_an_error():
     X[0, 0] = X[1, 1] = 1.0
     with pytest.raises(RtxError, match="positive definite"):
         EaseSolver(csr_matrix(X), 0.0)
+
+
+@pytest.mark.parametrize("vmax,U,I", [(5, 900, 300), (200, 300, 260), (16, 400, 200)])
+def test_ease_integer_valued_gram_paths(vmax, U, I):
+    """integer ratings: the Gram matrix runs on fp8 MFMA (|v| <= 16) or bf16 MFMA (|v| <= 256) and must still be exact"""
+    from oracle.ease_oracle import ease_fit
+    from rectorch_amd.engine import EaseSolver
+    rng = np.random.RandomState(vmax)
+    X = ((rng.rand(U, I) < 0.1) * rng.randint(1, vmax + 1, size=(U, I))).astype(np.float64)
+    X[0, 0] = vmax
+    B = EaseSolver(csr_matrix(X), 30.0).weights().cpu().numpy()
+    Bo = ease_fit(X, 30.0)
+    assert np.max(np.abs(B - Bo)) <= 1e-10 * max(1.0, np.max(np.abs(Bo)))

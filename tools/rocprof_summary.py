@@ -29,5 +29,18 @@ def pmc(path):
         print("%-56s %-12s %10d %6d %16.1f %10.2f" % (k[:56], c, g, n, v, d / 1e3))
 
 
+def bygrid(path):
+    """per (kernel, grid size) totals: separates the big and the small nodes of a recursion that reuses one kernel"""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    gx = "grid_x" if "grid_x" in cols else "grid_size_x" if "grid_size_x" in cols else "grid_size"
+    gy = "grid_y" if "grid_y" in cols else "grid_size_y" if "grid_size_y" in cols else "0"
+    rows = cur.execute("select name, %s, %s, count(*), sum(duration), avg(duration) from kernels group by name, %s, %s "
+                       "order by sum(duration) desc" % (gx, gy, gx, gy)).fetchall()
+    print("# per (kernel, grid) totals (us); columns of the kernels view: %s" % ",".join(cols))
+    for n, x, y, c, sm, a in rows[:60]:
+        print("%-40s grid=(%s,%s) calls=%d total=%.1f avg=%.2f" % (n[:40], x, y, c, sm / 1e3, a / 1e3))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "bygrid": bygrid}[sys.argv[1]](sys.argv[2])
