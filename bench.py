@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--items", type=int, default=20108)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cond-dim", type=int, default=0,
+                    help="measure the conditioned variant (CMultiVAE, SURVEY 8f-4): this many condition columns are "
+                         "appended to every input row, the target stays the item row; not the headline workload")
     ap.add_argument("--force-dp", action="store_true",
                     help="exercise the data-parallel code path (RCCL all-reduce + split step) even with one rank")
     return ap.parse_args()
@@ -105,22 +108,36 @@ def main():
 
     I, H, L, B = args.items, 600, 200, args.batch
     X = synth_interactions(args.users, I, seed=20240927)          # same matrix on every rank
-    net = MultiVAE_net([L, H, I], dropout=0.5)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in hash_state_dict([I, H, L], [L, H, I], "vae", 1234).items()})
-    model = MultiVAE(net, beta=0.2, anneal_steps=100000, learning_rate=1e-3, numerics=args.numerics)
+    Cd = args.cond_dim
+    if Cd:
+        from scipy.sparse import csr_matrix, hstack
+        from rectorch_amd.nets import CMultiVAE_net
+        from rectorch_amd.models import CMultiVAE
+        net = CMultiVAE_net(Cd, [L, H, I], dropout=0.5)
+        model = CMultiVAE(net, beta=0.2, anneal_steps=100000, learning_rate=1e-3, numerics=args.numerics)
+        rs = np.random.RandomState(7)
+        cu = rs.randint(-1, Cd, size=args.users)              # -1: unconditioned example
+        has = cu >= 0
+        onehot = csr_matrix((np.ones(int(has.sum()), dtype=X.dtype), (np.nonzero(has)[0], cu[has])), shape=(args.users, Cd))
+        Xin, Xtg = hstack([X, onehot], format="csr"), X
+    else:
+        net = MultiVAE_net([L, H, I], dropout=0.5)
+        model = MultiVAE(net, beta=0.2, anneal_steps=100000, learning_rate=1e-3, numerics=args.numerics)
+        Xin, Xtg = X, None
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in hash_state_dict([I + Cd, H, L], [L, H, I], "vae", 1234).items()})
     if world == 1 and args.force_dp:
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
     if world > 1 or args.force_dp:
         parallel.attach(model, fixed_global_batch=B * world)
     # resident sampler over the global batch; each rank takes its slice of every global batch
     np.random.seed(20240927)
-    smp = DataSampler(X, batch_size=B * world, shuffle=True)
+    smp = DataSampler(Xin, Xtg, batch_size=B * world, shuffle=True)
     batches = []
     for rb in smp.iter_rows():
         if len(rb) < B * world:
             break
         s, e = parallel.shard_rows(len(rb), rank, world)
-        batches.append(RowBatch(rb.tr, None, rb.rows[s:e].contiguous()))
+        batches.append(RowBatch(rb.tr, rb.te if Cd else None, rb.rows[s:e].contiguous()))
     net.train()
     torch.manual_seed(1000 + rank)
 
@@ -167,7 +184,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "MultiVAE train users/sec on ml-20m (synthetic, ml-20m-shaped)",
+        "metric": ("CMultiVAE (cond_dim=%d) " % Cd if Cd else "MultiVAE ") + "train users/sec on ml-20m (synthetic, ml-20m-shaped)",
         "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.numerics == "bf16" else "f32", "data": "synthetic",
@@ -186,7 +203,7 @@ def main():
                           "achieved_TFLOPs": step_flops / (ms_step * 1e-3) / 1e12},
         "mean_loss": loss_mean,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not Cd:
         out["cpu_baseline"] = cpu_baseline(X, (I, H, L), B, args.cpu_seconds)
     print(json.dumps(out))
     if dist.is_initialized():

@@ -46,10 +46,14 @@ typedef struct {
     float dropout_p;                      /* nn.Dropout(p) on the normalised input (nets.py:392)   */
     int32_t max_batch;                    /* largest batch this engine will be given               */
     int32_t splitk;                       /* split-K factor for the two K = n_items GEMMs, 0 = auto */
+    int32_t cond_dim;                     /* CMultiVAE_net (nets.py:455-480): the input rows carry cond_dim extra
+                                           * columns after the n_items item columns; they enter the first encoder
+                                           * layer raw (no normalisation, no dropout).  0 = MultiVAE / MultiDAE   */
 } rtx_cfg;
 
 /* A batch of users.  Either rows of a resident CSR matrix (fast path: nothing dense crosses the API)
- * or dense [batch][n_items] float32 device tensors (drop-in for train_batch(tr_batch, te_batch) /
+ * or dense [batch][n_items] float32 device tensors.  With cfg.cond_dim > 0 the INPUT (csr / x_dense) has
+ * n_items + cond_dim columns, the target keeps n_items and must be given (the conditioned samplers always do) (drop-in for train_batch(tr_batch, te_batch) /
  * predict(x), reference models.py:817-822, 619-624). */
 typedef struct {
     const rtx_csr* csr;          /* input rows (NULL -> use x_dense)                                 */

@@ -13,7 +13,7 @@ MAXL = 8
 class OrcCfg(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("n_dec", C.c_int32),
                 ("enc_dims", C.c_int32 * (MAXL + 1)), ("dec_dims", C.c_int32 * (MAXL + 1)),
-                ("variant", C.c_int32), ("dropout_p", C.c_float)]
+                ("variant", C.c_int32), ("dropout_p", C.c_float), ("cond_dim", C.c_int32)]
 
 
 def build():
@@ -33,7 +33,7 @@ def lib():
     return _LIB
 
 
-def make_cfg(enc_dims, dec_dims, variant="vae", dropout=0.5):
+def make_cfg(enc_dims, dec_dims, variant="vae", dropout=0.5, cond_dim=0):
     cfg = OrcCfg()
     cfg.n_enc, cfg.n_dec = len(enc_dims) - 1, len(dec_dims) - 1
     for i, d in enumerate(enc_dims):
@@ -42,6 +42,7 @@ def make_cfg(enc_dims, dec_dims, variant="vae", dropout=0.5):
         cfg.dec_dims[i] = int(d)
     cfg.variant = 0 if variant == "vae" else 1
     cfg.dropout_p = float(dropout)
+    cfg.cond_dim = int(cond_dim)
     return cfg
 
 
@@ -54,7 +55,8 @@ def _p(a, t):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
-def param_shapes(enc_dims, dec_dims, variant="vae"):
+def param_shapes(enc_dims, dec_dims, variant="vae", cond_dim=0):
+    enc_dims = [enc_dims[0] + cond_dim] + list(enc_dims[1:])
     enc_out = list(enc_dims[1:])
     if variant == "vae":
         enc_out[-1] *= 2
@@ -67,12 +69,12 @@ def param_shapes(enc_dims, dec_dims, variant="vae"):
 
 
 def forward_backward(enc_dims, dec_dims, params, x, gt=None, training=False, mask=None, eps=None,
-                     beta=0.0, lam=0.0, inv_batch=None, variant="vae", dropout=0.5, want_grads=True):
+                     beta=0.0, lam=0.0, inv_batch=None, variant="vae", dropout=0.5, want_grads=True, cond_dim=0):
     """Returns dict(logits, mu, logvar, loss, grads).  params: list of float32 arrays (W0,b0,W1,b1..)."""
-    cfg = make_cfg(enc_dims, dec_dims, variant, dropout)
+    cfg = make_cfg(enc_dims, dec_dims, variant, dropout, cond_dim)
     params = [np.ascontiguousarray(p, dtype=np.float32) for p in params]
     x = np.ascontiguousarray(x, dtype=np.float32)
-    B, I = x.shape
+    B, I = x.shape[0], x.shape[1] - cond_dim
     Z = enc_dims[-1]
     gt_ = None if gt is None else np.ascontiguousarray(gt, dtype=np.float32)
     mask_ = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
@@ -93,11 +95,11 @@ def forward_backward(enc_dims, dec_dims, params, x, gt=None, training=False, mas
                 loss=loss.value, grads=grads)
 
 
-def predict(enc_dims, dec_dims, params, x, remove_train=True, variant="vae"):
-    cfg = make_cfg(enc_dims, dec_dims, variant, 0.0)
+def predict(enc_dims, dec_dims, params, x, remove_train=True, variant="vae", cond_dim=0):
+    cfg = make_cfg(enc_dims, dec_dims, variant, 0.0, cond_dim)
     params = [np.ascontiguousarray(p, dtype=np.float32) for p in params]
     x = np.ascontiguousarray(x, dtype=np.float32)
-    B, I = x.shape
+    B, I = x.shape[0], x.shape[1] - cond_dim
     Z = enc_dims[-1]
     logits = np.empty((B, I), np.float32)
     mu = np.empty((B, Z), np.float32)
@@ -136,8 +138,9 @@ class OracleTrainer:
     (reference models.py:817-835 / 424-447) with injected RNG.  Keeps params + Adam state."""
 
     def __init__(self, enc_dims, dec_dims, params, variant="vae", dropout=0.5, beta=1.0, anneal_steps=0,
-                 lam=0.2, lr=1e-3, weight_decay=None):
+                 lam=0.2, lr=1e-3, weight_decay=None, cond_dim=0):
         self.enc_dims, self.dec_dims, self.variant, self.dropout = list(enc_dims), list(dec_dims), variant, dropout
+        self.cond_dim = cond_dim
         self.params = [np.array(p, dtype=np.float32, copy=True) for p in params]
         self.m = [np.zeros_like(p) for p in self.params]
         self.v = [np.zeros_like(p) for p in self.params]
@@ -156,7 +159,7 @@ class OracleTrainer:
     def train_batch(self, x, gt=None, mask=None, eps=None, inv_batch=None):
         out = forward_backward(self.enc_dims, self.dec_dims, self.params, x, gt, True, mask, eps,
                                beta=self.anneal_beta(), lam=self.lam if self.variant == "dae" else 0.0,
-                               inv_batch=inv_batch, variant=self.variant, dropout=self.dropout)
+                               inv_batch=inv_batch, variant=self.variant, dropout=self.dropout, cond_dim=self.cond_dim)
         self.step += 1
         for p, g, m, v in zip(self.params, out["grads"], self.m, self.v):
             adam(p.reshape(-1), g.reshape(-1), m.reshape(-1), v.reshape(-1), self.step, self.lr,
@@ -166,4 +169,4 @@ class OracleTrainer:
         return out["loss"]
 
     def predict(self, x, remove_train=True):
-        return predict(self.enc_dims, self.dec_dims, self.params, x, remove_train, self.variant)
+        return predict(self.enc_dims, self.dec_dims, self.params, x, remove_train, self.variant, self.cond_dim)

@@ -17,7 +17,7 @@ static int build_layers(const orc_cfg* c, layer_t* L)
     if (c->n_enc < 1 || c->n_dec < 1 || c->n_enc > ORC_MAX_LAYERS || c->n_dec > ORC_MAX_LAYERS) return -1;
     int n = 0;
     for (int e = 0; e < c->n_enc; ++e, ++n) {
-        L[n].in = c->enc_dims[e];
+        L[n].in = c->enc_dims[e] + (e == 0 ? c->cond_dim : 0); /* CMultiVAE_net: temp_dims[0] += cond_dim (nets.py:459-460) */
         L[n].out = c->enc_dims[e + 1];
         L[n].tanh_act = 1;
         if (e == c->n_enc - 1 && c->variant == ORC_VAE) {
@@ -74,11 +74,15 @@ int orc_forward_backward(const orc_cfg* cfg, const float* const* params, const f
     const int Z = cfg->enc_dims[cfg->n_enc]; /* latent */
     if (cfg->dec_dims[0] != Z || cfg->dec_dims[cfg->n_dec] != I) return -1;
     const int vae = (cfg->variant == ORC_VAE);
-    if (!gt) gt = x;
+    const int Iin = I + cfg->cond_dim; /* CMultiVAE_net.encode (nets.py:467-471): x = [items | condition] */
+    if (!gt) {
+        if (cfg->cond_dim) return -1;  /* a conditioned row is not a valid target */
+        gt = x;
+    }
 
     /* activations: act[l] = input of layer l, act[NL] = logits.  For the VAE the decoder input is z. */
     double** act = (double**)calloc((size_t)NL + 1, sizeof(double*));
-    act[0] = (double*)malloc(sizeof(double) * (size_t)B * I);
+    act[0] = (double*)malloc(sizeof(double) * (size_t)B * Iin);
     /* F.normalize (nets.py:395 / 220): x / max(||x||_2, 1e-12); dropout (nets.py:396-397 / 221-222) */
     const double scale = (training && cfg->dropout_p > 0.f)
                              ? (cfg->dropout_p < 1.f ? 1.0 / (1.0 - (double)cfg->dropout_p) : 0.0)
@@ -86,17 +90,19 @@ int orc_forward_backward(const orc_cfg* cfg, const float* const* params, const f
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
         double ss = 0.0;
-        for (int i = 0; i < I; ++i) ss += (double)x[(long)b * I + i] * (double)x[(long)b * I + i];
+        for (int i = 0; i < I; ++i) ss += (double)x[(long)b * Iin + i] * (double)x[(long)b * Iin + i];
         double nrm = sqrt(ss);
         if (nrm < 1e-12) nrm = 1e-12;
         for (int i = 0; i < I; ++i) {
-            double v = (double)x[(long)b * I + i] / nrm;
+            double v = (double)x[(long)b * Iin + i] / nrm;
             if (training && cfg->dropout_p > 0.f) {
                 int keep = mask ? mask[(long)b * I + i] != 0 : 1;
                 v = keep ? v * scale : 0.0;
             }
-            act[0][(long)b * I + i] = v;
+            act[0][(long)b * Iin + i] = v;
         }
+        /* the condition columns are concatenated raw, after normalisation and dropout */
+        for (int i = I; i < Iin; ++i) act[0][(long)b * Iin + i] = (double)x[(long)b * Iin + i];
     }
     double* mu = NULL;      /* views into the last encoder output */
     double* h_enc = NULL;   /* raw output of the last encoder layer [B, out] */
@@ -255,14 +261,17 @@ int orc_forward_backward(const orc_cfg* cfg, const float* const* params, const f
 int orc_predict(const orc_cfg* cfg, const float* const* params, const float* x, int B, int remove_train,
                 float* logits, float* mu, float* logvar)
 {
-    int rc = orc_forward_backward(cfg, params, x, NULL, B, 0, NULL, NULL, 0.f, 0.f, 0.f, logits, mu, logvar,
-                                  NULL, NULL);
+    /* scoring reads no target: hand the input's item block as a placeholder when the rows are conditioned */
+    int rc = orc_forward_backward(cfg, params, x, cfg->cond_dim ? x : NULL, B, 0, NULL, NULL, 0.f, 0.f, 0.f, logits, mu,
+                                  logvar, NULL, NULL);
     if (rc) return rc;
     if (remove_train) {
         /* recon_x[x.nonzero()] = -inf   (models.py:623-624 / 471-472) */
-        const long n = (long)B * cfg->enc_dims[0];
-        for (long k = 0; k < n; ++k)
-            if (x[k] != 0.f) logits[k] = -INFINITY;
+        /* CMultiVAE.predict masks x[:, :-cond_dim].nonzero() only (models.py:952-953) */
+        const int I = cfg->enc_dims[0], Iin = I + cfg->cond_dim;
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < I; ++i)
+                if (x[(long)b * Iin + i] != 0.f) logits[(long)b * I + i] = -INFINITY;
     }
     return 0;
 }

@@ -27,7 +27,7 @@ class Cfg(C.Structure):
     _fields_ = [("n_enc", C.c_int32), ("n_dec", C.c_int32),
                 ("enc_dims", C.c_int32 * (MAX_LAYERS + 1)), ("dec_dims", C.c_int32 * (MAX_LAYERS + 1)),
                 ("variant", C.c_int32), ("numerics", C.c_int32), ("dropout_p", C.c_float),
-                ("max_batch", C.c_int32), ("splitk", C.c_int32)]
+                ("max_batch", C.c_int32), ("splitk", C.c_int32), ("cond_dim", C.c_int32)]
 
 
 class Batch(C.Structure):
@@ -120,7 +120,7 @@ def require_gpu():
                        "there is no CPU implementation of this path (the reference's CPU trainer is rectorch itself).")
 
 
-def make_cfg(enc_dims, dec_dims, variant, numerics, dropout, max_batch, splitk=0):
+def make_cfg(enc_dims, dec_dims, variant, numerics, dropout, max_batch, splitk=0, cond_dim=0):
     cfg = Cfg()
     if len(enc_dims) - 1 > MAX_LAYERS or len(dec_dims) - 1 > MAX_LAYERS:
         raise RtxError("at most %d layers per encoder/decoder are supported" % MAX_LAYERS)
@@ -134,6 +134,7 @@ def make_cfg(enc_dims, dec_dims, variant, numerics, dropout, max_batch, splitk=0
     cfg.dropout_p = float(dropout)
     cfg.max_batch = int(max_batch)
     cfg.splitk = int(splitk)
+    cfg.cond_dim = int(cond_dim)
     return cfg
 
 

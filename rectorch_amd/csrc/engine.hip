@@ -58,6 +58,7 @@ struct TempCsr {  // dense batch converted to CSR on the device
 struct rtx_engine {
     rtx_cfg cfg;
     int NL = 0, I = 0, Z = 0, Ip = 0, Zp = 0;
+    int Iin = 0;   // input columns = I + cfg.cond_dim
     int Bp_alloc = 0;
     bool bf16 = false, vae = false;
     size_t esz = 4;
@@ -112,10 +113,11 @@ static int build_layers(const rtx_cfg& c, std::vector<Layer>& L)
               c.enc_dims[c.n_enc], c.dec_dims[0]);
     RTX_CHECK(c.enc_dims[0] == c.dec_dims[c.n_dec], RTX_EINVAL, "n_items mismatch: enc %d vs dec %d", c.enc_dims[0],
               c.dec_dims[c.n_dec]);
+    RTX_CHECK(c.cond_dim >= 0, RTX_EINVAL, "negative cond_dim %d", c.cond_dim);
     L.clear();
     for (int i = 0; i < c.n_enc; ++i) {
         Layer l;
-        l.in = c.enc_dims[i];
+        l.in = c.enc_dims[i] + (i == 0 ? c.cond_dim : 0);   // CMultiVAE_net: temp_dims[0] += cond_dim (nets.py:459-460)
         l.out = c.enc_dims[i + 1];
         l.tanh_act = true;
         if (i == c.n_enc - 1 && c.variant == RTX_VAE) {  // mu | logvar, linear (reference nets.py:262-265, 398-404)
@@ -251,40 +253,44 @@ static int ensure_tmp(rtx_engine* e, TempCsr& t, int64_t nnz)
     return RTX_OK;
 }
 
-static int dense_to_view(rtx_engine* e, TempCsr& t, const float* x, int B, RtxCsrView* v, hipStream_t st)
+static int dense_to_view(rtx_engine* e, TempCsr& t, const float* x, int B, int width, RtxCsrView* v, hipStream_t st)
 {
     RTX_TRY(ensure_tmp(e, t, 0));
-    RTX_TRY(rtx_launch_dense_count(x, B, e->I, t.counts, st));
+    RTX_TRY(rtx_launch_dense_count(x, B, width, t.counts, st));
     RTX_TRY(rtx_launch_scan_counts(t.counts, B, t.indptr, st));
     int64_t nnz = 0;
     RTX_HIP(hipMemcpyAsync(&nnz, t.indptr + B, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     RTX_HIP(hipStreamSynchronize(st));  // dense drop-in path only; the CSR path never synchronises
     RTX_TRY(ensure_tmp(e, t, nnz));
-    RTX_TRY(rtx_launch_dense_fill(x, B, e->I, t.indptr, t.indices, t.values, st));
+    RTX_TRY(rtx_launch_dense_fill(x, B, width, t.indptr, t.indices, t.values, st));
     v->indptr = t.indptr; v->indices = t.indices; v->values = t.values; v->row_ids = nullptr;
     return RTX_OK;
 }
 
-static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxCsrView* tg, hipStream_t st)
+static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxCsrView* tg, hipStream_t st, int need_target = 1)
 {
     RTX_CHECK(b, RTX_EINVAL, "batch is NULL");
     RTX_CHECK(b->batch >= 1 && b->batch <= e->cfg.max_batch, RTX_EINVAL, "batch %d outside [1, max_batch=%d]", b->batch,
               e->cfg.max_batch);
     if (b->csr) {
-        RTX_CHECK(b->csr->n_cols == e->I, RTX_EINVAL, "CSR has %d columns, network expects %d items", b->csr->n_cols, e->I);
+        RTX_CHECK(b->csr->n_cols == e->Iin, RTX_EINVAL, "CSR has %d columns, network expects %d (items + conditions)", b->csr->n_cols,
+                  e->Iin);
         RTX_CHECK(b->row_ids || b->batch <= b->csr->n_rows, RTX_EINVAL, "batch larger than the matrix");
         in->indptr = b->csr->indptr; in->indices = b->csr->indices; in->values = b->csr->values; in->row_ids = b->row_ids;
     } else {
         RTX_CHECK(b->x_dense, RTX_EINVAL, "batch has neither csr nor x_dense");
-        RTX_TRY(dense_to_view(e, e->tmp_in, b->x_dense, b->batch, in, st));
+        RTX_TRY(dense_to_view(e, e->tmp_in, b->x_dense, b->batch, e->Iin, in, st));
     }
     if (b->target_csr) {
         RTX_CHECK(b->target_csr->n_cols == e->I, RTX_EINVAL, "target CSR has %d columns, expected %d", b->target_csr->n_cols, e->I);
         tg->indptr = b->target_csr->indptr; tg->indices = b->target_csr->indices; tg->values = b->target_csr->values;
         tg->row_ids = b->row_ids;
     } else if (b->target_dense) {
-        RTX_TRY(dense_to_view(e, e->tmp_tg, b->target_dense, b->batch, tg, st));
+        RTX_TRY(dense_to_view(e, e->tmp_tg, b->target_dense, b->batch, e->I, tg, st));
     } else {
+        // a conditioned input has cond_dim extra columns: it cannot be its own target.  Scoring calls (need_target = 0)
+        // never read the target beyond its row sums, which k_gather restricts to the item columns.
+        RTX_CHECK(e->Iin == e->I || !need_target, RTX_EINVAL, "a conditioned network (cond_dim = %d) needs an explicit target", e->Iin - e->I);
         *tg = *in;
     }
     return RTX_OK;
@@ -307,7 +313,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
         }
         RtxGatherArgs a = {};
         a.in = *in; a.target = *tg;
-        a.B = B; a.Bp = Bp; a.I = e->I; a.ldx = l.inp; a.ldt = ldt;
+        a.B = B; a.Bp = Bp; a.I = e->I; a.Iin = e->Iin; a.ldx = l.inp; a.ldt = ldt;
         a.X = l.A; a.XT = need_T ? l.AT : nullptr; a.tsum = e->tsum;
         a.training = training; a.dropout_p = e->cfg.dropout_p;
         a.mask = step->dropout_mask; a.seed = step->seed; a.offset = step->offset;
@@ -442,7 +448,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 1; }
+int32_t rtx_abi_version(void) { return 2; }   // 2: rtx_cfg.cond_dim, rtx_ease_*
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -514,6 +520,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     if (rc) { delete e; return rc; }
     e->NL = (int)e->L.size();
     e->I = cfg->enc_dims[0];
+    e->Iin = e->I + cfg->cond_dim;
     e->Z = cfg->enc_dims[cfg->n_enc];
     e->Ip = rtx_pad(e->I);
     e->Zp = rtx_pad(e->Z);
@@ -645,11 +652,11 @@ int rtx_engine_forward(rtx_engine* e, const rtx_batch* batch, int32_t training, 
     hipStream_t st = (hipStream_t)stream;
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
-    RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
+    RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
     RTX_TRY(run_forward(e, &in, &in, batch->batch, training, step, 0, 0, e->NL, logits, e->I, mu, logvar, st));
     if (remove_train) {
         TIMED("neg_inf");
-        RTX_TRY(rtx_launch_neg_inf(in, batch->batch, logits, e->I, st));
+        RTX_TRY(rtx_launch_neg_inf(in, batch->batch, logits, e->I, e->I, st));
     }
     return RTX_OK;
 }
@@ -662,7 +669,7 @@ int rtx_engine_encode(rtx_engine* e, const rtx_batch* batch, int32_t training, c
     hipStream_t st = (hipStream_t)stream;
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
-    RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
+    RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
     const int ne = e->cfg.n_enc;
     RTX_TRY(run_forward(e, &in, &in, batch->batch, training, step, 0, 0, ne, nullptr, 0, out0, out1, st));
     if (!e->vae) {

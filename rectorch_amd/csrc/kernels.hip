@@ -61,11 +61,13 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
     }
     const int64_t u = csr_row(a.in, b);
     const int64_t beg = a.in.indptr[u], end = a.in.indptr[u + 1];
-    // ||x||_2 over the stored entries (F.normalize: x / max(||x||, 1e-12))
+    // ||x||_2 over the stored entries (F.normalize: x / max(||x||, 1e-12)); a conditioned row (Iin > I) is normalised
+    // over its item columns only (CMultiVAE_net.encode, reference nets.py:467-471)
+    const bool cond = a.Iin > a.I;
     float ss = 0.f;
     for (int64_t k = beg + tid; k < end; k += 256) {
         const float v = a.in.values ? a.in.values[k] : 1.f;
-        ss += v * v;
+        if (!cond || a.in.indices[k] < a.I) ss += v * v;
     }
     ss = block_sum(ss, red);
     const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
         const int64_t ut = csr_row(a.target, b);
         const int64_t tb = a.target.indptr[ut], te = a.target.indptr[ut + 1];
         float ts = 0.f;
-        for (int64_t k = tb + tid; k < te; k += 256) ts += a.target.values ? a.target.values[k] : 1.f;
+        for (int64_t k = tb + tid; k < te; k += 256)
+            if (!cond || a.target.indices[k] < a.I) ts += a.target.values ? a.target.values[k] : 1.f;
         ts = block_sum(ts, red);
         if (tid == 0) a.tsum[b] = ts;
     }
@@ -87,8 +90,9 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
         for (int64_t k = beg + tid; k < end; k += 256) {
             const int i = a.in.indices[k];
             if (i >= c0 && i < c0 + cn) {
-                float v = (a.in.values ? a.in.values[k] : 1.f) * inv;
-                if (drop) {
+                float v = a.in.values ? a.in.values[k] : 1.f;
+                if (i < a.I) v *= inv;
+                if (drop && i < a.I) {   // condition columns are concatenated after the dropout (nets.py:469-471)
                     const uint64_t e = (uint64_t)b * (uint64_t)a.I + (uint64_t)i;
                     const bool keep = a.mask ? (a.mask[e] != 0) : rtx_dropout_keep(a.seed, a.offset, e, a.dropout_p);
                     v = keep ? v * scale : 0.f;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
         }
         __syncthreads();
     }
-    if (XT && tid == 0) XT[(size_t)a.I * a.ldt + b] = Elem<T>::from(1.f);  // ones row -> bias gradient
+    if (XT && tid == 0) XT[(size_t)a.Iin * a.ldt + b] = Elem<T>::from(1.f);  // ones row -> bias gradient
 }
 
 int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream)
@@ -521,20 +525,23 @@ int rtx_launch_target_fixup(const RtxCsrView& target, int B, float inv_batch, vo
     return RTX_OK;
 }
 
-__global__ __launch_bounds__(256) void k_neg_inf(const RtxCsrView v, float* logits, long ld)
+// n_items bounds the masked columns: a conditioned input row carries its condition columns after the items
+// (CMultiVAE.predict masks x[:, :-cond_dim].nonzero() only, reference models.py:952-953)
+__global__ __launch_bounds__(256) void k_neg_inf(const RtxCsrView v, float* logits, long ld, int n_items)
 {
     const int b = blockIdx.x;
     const int64_t u = csr_row(v, b);
     for (int64_t k = v.indptr[u] + threadIdx.x; k < v.indptr[u + 1]; k += 256) {
         const float val = v.values ? v.values[k] : 1.f;
-        if (val != 0.f) logits[(size_t)b * ld + v.indices[k]] = -INFINITY;
+        const int i = v.indices[k];
+        if (val != 0.f && i < n_items) logits[(size_t)b * ld + i] = -INFINITY;
     }
 }
 
-int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, hipStream_t stream)
+int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, int n_items, hipStream_t stream)
 {
     if (B <= 0) return RTX_OK;
-    hipLaunchKernelGGL(k_neg_inf, dim3(B), dim3(256), 0, stream, in, logits, ld);
+    hipLaunchKernelGGL(k_neg_inf, dim3(B), dim3(256), 0, stream, in, logits, ld, n_items);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

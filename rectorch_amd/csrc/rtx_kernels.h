@@ -29,6 +29,7 @@ struct rtx_csr {
 struct RtxGatherArgs {
     RtxCsrView in, target;
     int B, Bp, I, ldx, ldt;
+    int Iin;              // input columns (= I, or I + cond_dim: trailing condition columns stay raw)
     void* X;
     void* XT;
     float* tsum;
@@ -127,7 +128,7 @@ int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float*
 int rtx_launch_target_fixup(const RtxCsrView& target, int B, float inv_batch, void* D, int ldd, void* DT, int ldt,
                             int is_bf16, hipStream_t stream);
 // predict(): logits[b][i] = -inf where the input has a stored non-zero
-int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, hipStream_t stream);
+int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, int n_items, hipStream_t stream);
 // public loss_function on dense tensors: row_loss[b] = s*lse - <x,y>  (+ beta * KL_b)
 int rtx_launch_dense_loss(const float* Y, const float* X, int B, int I, const float* mu, const float* lv, int Z,
                           float beta, float inv_batch, float* row_loss, hipStream_t stream);

@@ -80,7 +80,7 @@ def _check_width(t, n_items, what):
         raise _lib.RtxError("%s must be [batch, %d] (n_items of the network), got %s" % (what, n_items, tuple(t.shape)))
 
 
-def make_batch(x, target=None, keep=None, n_items=None):
+def make_batch(x, target=None, keep=None, n_items=None, n_in=None):
     """Build the C ``rtx_batch`` for ``x`` (a RowBatch, or a dense [B, n_items] device tensor, or a dense
     tensor carrying the RowBatch it was gathered from).  ``keep`` collects tensors that must outlive the call."""
     b = Batch()
@@ -92,7 +92,7 @@ def make_batch(x, target=None, keep=None, n_items=None):
         if target is None and rb.te is not None and isinstance(x, RowBatch) and x.te is not None:
             b.target_csr = rb.te.handle
     else:
-        _check_width(x, n_items, "the input batch")
+        _check_width(x, n_in if n_in is not None else n_items, "the input batch")
         x = x.to(torch.float32).contiguous()
         if keep is not None:
             keep.append(x)
@@ -124,13 +124,15 @@ class Engine:
     master parameters (the nn.Parameters themselves) and, for training, to gradient buffers and the Adam
     moments held in ``torch.optim.Adam``'s state."""
 
-    def __init__(self, enc_dims, dec_dims, variant, dropout, numerics="bf16", max_batch=512, splitk=0):
+    def __init__(self, enc_dims, dec_dims, variant, dropout, numerics="bf16", max_batch=512, splitk=0, cond_dim=0):
         _lib.require_gpu()
         self.enc_dims, self.dec_dims = [int(d) for d in enc_dims], [int(d) for d in dec_dims]
         self.variant, self.numerics = variant, numerics
         self.max_batch = int(max_batch)
         self.n_items, self.latent = self.enc_dims[0], self.enc_dims[-1]
-        cfg = _lib.make_cfg(self.enc_dims, self.dec_dims, variant, numerics, dropout, max_batch, splitk)
+        self.cond_dim = int(cond_dim)
+        self.n_in = self.n_items + self.cond_dim      # input columns: items, then the condition one-hot (CMultiVAE)
+        cfg = _lib.make_cfg(self.enc_dims, self.dec_dims, variant, numerics, dropout, max_batch, splitk, cond_dim)
         h = C.c_void_p()
         check(lib().rtx_engine_create(C.byref(cfg), C.byref(h)))
         self.handle = h
@@ -177,7 +179,7 @@ class Engine:
 
     def forward(self, x, training=False, remove_train=False, seed=0, offset=0, mask=None, noise=None):
         keep = []
-        b = make_batch(x, keep=keep, n_items=self.n_items)
+        b = make_batch(x, keep=keep, n_items=self.n_items, n_in=self.n_in)
         dev = torch.device("cuda", torch.cuda.current_device())
         logits = torch.empty((b.batch, self.n_items), dtype=torch.float32, device=dev)
         mu = logvar = None
@@ -191,7 +193,7 @@ class Engine:
 
     def encode(self, x, training=False, seed=0, offset=0, mask=None):
         keep = []
-        b = make_batch(x, keep=keep, n_items=self.n_items)
+        b = make_batch(x, keep=keep, n_items=self.n_items, n_in=self.n_in)
         dev = torch.device("cuda", torch.cuda.current_device())
         o0 = torch.empty((b.batch, self.latent), dtype=torch.float32, device=dev)
         o1 = torch.empty_like(o0) if self.variant == "vae" else None
@@ -209,7 +211,7 @@ class Engine:
     # ---- training ---------------------------------------------------------------------------------
     def loss_grads(self, x, target, step, loss_out, loss_accum=None, layer_cb=None):
         keep = []
-        b = make_batch(x, target, keep=keep, n_items=self.n_items)
+        b = make_batch(x, target, keep=keep, n_items=self.n_items, n_in=self.n_in)
         cb = _lib.LAYER_CB(layer_cb) if layer_cb is not None else _lib.LAYER_CB()
         check(lib().rtx_engine_loss_grads(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           cb, None, stream_ptr()))
@@ -219,7 +221,7 @@ class Engine:
 
     def train_step(self, x, target, step, loss_out, loss_accum=None):
         keep = []
-        b = make_batch(x, target, keep=keep, n_items=self.n_items)
+        b = make_batch(x, target, keep=keep, n_items=self.n_items, n_in=self.n_in)
         check(lib().rtx_engine_train_step(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           stream_ptr()))
 

@@ -23,7 +23,7 @@ from .engine import CsrMatrix, EaseSolver, RowBatch, multinomial_loss
 from .evaluation import ValidFunc, evaluate
 from .samplers import DataSampler
 
-__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE', 'EASE']
+__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE', 'CMultiVAE', 'EASE']
 
 logger = logging.getLogger(__name__)
 
@@ -499,6 +499,32 @@ class MultiVAE(VAE):
         checkpoint = super().load_model(filepath)
         self.gradient_updates = checkpoint['gradient_updates']
         return checkpoint
+
+
+class CMultiVAE(MultiVAE):
+    r"""Conditioned Variational Autoencoder for collaborative filtering (reference models.py:911-956).
+
+    Same training procedure as :class:`MultiVAE`; the network is a :class:`rectorch_amd.nets.CMultiVAE_net` and the
+    sampler a :class:`rectorch_amd.samplers.ConditionedDataSampler`, whose batches are ``[items | condition]`` rows
+    with the condition-filtered rows as loss target.  ``predict`` masks the *item* columns of ``x`` only
+    (``x[:, :-cond_dim].nonzero()``, reference models.py:952-953) -- the engine bounds the mask at ``n_items``.
+    """
+    def __init__(self,
+                 cmvae_net,
+                 beta=1.,
+                 anneal_steps=0,
+                 learning_rate=1e-3,
+                 numerics="bf16",
+                 predict_numerics="fp32"):
+        super(CMultiVAE, self).__init__(cmvae_net,
+                                        beta=beta,
+                                        anneal_steps=anneal_steps,
+                                        learning_rate=learning_rate,
+                                        numerics=numerics,
+                                        predict_numerics=predict_numerics)
+
+    def predict(self, x, remove_train=True):
+        return self._predict_tuple(x, remove_train)
 
 
 class EASE(RecSysModel):

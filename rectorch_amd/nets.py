@@ -95,7 +95,8 @@ class AE_net(nn.Module):
         eng = self._rtx_engines.get(numerics)
         if eng is None or eng.max_batch < max_batch:
             mb = max(max_batch, DEFAULT_MAX_BATCH if eng is None else eng.max_batch)
-            eng = Engine(self.enc_dims, self.dec_dims, self._variant, self.dropout.p, numerics, mb)
+            eng = Engine(self.enc_dims, self.dec_dims, self._variant, self.dropout.p, numerics, mb,
+                         cond_dim=getattr(self, "cond_dim", 0))
             self._rtx_engines[numerics] = eng
             self._rtx_shadow_versions.pop(numerics, None)
         params = [p.data for p in self._param_list()]
@@ -233,3 +234,26 @@ class MultiVAE_net(VAE_net):
         x = self._as_input(x)
         eng = self.rtx_engine("fp32", x.shape[0])
         return eng.forward(x, training=self.training, seed=draw_seed() if self.training else 0)
+
+
+class CMultiVAE_net(MultiVAE_net):
+    r"""Conditioned Variational Autoencoder network for collaborative filtering (reference nets.py:420-480).
+
+    The input rows are ``[items | condition one-hot]``: the item part is L2-normalised and dropped out, the
+    ``cond_dim`` condition columns are concatenated raw, so the first encoder layer is
+    ``Linear(n_items + cond_dim, ...)``.  On the device this is the same engine with ``rtx_cfg.cond_dim`` set: the
+    gather kernel leaves the trailing columns unscaled and the first GEMM simply has a longer K.
+    """
+
+    def __init__(self, cond_dim, dec_dims, enc_dims=None, dropout=0.5):
+        super(CMultiVAE_net, self).__init__(dec_dims, enc_dims, dropout)
+        self.cond_dim = cond_dim
+
+        temp_dims = self.enc_dims[:-1] + [self.enc_dims[-1] * 2]
+        temp_dims[0] += self.cond_dim
+        self.enc_layers = nn.ModuleList(
+            [nn.Linear(d_in, d_out) for d_in, d_out in zip(temp_dims[:-1], temp_dims[1:])])
+
+        self.dec_layers = nn.ModuleList(
+            [nn.Linear(d_in, d_out) for d_in, d_out in zip(self.dec_dims[:-1], self.dec_dims[1:])])
+        self.init_weights()

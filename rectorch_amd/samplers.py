@@ -9,10 +9,12 @@ device; ``iter_rows()`` yields only row numbers for trainers that take the spars
 """
 import numpy as np
 import torch
+from scipy.sparse import csr_matrix, hstack
 
 from .engine import CsrMatrix, RowBatch
 
-__all__ = ['Sampler', 'DataSampler']
+__all__ = ['Sampler', 'DataSampler', 'ConditionedDataSampler', 'BalancedConditionedDataSampler',
+           'EmptyConditionedDataSampler']
 
 
 class Sampler():
@@ -79,7 +81,9 @@ class DataSampler(Sampler):
         if self._src[1] is not self.sparse_data_te:
             self._csr_te = None if self.sparse_data_te is None else CsrMatrix(self.sparse_data_te)
             if self._csr_te is not None:
-                assert self._csr_te.shape == self._csr_tr.shape, "tr and te matrices must have the same shape"
+                # same users; a conditioned input matrix carries its condition columns after the items (CMultiVAE)
+            assert self._csr_te.shape[0] == self._csr_tr.shape[0] and self._csr_te.shape[1] <= self._csr_tr.shape[1], \
+                "tr and te matrices must have the same shape"
         self._src = (self.sparse_data_tr, self.sparse_data_te)
 
     def _order(self):
@@ -124,3 +128,205 @@ class DataSampler(Sampler):
                 data_te = self.sparse_data_te[idxlist[start_idx:end_idx]]
                 data_te = torch.FloatTensor(data_te.toarray())
             yield data_tr, data_te
+
+
+class ConditionedDataSampler(Sampler):
+    r"""Data sampler with conditioned filtering for :class:`rectorch_amd.models.CMultiVAE` (reference
+    samplers.py:108-234).
+
+    Every user appears once unconditioned -- example ``(row, -1)`` -- and once per condition known to at least one of
+    the user's items -- ``(row, c)``.  A batch is the examples' training rows with the ``n_cond`` one-hot condition
+    columns appended, and as target the test rows restricted to the items valid under the example's condition (all
+    items having any condition when unconditioned); examples whose filtered target is empty are dropped.
+
+    This is host-side bookkeeping, as in the reference; the batches it yields are what the MI355X engine consumes.
+    With ``sparse=True`` (not in the reference) the pair is yielded as a :class:`rectorch_amd.engine.RowBatch` of two
+    small per-batch CSR matrices uploaded to HBM, so nothing dense of width ``n_items`` crosses PCIe.
+
+    Parameters
+    ----------
+    iid2cids : :obj:`dict` (key :obj:`int` - value :obj:`list` of :obj:`int`)
+        Maps each item (inner id) to the list of its valid conditions (integers in ``[0, n_cond)``).
+    n_cond : :obj:`int`
+        Number of possible conditions.
+    sparse_data_tr : :obj:`scipy.sparse.csr_matrix`
+        The training sparse user-item rating matrix.
+    sparse_data_te : :obj:`scipy.sparse.csr_matrix` [optional]
+        The test sparse user-item rating matrix (same shape), by default :obj:`None` (= the training matrix).
+    batch_size : :obj:`int` [optional]
+        The size of the batches, by default 1.
+    shuffle : :obj:`bool` [optional]
+        Whether the examples are shuffled (global numpy RNG, as in the reference) before batching, by default ``True``.
+    """
+    def __init__(self,
+                 iid2cids,
+                 n_cond,
+                 sparse_data_tr,
+                 sparse_data_te=None,
+                 batch_size=1,
+                 shuffle=True,
+                 sparse=False):
+        super(ConditionedDataSampler, self).__init__()
+        self.sparse_data_tr = sparse_data_tr
+        self.sparse_data_te = sparse_data_te
+        self.iid2cids = iid2cids
+        self.batch_size = batch_size
+        self.n_cond = n_cond
+        self.shuffle = shuffle
+        self.sparse = sparse
+        self._compute_conditions()
+
+    def _row_conditions(self):
+        """row -> the set of conditions of the row's items.  Built as a union of per-item sets in column order so that
+        iterating it visits the conditions in the order the reference's own sets do (samplers.py:171-174)."""
+        tr = self.sparse_data_tr.tocsr()
+        out = {}
+        for r in range(tr.shape[0]):
+            cols = tr.indices[tr.indptr[r]:tr.indptr[r + 1]][tr.data[tr.indptr[r]:tr.indptr[r + 1]] != 0]
+            out[r] = set.union(*[set(self.iid2cids[c]) for c in np.sort(cols)])
+        return out
+
+    def _item_condition_matrix(self):
+        items = list(self.iid2cids)
+        rows = np.repeat(items, [len(self.iid2cids[m]) for m in items]).astype(np.int64)
+        cols = np.array([g for m in items for g in self.iid2cids[m]], dtype=np.int64)
+        return csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(len(self.iid2cids), self.n_cond))
+
+    def _compute_conditions(self):
+        r2cond = self._row_conditions()
+        ex = [(r, -1) for r in r2cond]
+        ex += [(r, c) for r in r2cond for c in r2cond[r]]
+        self.examples = np.array(ex)
+        self.M = self._item_condition_matrix()
+
+    def __len__(self):
+        return int(np.ceil(len(self.examples) / self.batch_size))
+
+    def _batch(self, ex):
+        """(input rows [b, n_items + n_cond], filtered target rows [b, n_items]) as scipy CSR, empty targets dropped"""
+        n = len(ex)
+        rows_, conds = ex[:, 0], ex[:, 1]
+        has = conds >= 0
+        onehot = csr_matrix((np.ones(int(has.sum())), (np.nonzero(has)[0], conds[has])), shape=(n, self.n_cond))
+        data_tr = hstack([self.sparse_data_tr[rows_], onehot], format="csr")
+        if self.sparse_data_te is None:
+            self.sparse_data_te = self.sparse_data_tr
+        # an unconditioned example admits every condition
+        allow = onehot.tolil()
+        allow[np.nonzero(~has)[0], :] = 1
+        filtered = allow.tocsr().dot(self.M.transpose().tocsr()) > 0
+        data_te = self.sparse_data_te[rows_].multiply(filtered).tocsr()
+        keep = np.diff(data_te.indptr) != 0
+        return data_tr[keep], data_te[keep]
+
+    def _emit(self, data_tr, data_te):
+        if self.sparse:
+            tr, te = CsrMatrix(data_tr), CsrMatrix(data_te)
+            return RowBatch(tr, te, torch.arange(data_tr.shape[0], dtype=torch.int32, device="cuda"))
+        return torch.FloatTensor(data_tr.toarray()), torch.FloatTensor(data_te.toarray())
+
+    def __iter__(self):
+        n = len(self.examples)
+        idxlist = list(range(n))
+        if self.shuffle:
+            np.random.shuffle(idxlist)
+        for start_idx in range(0, n, self.batch_size):
+            end_idx = min(start_idx + self.batch_size, n)
+            data_tr, data_te = self._batch(self.examples[idxlist[start_idx:end_idx]])
+            yield self._emit(data_tr, data_te)
+
+
+class BalancedConditionedDataSampler(ConditionedDataSampler):
+    r"""Sub-sampled version of :class:`ConditionedDataSampler` (reference samplers.py:237-338): every user once
+    unconditioned, plus for each condition *c* ``m = int(num_cond_examples * subsample / n_cond)`` users drawn with
+    replacement (``np.random.choice``) among those knowing *c*.
+
+    Parameters
+    ----------
+    subsample : :obj:`float` [optional]
+        Fraction of the conditioned examples to keep, in (0, 1], by default 0.2.
+    (the others as in :class:`ConditionedDataSampler`; there is no ``shuffle`` argument, as in the reference)
+    """
+    def __init__(self,
+                 iid2cids,
+                 n_cond,
+                 sparse_data_tr,
+                 sparse_data_te=None,
+                 batch_size=1,
+                 subsample=.2,
+                 sparse=False):
+        super(BalancedConditionedDataSampler, self).__init__(iid2cids,
+                                                             n_cond,
+                                                             sparse_data_tr,
+                                                             sparse_data_te,
+                                                             batch_size,
+                                                             sparse=sparse)
+        self.subsample = subsample
+        self._compute_sampled_conditions()
+
+    def _compute_conditions(self):
+        r2cond = self._row_conditions()
+        self.examples = {-1: list(r2cond.keys())}
+        for c in range(self.n_cond):
+            self.examples[c] = [r for r in r2cond if c in r2cond[r]]
+        self.num_cond_examples = sum(len(self.examples[c]) for c in range(self.n_cond))
+        self.M = self._item_condition_matrix()
+
+    def _compute_sampled_conditions(self):
+        data = [(r, -1) for r in self.examples[-1]]
+        m = int(self.num_cond_examples * self.subsample / self.n_cond)
+        for c in range(self.n_cond):
+            data += [(r, c) for r in np.random.choice(self.examples[c], m)]
+        self.examples = np.array(data)
+
+    def __len__(self):
+        m = int(self.num_cond_examples * self.subsample) + self.sparse_data_tr.shape[0]
+        return int(np.ceil(m / self.batch_size))
+
+
+class EmptyConditionedDataSampler(Sampler):
+    r"""Unconditioned batches for :class:`rectorch_amd.models.CMultiVAE` (reference samplers.py:341-419): like
+    :class:`DataSampler`, with ``cond_size`` zero columns appended to the input rows.
+
+    Parameters
+    ----------
+    cond_size : :obj:`int`
+        Number of possible conditions.
+    sparse_data_tr, sparse_data_te, batch_size, shuffle
+        As in :class:`DataSampler`.
+    """
+    def __init__(self,
+                 cond_size,
+                 sparse_data_tr,
+                 sparse_data_te=None,
+                 batch_size=1,
+                 shuffle=True,
+                 sparse=False):
+        super(EmptyConditionedDataSampler, self).__init__()
+        self.sparse_data_tr = sparse_data_tr
+        self.sparse_data_te = sparse_data_te
+        self.batch_size = batch_size
+        self.cond_size = cond_size
+        self.shuffle = shuffle
+        self.sparse = sparse
+
+    def __len__(self):
+        return int(np.ceil(self.sparse_data_tr.shape[0] / self.batch_size))
+
+    def __iter__(self):
+        n = self.sparse_data_tr.shape[0]
+        idxlist = list(range(n))
+        if self.shuffle:
+            np.random.shuffle(idxlist)
+        for start_idx in range(0, n, self.batch_size):
+            rows = idxlist[start_idx:min(start_idx + self.batch_size, n)]
+            data_tr = self.sparse_data_tr[rows]
+            data_tr = hstack([data_tr, csr_matrix((data_tr.shape[0], self.cond_size))], format="csr")
+            if self.sparse_data_te is None:
+                self.sparse_data_te = self.sparse_data_tr
+            data_te = self.sparse_data_te[rows]
+            if self.sparse:
+                yield RowBatch(CsrMatrix(data_tr), CsrMatrix(data_te),
+                               torch.arange(len(rows), dtype=torch.int32, device="cuda"))
+            else:
+                yield torch.FloatTensor(data_tr.toarray()), torch.FloatTensor(data_te.toarray())

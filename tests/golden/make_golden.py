@@ -26,9 +26,10 @@ import torch                             # noqa: E402
 import torch.nn.functional as F          # noqa: E402
 from scipy.sparse import csr_matrix      # noqa: E402
 
-from rectorch.nets import MultiVAE_net, MultiDAE_net            # noqa: E402
-from rectorch.models import MultiVAE, MultiDAE, EASE            # noqa: E402
-from rectorch.samplers import DataSampler                       # noqa: E402
+from rectorch.nets import MultiVAE_net, MultiDAE_net, CMultiVAE_net  # noqa: E402
+from rectorch.models import MultiVAE, MultiDAE, EASE, CMultiVAE  # noqa: E402
+from rectorch.samplers import DataSampler, ConditionedDataSampler, BalancedConditionedDataSampler, \
+    EmptyConditionedDataSampler                                 # noqa: E402
 from rectorch.evaluation import evaluate                        # noqa: E402
 from rectorch.metrics import Metrics                            # noqa: E402
 
@@ -108,11 +109,16 @@ def g1_g7():
 
 # ---------------------------------------------------------------- G2
 def train_steps_vae(name, enc_dims, dec_dims, B, xs, gts, beta, anneal_steps, p, seeds, hseed,
-                    lr=1e-3, extra=None):
+                    lr=1e-3, extra=None, cond_dim=0):
     I, L = enc_dims[0], enc_dims[-1]
-    net = MultiVAE_net(list(dec_dims), list(enc_dims), dropout=p)
-    sd0 = load_hash(net, enc_dims, dec_dims, "vae", hseed)
-    model = MultiVAE(net, beta=beta, anneal_steps=anneal_steps, learning_rate=lr)
+    if cond_dim:
+        net = CMultiVAE_net(cond_dim, list(dec_dims), list(enc_dims), dropout=p)
+        sd0 = load_hash(net, [I + cond_dim] + list(enc_dims[1:]), dec_dims, "vae", hseed)
+        model = CMultiVAE(net, beta=beta, anneal_steps=anneal_steps, learning_rate=lr)
+    else:
+        net = MultiVAE_net(list(dec_dims), list(enc_dims), dropout=p)
+        sd0 = load_hash(net, enc_dims, dec_dims, "vae", hseed)
+        model = MultiVAE(net, beta=beta, anneal_steps=anneal_steps, learning_rate=lr)
     out = dict(flat("sd0__", sd0))
     names = [k for k, _ in net.named_parameters()]
     for t, seed in enumerate(seeds):
@@ -411,7 +417,77 @@ def g10():
     save("g10_ease_ratings", X=Xb, lam=np.float64(50.), model=ease.model)
 
 
+def g11():
+    """CMultiVAE (reference nets.py:420-480, models.py:911-956) and the conditioned samplers (samplers.py:108-419)."""
+    I, C, H, L, B = 64, 4, 16, 8, 6
+    rng = np.random.default_rng(11)
+    # (a) eval forward + predict
+    net = CMultiVAE_net(C, [L, H, I], dropout=0.5)
+    sd = load_hash(net, [I + C, H, L], [L, H, I], "vae", 21)
+    x = small_x(B, I, 5)
+    cond = np.zeros((B, C), dtype=np.float32)
+    cond[0, 1] = cond[3, 0] = cond[4, 3] = cond[2, 2] = 1.0        # rows 1 and 5 unconditioned
+    xc = np.concatenate([x, cond], axis=1)
+    model = CMultiVAE(net, beta=0.3)
+    net.eval()
+    with torch.no_grad():
+        y, mu, logvar = net(torch.from_numpy(xc))
+    pred = model.predict(torch.from_numpy(xc), remove_train=True)[0].numpy()
+    save("g11_cmvae_fwd_eval", x=xc, logits=y.numpy(), mu=mu.numpy(), logvar=logvar.numpy(), pred=pred,
+         dims=np.array([I, H, L]), cond_dim=np.int64(C), **flat("sd__", sd))
+    # (b) three training steps with annealing, filtered targets
+    xs, gts = [], []
+    for t in range(3):
+        xi = small_x(B, I, 30 + t)
+        ci = np.zeros((B, C), dtype=np.float32)
+        ci[np.arange(B), rng.integers(0, C, size=B)] = 1.0
+        ci[t, :] = 0.0
+        gi = xi * (rng.random((B, I)) < 0.7)
+        gi[0, 5] = 1.0
+        xs.append(np.concatenate([xi, ci], axis=1))
+        gts.append(gi.astype(np.float32))
+    train_steps_vae("g11_cmvae_train_steps", [I, H, L], [L, H, I], B, xs, gts, beta=0.3, anneal_steps=2, p=0.5,
+                    seeds=[41, 42, 43], hseed=22, cond_dim=C)
+    # (c) samplers
+    U, NI, NC = 23, 17, 5
+    tr = csr_matrix((rng.random((U, NI)) < 0.25).astype(np.float64))
+    for u in range(U):
+        if tr[u].nnz == 0:
+            tr[u, u % NI] = 1.0
+    tr = csr_matrix(tr)
+    te = csr_matrix((rng.random((U, NI)) < 0.3).astype(np.float64))
+    iid2cids = {i: sorted(set(rng.integers(0, NC, size=1 + i % 3).tolist())) for i in range(NI)}
+    out = {"tr": tr.toarray(), "te": te.toarray(), "n_cond": np.int64(NC),
+           "iid2cids_items": np.array([i for i in iid2cids for _ in iid2cids[i]]),
+           "iid2cids_conds": np.array([c for i in iid2cids for c in iid2cids[i]])}
+    s0 = ConditionedDataSampler(iid2cids, NC, tr, te, batch_size=7, shuffle=False)
+    out["cds_examples"] = s0.examples.copy()
+    out["cds_len"] = np.int64(len(s0))
+    np.random.seed(5)
+    s1 = ConditionedDataSampler(iid2cids, NC, tr, te, batch_size=7, shuffle=True)
+    for i, (a, b) in enumerate(s1):
+        out["cds_tr_%d" % i] = a.numpy()
+        out["cds_te_%d" % i] = b.numpy()
+    out["cds_n_batches"] = np.int64(i + 1)
+    np.random.seed(6)
+    s2 = BalancedConditionedDataSampler(iid2cids, NC, tr, None, batch_size=9, subsample=0.3)
+    out["bal_examples"] = s2.examples.copy()
+    out["bal_len"] = np.int64(len(s2))
+    np.random.seed(7)
+    for i, (a, b) in enumerate(s2):
+        out["bal_tr_%d" % i] = a.numpy()
+        out["bal_te_%d" % i] = b.numpy()
+    out["bal_n_batches"] = np.int64(i + 1)
+    np.random.seed(8)
+    s3 = EmptyConditionedDataSampler(NC, tr, te, batch_size=10, shuffle=True)
+    for i, (a, b) in enumerate(s3):
+        out["emp_tr_%d" % i] = a.numpy()
+        out["emp_te_%d" % i] = b.numpy()
+    out["emp_n_batches"] = np.int64(i + 1)
+    save("g11_conditioned_samplers", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
     for w in which:
-        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10}[w]()
+        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11}[w]()

@@ -29,13 +29,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, "declared in include/*.h but not exported: %s" % missing
     # the ctypes signature table covers exactly the declared symbols
     assert set(_lib.SIGNATURES) == syms
-    assert _lib.lib().rtx_abi_version() == 1
+    assert _lib.lib().rtx_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     from rectorch_amd import _lib
-    # int32 x2, int32[9] x2, int32 x2, float, int32 x2 = 25 * 4 bytes
-    assert ctypes.sizeof(_lib.Cfg) == 25 * 4
+    # int32 x2, int32[9] x2, int32 x2, float, int32 x3 (max_batch, splitk, cond_dim) = 26 * 4 bytes
+    assert ctypes.sizeof(_lib.Cfg) == 26 * 4
     assert ctypes.sizeof(_lib.Batch) == 5 * 8 + 8
     # 8 floats, int32, pad to 8, 2 x u64, 2 x ptr
     assert ctypes.sizeof(_lib.Step) == 8 * 4 + 8 + 16 + 16

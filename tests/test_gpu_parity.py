@@ -691,3 +691,77 @@ def test_ease_integer_valued_gram_paths(vmax, U, I):
     B = EaseSolver(csr_matrix(X), 30.0).weights().cpu().numpy()
     Bo = ease_fit(X, 30.0)
     assert np.max(np.abs(B - Bo)) <= 1e-10 * max(1.0, np.max(np.abs(Bo)))
+
+
+# ------------------------------------------------------------------------------------------------ CMultiVAE
+def make_cvae(cond, enc, dec, p, sd, **kw):
+    from rectorch_amd.nets import CMultiVAE_net
+    from rectorch_amd.models import CMultiVAE
+    net = CMultiVAE_net(cond, list(dec), list(enc), dropout=p)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return net, CMultiVAE(net, **kw)
+
+
+def test_g11_cmvae_eval_forward_and_predict():
+    g = load_golden("g11_cmvae_fwd_eval")
+    I, H, L = [int(v) for v in g["dims"]]
+    C_ = int(g["cond_dim"])
+    net, model = make_cvae(C_, [I, H, L], [L, H, I], 0.5, sd_from(g, "sd__"), beta=0.3)
+    assert net.enc_layers[0].weight.shape == (H, I + C_)
+    net.eval()
+    y, mu, logvar = net(torch.from_numpy(g["x"]))
+    assert y.shape == (g["x"].shape[0], I)
+    assert rel(y.cpu(), g["logits"]) < 1e-5 and rel(mu.cpu(), g["mu"]) < 1e-5 and rel(logvar.cpu(), g["logvar"]) < 1e-5
+    pred = model.predict(torch.from_numpy(g["x"]), remove_train=True)[0].cpu().numpy()
+    assert np.array_equal(np.isneginf(pred), np.isneginf(g["pred"]))
+    fin = np.isfinite(pred)
+    assert rel(pred[fin], g["pred"][fin]) < 1e-5
+    with pytest.raises(Exception):
+        model.train_batch(torch.from_numpy(g["x"]))          # a conditioned row cannot be its own target
+
+
+def test_g11_cmvae_train_steps_fp32():
+    g = load_golden("g11_cmvae_train_steps")
+    enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
+    beta, anneal, p, lr = [float(v) for v in g["meta"]]
+    C_ = g["xs"].shape[2] - enc[0]
+    net, model = make_cvae(C_, enc, dec, p, sd_from(g, "sd0__"), beta=beta, anneal_steps=int(anneal), learning_rate=lr,
+                           numerics="fp32")
+    _, keys = params_in_order(sd_from(g, "sd0__"))
+    for t in range(g["xs"].shape[0]):
+        model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), dev(g["eps_%d" % t]))
+        loss = model.train_batch(torch.from_numpy(g["xs"][t]), torch.from_numpy(g["gts"][t]))
+        assert abs(loss - float(g["loss_%d" % t])) < 1e-5 * abs(float(g["loss_%d" % t])), (t, loss)
+        sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
+        for k, prm, ref in zip(keys, net._param_list(), sd_t):
+            gref = g["grad_%d__%s" % (t, k.replace(".", "__"))]
+            assert rel(prm.grad.cpu(), gref) < 2e-4, (t, k)
+            assert float(np.max(np.abs(prm.detach().cpu().numpy() - ref))) < 5e-6, (t, k)
+    assert model.gradient_updates == float(g["gradient_updates"])
+
+
+def test_cmvae_sparse_sampler_batches_equal_dense_batches():
+    """the conditioned sampler's per-batch CSR form (sparse=True) drives the engine to the same step as its dense form"""
+    from rectorch_amd.samplers import ConditionedDataSampler
+    from rectorch_amd.utils.hashinit import hash_state_dict
+    rng = np.random.RandomState(4)
+    U, I, C_, H, L = 40, 96, 3, 24, 8
+    tr = csr_matrix((rng.rand(U, I) < 0.15).astype(np.float32))
+    tr = csr_matrix(tr + csr_matrix((np.ones(U), (np.arange(U), np.arange(U) % I)), shape=(U, I)))
+    tr.data[:] = 1.0
+    iid2cids = {i: sorted({int(i % C_), int((i * 7) % C_)}) for i in range(I)}
+    sd = hash_state_dict([I + C_, H, L], [L, H, I], "vae", 5, 1.0)
+    losses = {}
+    for sparse in (False, True):
+        torch.manual_seed(123)                 # the per-step Philox seed is drawn from torch's CPU generator
+        net, model = make_cvae(C_, [I, H, L], [L, H, I], 0.0, sd, beta=0.1, numerics="fp32")
+        sampler = ConditionedDataSampler(iid2cids, C_, tr, None, batch_size=16, shuffle=False, sparse=sparse)
+        out = []
+        for item in sampler:
+            if sparse:
+                out.append(model._fused_step(item, None, want_loss=True))
+            else:
+                out.append(model.train_batch(*item))
+        losses[sparse] = out
+    assert len(losses[True]) == len(losses[False]) > 3
+    np.testing.assert_allclose(losses[True], losses[False], rtol=1e-6)

@@ -258,3 +258,74 @@ def test_hashinit_and_synth_are_deterministic():
     assert (X != Y).nnz == 0 and X.shape == (300, 200) and X.has_sorted_indices
     d = np.diff(X.indptr)
     assert d.min() >= 5 and np.all(X.data == 1)
+
+
+# ------------------------------------------------------------------------------------------ conditioned samplers
+def _g11_samplers():
+    from conftest import load_golden
+    from scipy.sparse import csr_matrix
+    g = load_golden("g11_conditioned_samplers")
+    iid2cids = {}
+    for i, c in zip(g["iid2cids_items"], g["iid2cids_conds"]):
+        iid2cids.setdefault(int(i), []).append(int(c))
+    return g, iid2cids, csr_matrix(g["tr"]), csr_matrix(g["te"]), int(g["n_cond"])
+
+
+def test_conditioned_sampler_reference_kat():
+    """the reference's own test (tests/test_samplers.py:58-112) restated"""
+    from scipy.sparse import csr_matrix
+    from rectorch_amd.samplers import ConditionedDataSampler, EmptyConditionedDataSampler
+    train = csr_matrix((np.ones(4), (np.array([0, 0, 1, 1]), np.array([0, 1, 1, 2]))))
+    val_tr = csr_matrix((np.ones(1), (np.array([0]), np.array([0]))), shape=(1, 3))
+    val_te = csr_matrix((np.ones(1), (np.array([0]), np.array([1]))), shape=(1, 3))
+    iid2cids = {0: [1], 1: [0, 1], 2: [0]}
+    sampler = ConditionedDataSampler(iid2cids, 2, train, batch_size=2, shuffle=False)
+    assert len(sampler) == 3
+    exp_tr = [[[1, 1, 0, 0, 0], [0, 1, 1, 0, 0]], [[1, 1, 0, 1, 0], [1, 1, 0, 0, 1]], [[0, 1, 1, 1, 0], [0, 1, 1, 0, 1]]]
+    exp_te = [[[1, 1, 0], [0, 1, 1]], [[0, 1, 0], [1, 1, 0]], [[0, 1, 1], [0, 1, 0]]]
+    for i, (tr, te) in enumerate(sampler):
+        assert isinstance(tr, torch.FloatTensor) and isinstance(te, torch.FloatTensor)
+        assert np.all(tr.numpy() == np.array(exp_tr[i])) and np.all(te.numpy() == np.array(exp_te[i]))
+    np.random.seed(1)
+    sampler = ConditionedDataSampler(iid2cids, 2, val_tr, val_te, batch_size=1, shuffle=True)
+    assert len(sampler) == 2
+    for i, (tr, te) in enumerate(sampler):
+        assert np.all(tr.numpy() == np.array([1, 0, 0, 0, 0] if i == 0 else [1, 0, 0, 0, 1]))
+        assert np.all(te.numpy() == np.array([0, 1, 0]))
+    sampler = EmptyConditionedDataSampler(2, train, batch_size=2, shuffle=False)
+    assert len(sampler) == 1
+    for tr, te in sampler:
+        assert np.all(tr.numpy() == np.array([[1, 1, 0, 0, 0], [0, 1, 1, 0, 0]]))
+        assert np.all(te.numpy() == np.array([[1, 1, 0], [0, 1, 1]]))
+
+
+def test_conditioned_samplers_match_reference_g11():
+    """example lists and every batch (seeded shuffles / sub-sampling) equal to the reference's samplers"""
+    from rectorch_amd.samplers import ConditionedDataSampler, BalancedConditionedDataSampler, \
+        EmptyConditionedDataSampler
+    g, iid2cids, tr, te, nc = _g11_samplers()
+    s0 = ConditionedDataSampler(iid2cids, nc, tr, te, batch_size=7, shuffle=False)
+    assert np.array_equal(s0.examples, g["cds_examples"]) and len(s0) == int(g["cds_len"])
+    np.random.seed(5)
+    s1 = ConditionedDataSampler(iid2cids, nc, tr, te, batch_size=7, shuffle=True)
+    n = 0
+    for i, (a, b) in enumerate(s1):
+        assert np.array_equal(a.numpy(), g["cds_tr_%d" % i]) and np.array_equal(b.numpy(), g["cds_te_%d" % i])
+        n += 1
+    assert n == int(g["cds_n_batches"])
+    np.random.seed(6)
+    s2 = BalancedConditionedDataSampler(iid2cids, nc, tr, None, batch_size=9, subsample=0.3)
+    assert np.array_equal(s2.examples, g["bal_examples"]) and len(s2) == int(g["bal_len"])
+    np.random.seed(7)
+    n = 0
+    for i, (a, b) in enumerate(s2):
+        assert np.array_equal(a.numpy(), g["bal_tr_%d" % i]) and np.array_equal(b.numpy(), g["bal_te_%d" % i])
+        n += 1
+    assert n == int(g["bal_n_batches"])
+    np.random.seed(8)
+    s3 = EmptyConditionedDataSampler(nc, tr, te, batch_size=10, shuffle=True)
+    n = 0
+    for i, (a, b) in enumerate(s3):
+        assert np.array_equal(a.numpy(), g["emp_tr_%d" % i]) and np.array_equal(b.numpy(), g["emp_te_%d" % i])
+        n += 1
+    assert n == int(g["emp_n_batches"])
