@@ -82,8 +82,8 @@ class DataSampler(Sampler):
             self._csr_te = None if self.sparse_data_te is None else CsrMatrix(self.sparse_data_te)
             if self._csr_te is not None:
                 # same users; a conditioned input matrix carries its condition columns after the items (CMultiVAE)
-            assert self._csr_te.shape[0] == self._csr_tr.shape[0] and self._csr_te.shape[1] <= self._csr_tr.shape[1], \
-                "tr and te matrices must have the same shape"
+                assert self._csr_te.shape[0] == self._csr_tr.shape[0] and self._csr_te.shape[1] <= self._csr_tr.shape[1], \
+                    "tr and te matrices must have the same shape"
         self._src = (self.sparse_data_tr, self.sparse_data_te)
 
     def _order(self):
