@@ -173,8 +173,13 @@ def main():
     step_bytes, step_flops = eng.step_cost(B)
     P = sum(p.numel() for p in net.parameters())
     adam_ms, adam_n = timings.get("adam", (0.0, 0))
-    adam_us = adam_ms * 1e3 / max(adam_n, 1)
-    adam_bytes = 28.0 * P       # Adam reads p,g,m,v (16 B/param) and writes p,m,v (12 B/param)
+    dp = world > 1 or args.force_dp
+    # single GPU: one launch per step.  Data parallel: one launch per gradient bucket, right behind its all-reduce;
+    # the per-step figure is the sum of the step's launches
+    adam_us = adam_ms * 1e3 / (args.steps if dp else max(adam_n, 1))
+    # Adam reads p,g,m,v (16 B/param) and writes p,m,v (12 B/param); with the bf16 gradient exchange of the
+    # data-parallel bf16 mode the reduced gradient is read as bf16 (2 B/param less)
+    adam_bytes = (26.0 if dp and args.numerics == "bf16" else 28.0) * P
     achieved = adam_bytes / (adam_us * 1e-6) / 1e9 if adam_us else None
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r1_pmc_adam.json")

@@ -133,6 +133,15 @@ int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step*
                           float* loss_accum, rtx_layer_cb cb, void* user, void* stream);
 /* optimizer.step() (models.py:833): fused multi-tensor Adam over the bound tensors + shadow refresh */
 int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream);
+/* the same update restricted to layers [layer_lo, layer_hi) (network order, encoder first).  A data-parallel caller
+ * applies it bucket by bucket, each as soon as that bucket's gradient all-reduce has landed, on its own stream, so the
+ * optimizer pass of the decoder matrix hides under the exchange of the encoder matrix.  grads_bf16 (nullable): one
+ * pointer per bound tensor (2 per layer, ALL layers, W then b) to a bf16 image of the reduced gradient, read instead
+ * of the float32 gradient buffers (bf16 gradient exchange halves the bytes on xGMI and the Adam read). */
+int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t layer_lo, int32_t layer_hi,
+                                 const uint16_t* const* grads_bf16, void* stream);
+/* float32 -> bfloat16 (round to nearest even) of n contiguous elements: stages a gradient bucket for a bf16 all-reduce */
+int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* both of the above: one full train_batch */
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out,
                           float* loss_accum, void* stream);

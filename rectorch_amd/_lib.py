@@ -65,6 +65,8 @@ SIGNATURES = {
     "rtx_engine_decode": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rtx_engine_loss_grads": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, LAYER_CB, _P, _P]),
     "rtx_engine_apply_adam": (C.c_int, [_P, C.POINTER(Step), _P]),
+    "rtx_engine_apply_adam_layers": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, _P, _P]),
+    "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "rtx_sum_l2_norms": (C.c_int, [_P, _P, C.c_int32, _P, _P]),

@@ -869,6 +869,32 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
     return RTX_OK;
 }
 
+int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t layer_lo, int32_t layer_hi,
+                                 const uint16_t* const* grads_bf16, void* stream)
+{
+    RTX_TRY(check_ready(e, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "apply_adam: step count must be >= 1");
+    RTX_CHECK(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= e->NL, RTX_EINVAL, "apply_adam_layers: bad layer range [%d, %d) of %d",
+              layer_lo, layer_hi, e->NL);
+    hipStream_t st = (hipStream_t)stream;
+    RtxAdamArgs a = {};
+    fill_adam_tensors(e, a, layer_lo, layer_hi);
+    if (grads_bf16)
+        for (int t = 0; t < a.n; ++t) a.t[t].g16 = grads_bf16[2 * layer_lo + t];
+    fill_adam_scalars(e, step, a, 2 * layer_lo);
+    TIMED("adam");
+    RTX_TRY(rtx_launch_adam(a, e->bf16, st));
+    // the compute copies are whole again once every layer has been visited; callers cover [0, NL) each step
+    e->shadows_valid = true;
+    return RTX_OK;
+}
+
+int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream)
+{
+    RTX_CHECK(src && dst && n >= 0, RTX_EINVAL, "cast_f32_bf16: bad arguments");
+    return rtx_launch_cast_f32_bf16(src, dst, (long)n, (hipStream_t)stream);
+}
+
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                           void* stream)
 {

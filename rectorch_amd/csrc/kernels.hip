@@ -718,15 +718,22 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
                 const float4 p4 = *(const float4*)(t.p + o);
                 pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
                 if (a.update) {
-                    const float4 g4 = *(const float4*)(t.g + o), m4 = *(const float4*)(t.m + o), v4 = *(const float4*)(t.v + o);
-                    gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+                    const float4 m4 = *(const float4*)(t.m + o), v4 = *(const float4*)(t.v + o);
+                    if (t.g16) {   // data parallel, bf16 exchange: the all-reduced gradient arrives as bf16
+                        const uint2 u = *(const uint2*)(t.g16 + o);
+                        gv[0] = bf16_to_f32((bf16_t)(u.x & 0xffff)); gv[1] = bf16_to_f32((bf16_t)(u.x >> 16));
+                        gv[2] = bf16_to_f32((bf16_t)(u.y & 0xffff)); gv[3] = bf16_to_f32((bf16_t)(u.y >> 16));
+                    } else {
+                        const float4 g4 = *(const float4*)(t.g + o);
+                        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+                    }
                     mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
                     vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
                 }
             } else {
                 for (int e = 0; e < nv; ++e) {
                     pv[e] = t.p[o + e];
-                    if (a.update) { gv[e] = t.g[o + e]; mv[e] = t.m[o + e]; vv[e] = t.v[o + e]; }
+                    if (a.update) { gv[e] = t.g16 ? bf16_to_f32(t.g16[o + e]) : t.g[o + e]; mv[e] = t.m[o + e]; vv[e] = t.v[o + e]; }
                 }
             }
             if (a.update) {
@@ -1016,6 +1023,33 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
     }
     a.ndcg = ndcg; a.recall = recall; a.topk = topk; a.B = B;
     hipLaunchKernelGGL(k_topk_metrics, dim3(B), dim3(256), 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+
+// f32 -> bf16 (round to nearest even) of a gradient range before its RCCL all-reduce (data parallel, bf16 exchange)
+__global__ __launch_bounds__(256) void k_cast_f32_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, long n)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+        o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+        o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+        *(uint4*)(dst + i) = o;
+    } else {
+        for (long k = i; k < n; ++k) dst[k] = f32_to_bf16(src[k]);
+    }
+}
+
+int rtx_launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream)
+{
+    if (n <= 0) return RTX_OK;
+    RTX_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, RTX_EINVAL, "cast: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_cast_f32_bf16, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, stream, src, dst, n);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

@@ -144,6 +144,7 @@ int rtx_launch_dense_fill(const float* X, int B, int I, const int64_t* indptr, i
 struct RtxAdamTensor {
     float* p;
     const float* g;
+    const bf16_t* g16;   // nullable: read the gradient from this bf16 image instead of g
     float* m;
     float* v;
     void* sh;    // T [rows_p][ld_sh]   compute copy, same orientation   (nullable)
@@ -165,6 +166,7 @@ struct RtxAdamArgs {
     float grad_scale;  // multiplies g before use (1.0; data-parallel averaging hooks)
 };
 int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream);
+int rtx_launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
 int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, float* sumsq, hipStream_t stream);
 
 // out[c][r] = in[r][c], r < R, c < C (compute-copy transpose after the fused dW+Adam GEMM)

@@ -219,6 +219,14 @@ class Engine:
     def apply_adam(self, step):
         check(lib().rtx_engine_apply_adam(self.handle, C.byref(step), stream_ptr()))
 
+    def apply_adam_layers(self, step, layer_lo, layer_hi, grads_bf16=None):
+        """Adam + shadow refresh of layers [layer_lo, layer_hi) on the CURRENT stream; ``grads_bf16``: list of device
+        addresses (one per bound tensor) of the bf16 image of the reduced gradients, or None."""
+        arr = None
+        if grads_bf16 is not None:
+            arr = (C.c_void_p * self.n_tensors)(*[C.c_void_p(int(a)) for a in grads_bf16])
+        check(lib().rtx_engine_apply_adam_layers(self.handle, C.byref(step), int(layer_lo), int(layer_hi), arr, stream_ptr()))
+
     def train_step(self, x, target, step, loss_out, loss_accum=None):
         keep = []
         b = make_batch(x, target, keep=keep, n_items=self.n_items, n_in=self.n_in)
@@ -349,3 +357,9 @@ class EaseSolver:
             except Exception:
                 pass
             self.handle = None
+
+
+def cast_f32_bf16(src, dst):
+    """``dst`` (bfloat16) = round-to-nearest-even of ``src`` (float32), same number of elements, on the current stream."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    check(lib().rtx_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), stream_ptr()))

@@ -50,6 +50,7 @@ class _RtxState:
         self.flat_grads = None
         self.grads = None
         self.layer_ranges = None
+        self.tensor_offsets = None
         self.adam_step = 0
         self.loss_buf = None      # [0] = last loss, [1] = running sum since the last read-back
         self.reducer = None       # data parallel: rectorch_amd.parallel.GradAllReducer
@@ -228,6 +229,7 @@ class AETrainer(TorchNNTrainer):
             st.flat_grads = torch.zeros(total, dtype=torch.float32, device=params[0].device)
             st.grads = [st.flat_grads[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
             st.layer_ranges = [(offs[2 * l], offs[2 * l + 1] + params[2 * l + 1].numel()) for l in range(len(params) // 2)]
+            st.tensor_offsets = offs
             for p, g in zip(params, st.grads):
                 p.grad = g
             st.loss_buf = torch.zeros(2, dtype=torch.float32, device=params[0].device)
@@ -271,9 +273,16 @@ class AETrainer(TorchNNTrainer):
         if red is None:
             eng.train_step(x, target, step, loss_out, loss_acc)
         else:
+            if getattr(red, "bucket_adam", False):
+                g16 = red.grads16_ptrs()
+                red.adam = lambda lo, hi: eng.apply_adam_layers(step, lo, hi, g16)
+            else:
+                red.adam = None
             eng.loss_grads(x, target, step, loss_out, loss_acc, layer_cb=red.on_layer)
             red.wait()
-            eng.apply_adam(step)
+            if red.adam is None:
+                eng.apply_adam(step)
+            red.adam = None
         self.network._rtx_mark_updated(self.numerics)
         self._after_step()
         if want_loss:

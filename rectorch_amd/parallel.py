@@ -10,8 +10,12 @@ each already scaled by 1/B_global.  One exchange per step:
     engine calls back (``rtx_layer_cb``); the reducer records an event and issues ``all_reduce(SUM)`` of that
     layer's contiguous slice of the flat gradient buffer on a side HIP stream, so the big decoder bucket
     (dW4: 48 MB of the 98 MB at the ml-20m shape) is in flight while the remaining backward GEMMs run;
-  * the compute stream waits for the side stream, then every rank applies the same fused Adam update
-    (replicated weights stay bit-identical: same reduced gradient, same arithmetic).
+  * behind each bucket's all-reduce, on a third stream, that bucket's fused Adam update runs (every rank applies the
+    same update: replicated weights stay bit-identical -- same reduced gradient, same arithmetic), so the optimizer
+    pass of the decoder matrix hides under the exchange of the encoder matrix; the compute stream waits for both
+    side streams before the next forward;
+  * in bf16 numerics the exchange itself is bf16 (HIP cast kernel -> RCCL bf16 sum -> Adam reads bf16): xGMI bytes,
+    not compute, bound the step at this model size.
 
 Small layers are coalesced into one message (``min_bucket_bytes``).  Works with any torch.distributed
 backend: "nccl" (= RCCL on ROCm) for device tensors, "gloo" for the CPU tests of the plan itself.
@@ -32,7 +36,8 @@ def shard_rows(n_rows, rank, world):
 
 
 class GradAllReducer:
-    """Bucketed all-reduce of a flat gradient buffer, overlapped with the backward pass.
+    """Bucketed all-reduce of a flat gradient buffer, overlapped with the backward pass and -- when the trainer hands
+    over an ``adam`` callable -- followed bucket by bucket by that bucket's optimizer pass on a third stream.
 
     Parameters
     ----------
@@ -40,18 +45,31 @@ class GradAllReducer:
     layer_ranges : list of (start, end), layer order = parameter order (encoder first).
     min_bucket_bytes : layers are coalesced (in completion order, i.e. last layer first) until a bucket
         reaches this size; the big n_items x hidden layers go out on their own.
+    comm_dtype : ``torch.float32`` (exact sum, the parity mode) or ``torch.bfloat16``: the bucket is rounded to bf16
+        by a HIP kernel, summed by RCCL in bf16 and consumed by the Adam kernel as bf16 -- half the bytes on the xGMI
+        links, which bound the step (98 MB of float32 gradients per 0.45 ms of compute at the ml-20m shape).
+    tensor_offsets : element offset of every parameter tensor in ``flat`` (needed for the bf16 exchange: the Adam
+        kernel reads the reduced gradients from the bf16 mirror of ``flat``).
     """
 
-    def __init__(self, flat, layer_ranges, group=None, min_bucket_bytes=4 << 20):
+    def __init__(self, flat, layer_ranges, group=None, min_bucket_bytes=4 << 20, comm_dtype=torch.float32,
+                 tensor_offsets=None):
         self.flat = flat
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.layer_ranges = list(layer_ranges)
         self.on_device = flat.is_cuda
-        self.side = torch.cuda.Stream() if self.on_device else None
+        self.side = torch.cuda.Stream() if self.on_device else None     # RCCL
+        self.opt = torch.cuda.Stream() if self.on_device else None      # per-bucket Adam
+        self.comm_dtype = comm_dtype
+        self.flat16 = torch.zeros(flat.numel(), dtype=torch.bfloat16, device=flat.device) \
+            if comm_dtype == torch.bfloat16 else None
+        self.tensor_offsets = None if tensor_offsets is None else list(tensor_offsets)
+        self.adam = None          # set per step by the trainer: adam(layer_lo, layer_hi) enqueues on the current stream
         # plan: walking layers in completion order, a bucket closes at layer l when it is big enough or l == 0
         self.close_at = {}
+        self.bucket_layers = {}   # closing layer -> (first layer, one past the last layer) of the bucket
         n = len(self.layer_ranges)
         hi = n - 1
         size = 0
@@ -59,6 +77,7 @@ class GradAllReducer:
             size += (self.layer_ranges[l][1] - self.layer_ranges[l][0]) * flat.element_size()
             if size >= min_bucket_bytes or l == 0:
                 self.close_at[l] = (self.layer_ranges[l][0], self.layer_ranges[hi][1])
+                self.bucket_layers[l] = (l, hi + 1)
                 hi = l - 1
                 size = 0
         self.launched = []
@@ -68,26 +87,58 @@ class GradAllReducer:
         """(closing layer, start, end) in launch order -- for tests and the design notes."""
         return [(l, *self.close_at[l]) for l in sorted(self.close_at, reverse=True)]
 
+    def grads16_ptrs(self):
+        """device address of every tensor's reduced bf16 gradient (None with a float32 exchange)"""
+        if self.flat16 is None:
+            return None
+        assert self.tensor_offsets is not None, "the bf16 exchange needs the tensors' offsets in the flat buffer"
+        base = self.flat16.data_ptr()
+        return [base + 2 * int(o) for o in self.tensor_offsets]
+
+    def _exchange(self, rng):
+        view = self.flat[rng[0]:rng[1]]
+        if self.flat16 is None:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        v16 = self.flat16[rng[0]:rng[1]]
+        if self.on_device:
+            from .engine import cast_f32_bf16
+            cast_f32_bf16(view, v16)
+        else:
+            v16.copy_(view)
+        dist.all_reduce(v16, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.on_device or self.adam is None:
+            view.copy_(v16)       # consumers that read the float32 buffer (host tests, unfused optimizer, p.grad)
+
     def on_layer(self, layer, _user=None):
         """Host callback from rtx_engine_loss_grads: gradients of ``layer`` are enqueued on the compute stream."""
         rng = self.close_at.get(int(layer))
         if rng is None:
             return
-        view = self.flat[rng[0]:rng[1]]
+        lo, hi = self.bucket_layers[int(layer)]
         if self.on_device:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                self._exchange(rng)
+            if self.adam is not None:
+                # the event also orders this bucket's weights after their last reader of this step (dX of the layer
+                # is enqueued before its dW), so the update may run while the rest of the backward is still going
+                self.opt.wait_stream(self.side)
+                with torch.cuda.stream(self.opt):
+                    self.adam(lo, hi)
         else:
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            self._exchange(rng)
+            if self.adam is not None:
+                self.adam(lo, hi)
         self.launched.append(int(layer))
 
     def wait(self):
         """Make the compute stream wait for every bucket launched since the last wait()."""
         if self.on_device:
             torch.cuda.current_stream().wait_stream(self.side)
+            torch.cuda.current_stream().wait_stream(self.opt)
         self.launched = []
 
     def global_batch(self, local_batch):
@@ -126,15 +177,21 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None):
+def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None, comm_dtype=None, bucket_adam=True):
     """Turn a :class:`rectorch_amd.models.AETrainer` into a data-parallel replica: broadcasts rank 0's
     parameters, then every ``train_batch`` all-reduces the gradients as described above.  Each rank must feed
-    ITS slice of the global batch (see ``shard_rows``)."""
+    ITS slice of the global batch (see ``shard_rows``).
+
+    ``comm_dtype``: None -> bfloat16 when the model trains in bf16 numerics, float32 (exact) in the fp32 parity mode.
+    ``bucket_adam``: apply Adam per bucket right behind its all-reduce (third stream) instead of once after all."""
     st, params, m, v = model._ensure_train_state()
     for p in params:
         dist.broadcast(p.data, src=0, group=group)
     model.network._rtx_shadow_versions.clear()      # parameters changed under the engines: refresh the shadows
-    red = GradAllReducer(st.flat_grads, st.layer_ranges, group, min_bucket_bytes)
+    if comm_dtype is None:
+        comm_dtype = torch.bfloat16 if getattr(model, "numerics", "fp32") == "bf16" else torch.float32
+    red = GradAllReducer(st.flat_grads, st.layer_ranges, group, min_bucket_bytes, comm_dtype, st.tensor_offsets)
+    red.bucket_adam = bool(bucket_adam)
     if fixed_global_batch is not None:
         red.global_batch = lambda local, _g=int(fixed_global_batch): _g
     st.reducer = red

@@ -1,0 +1,69 @@
+"""Run by test_gpu_parity.py::test_dp_path_world1_rccl in its own process: the data-parallel step (per-layer callback ->
+RCCL all-reduce on a side stream -> per-bucket Adam on a third stream) with a world of ONE rank must reproduce the
+single-GPU step: exactly the golden G2 trajectory with the float32 exchange, and within bf16 rounding of the gradients
+with the bf16 exchange."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import load_golden, sd_from, params_in_order          # noqa: E402
+from rectorch_amd import parallel                                   # noqa: E402
+from rectorch_amd.models import MultiVAE                            # noqa: E402
+from rectorch_amd.nets import MultiVAE_net                          # noqa: E402
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def run(g, comm_dtype, bucket_adam, min_bucket):
+    enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
+    beta, anneal, p, lr = [float(v) for v in g["meta"]]
+    net = MultiVAE_net(dec, enc, dropout=p)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_from(g, "sd0__").items()})
+    net.to("cuda")
+    model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
+    if comm_dtype is not None:
+        red = parallel.attach(model, min_bucket_bytes=min_bucket, comm_dtype=comm_dtype, bucket_adam=bucket_adam)
+        assert len(red.buckets()) >= 2
+    losses = []
+    for t in range(g["xs"].shape[0]):
+        model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), dev(g["eps_%d" % t]))
+        gt = torch.from_numpy(g["gts"][t]) if "gts" in g else None
+        losses.append(model.train_batch(torch.from_numpy(g["xs"][t]), gt))
+    torch.cuda.synchronize()
+    return losses, [p_.detach().cpu().numpy().copy() for p_ in net._param_list()]
+
+
+def main():
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[1], rank=0, world_size=1)
+    g = load_golden("g2c_mvae_train_step_deep")
+    _, keys = params_in_order(sd_from(g, "sd0__"))
+    ref_losses, ref_params = run(g, None, False, 0)
+    for bucket_adam in (False, True):
+        losses, params = run(g, torch.float32, bucket_adam, 256)
+        assert losses == ref_losses, (bucket_adam, losses, ref_losses)
+        for k, a, b in zip(keys, params, ref_params):
+            assert np.array_equal(a, b), ("fp32 exchange must be bit-identical to the single-GPU step", bucket_adam, k)
+        sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % (g["xs"].shape[0] - 1)))
+        for k, a, b in zip(keys, params, sd_t):
+            assert float(np.max(np.abs(a - b))) < 5e-6, (bucket_adam, k)
+    for bucket_adam in (False, True):
+        losses, params = run(g, torch.bfloat16, bucket_adam, 256)
+        for k, a, b in zip(keys, params, ref_params):
+            # Adam normalises the step: a gradient rounded to 8 bits moves a parameter by at most ~lr per step
+            assert float(np.max(np.abs(a - b))) < 3 * 1e-3 * 0.02 + 1e-6, (bucket_adam, k, float(np.max(np.abs(a - b))))
+    dist.destroy_process_group()
+    print("DP_WORLD1_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -765,3 +765,16 @@ def test_cmvae_sparse_sampler_batches_equal_dense_batches():
         losses[sparse] = out
     assert len(losses[True]) == len(losses[False]) > 3
     np.testing.assert_allclose(losses[True], losses[False], rtol=1e-6)
+
+
+def test_dp_path_world1_rccl():
+    """the data-parallel step (RCCL all-reduce per bucket on a side stream, per-bucket Adam on a third stream, float32
+    and bf16 exchange) against the single-GPU step, in its own process with a one-rank RCCL group"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "dp_world1_check.py"), str(port)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DP_WORLD1_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

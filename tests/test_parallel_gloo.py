@@ -55,6 +55,28 @@ def _worker(rank, world, port, out_dir):
         for l in range(4):
             want = sum((r + 1) * (l + 1) + step for r in range(world))
             assert torch.all(flat[ranges[l][0]:ranges[l][1]] == want), (rank, l)
+    # bf16 exchange + per-bucket optimizer callback: same sums (small integers are exact in bf16), every layer handed
+    # to the optimizer exactly once, bucket by bucket in completion order, each AFTER its own exchange
+    flat2 = torch.zeros(total)
+    red2 = GradAllReducer(flat2, ranges, min_bucket_bytes=64 << 10, comm_dtype=torch.bfloat16, tensor_offsets=offs)
+    calls = []
+
+    def adam(lo, hi):
+        for l in range(lo, hi):
+            want = sum((r + 1) * (l + 1) for r in range(world))
+            assert torch.all(red2.flat16[ranges[l][0]:ranges[l][1]].float() == want), (rank, l)
+        calls.append((lo, hi))
+
+    red2.adam = adam
+    for l in range(4):
+        flat2[ranges[l][0]:ranges[l][1]] = (rank + 1) * (l + 1)
+    for l in (3, 2, 1, 0):
+        red2.on_layer(l)
+    red2.wait()
+    assert [c[0] for c in calls] == [b[0] for b in red2.buckets()], calls
+    assert sorted(l for lo, hi in calls for l in range(lo, hi)) == [0, 1, 2, 3], calls
+    ptrs = red2.grads16_ptrs()
+    assert len(ptrs) == 8 and ptrs[0] == red2.flat16.data_ptr() and ptrs[2] - ptrs[0] == 2 * offs[2]
     assert red.global_batch(250 + rank) == sum(250 + r for r in range(world))
     assert abs(red.reduce_scalar(torch.tensor([0.5 * (rank + 1)])) - sum(0.5 * (r + 1) for r in range(world))) < 1e-6
     # row sharding: every rank takes its slice of the same global permutation -> disjoint cover
