@@ -183,6 +183,36 @@ int rtx_ease_scores(const rtx_ease* h, const rtx_csr* X, const int32_t* row_ids,
  * inverse of the factor, inv_ms = P = W^T W */
 int rtx_ease_timings(const rtx_ease* h, double* fit_ms, double* gram_ms, double* chol_ms, double* inv_ms);
 
+/* ---- SVAE: sequential VAE, one user sequence per optimizer step (rectorch/nets.py:624-693,
+ * rectorch/models.py:1581-1635) ---------------------------------------------------------------------------------------
+ * Parameter tensors in the order of SVAE_net.parameters(): enc W,b ... dec W,b ..., item_embed.weight [n_items][embed],
+ * gru.weight_ih_l0 [3R][embed], gru.weight_hh_l0 [3R][R], gru.bias_ih_l0 [3R], gru.bias_hh_l0 [3R] (gate order r|z|n). */
+typedef struct rtx_svae rtx_svae;
+typedef struct {
+    int32_t n_items, embed_size, rnn_size;
+    int32_t n_enc, n_dec;
+    int32_t enc_dims[RTX_MAX_LAYERS + 1]; /* enc_dims[0] = rnn_size ... enc_dims[n_enc] = latent */
+    int32_t dec_dims[RTX_MAX_LAYERS + 1]; /* dec_dims[0] = latent   ... dec_dims[n_dec] = n_items */
+    int32_t max_len;                      /* longest input sequence (time steps) */
+} rtx_svae_cfg;
+int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out);
+int rtx_svae_destroy(rtx_svae* s);
+int32_t rtx_svae_n_tensors(const rtx_svae* s);
+int rtx_svae_tensor_shape(const rtx_svae* s, int32_t t, int32_t* rows, int32_t* cols);
+int rtx_svae_bind(rtx_svae* s, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq);
+/* SVAE_net.forward (nets.py:666-676) on one sequence `items` (device int32 [T]); z is always sampled (eps_noise: injected
+ * N(0,1) draws [T][latent], NULL -> Philox(seed, offset)).  Any output may be NULL: logits_all [T][n_items], logits_last
+ * [n_items] = recon_x[:, -1, :] with -inf at the items of the sequence when remove_train (SVAE.predict,
+ * models.py:1628-1635), mu / logvar [T][latent]. */
+int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* eps_noise, uint64_t seed, uint64_t offset,
+                     int32_t remove_train, float* logits_all, float* logits_last, float* mu, float* logvar, void* stream);
+/* MultiVAE.train_batch with SVAE.loss_function and the SVAE optimizer (models.py:817-835, 1622-1626, 1618-1620):
+ * forward, loss = sum_t NLL_t * step->inv_batch + step->beta * mean_t KL_t (inv_batch = 1 / number of ones in the
+ * target), backward (decoder, encoder head, GRU through time, embedding), Adam with step->weight_decay.  The target is
+ * either a CSR over the T steps (device int64 indptr [T+1], int32 indices, implicit ones) or a dense device [T][n_items]. */
+int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
+                        const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream);
+
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
 int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);
 /* synchronises, returns up to `cap` entries (name, total ms, launches) and clears the counters */

@@ -30,6 +30,13 @@ class Cfg(C.Structure):
                 ("max_batch", C.c_int32), ("splitk", C.c_int32), ("cond_dim", C.c_int32)]
 
 
+class SvaeCfg(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("embed_size", C.c_int32), ("rnn_size", C.c_int32),
+                ("n_enc", C.c_int32), ("n_dec", C.c_int32),
+                ("enc_dims", C.c_int32 * (MAX_LAYERS + 1)), ("dec_dims", C.c_int32 * (MAX_LAYERS + 1)),
+                ("max_len", C.c_int32)]
+
+
 class Batch(C.Structure):
     _fields_ = [("csr", C.c_void_p), ("row_ids", C.c_void_p), ("target_csr", C.c_void_p),
                 ("x_dense", C.c_void_p), ("target_dense", C.c_void_p), ("batch", C.c_int32)]
@@ -77,6 +84,13 @@ SIGNATURES = {
     "rtx_ease_copy_weights": (C.c_int, [_P, _P, _P]),
     "rtx_ease_scores": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "rtx_ease_timings": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rtx_svae_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "rtx_svae_destroy": (C.c_int, [_P]),
+    "rtx_svae_n_tensors": (C.c_int32, [_P]),
+    "rtx_svae_tensor_shape": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rtx_svae_bind": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rtx_svae_forward": (C.c_int, [_P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P, _P, _P, _P]),
+    "rtx_svae_train_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(Step), _P, _P, _P]),
     "rtx_engine_set_timing": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rtx_engine_get_timings": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     "rtx_engine_step_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

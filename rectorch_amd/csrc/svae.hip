@@ -1,0 +1,613 @@
+// svae.hip -- Sequential VAE (BASELINE.json configs[4]) on MI355X: one user sequence per optimizer step.
+//
+// Reference: rectorch/nets.py:624-693 (SVAE_net: Embedding -> 1-layer GRU (batch_first) -> VAE head that ALWAYS samples
+// (VAE_net._reparameterize, nets.py:316-319) -> tanh MLP decoder), rectorch/models.py:1609-1635 (SVAE: loss =
+// sum_t NLL_t / #target-ones + beta * mean_t KL_t; Adam with weight_decay 5e-3; predict = last time step, -inf at the
+// items of the input sequence).
+//
+// The reference trains one user (T ~ 100 time steps) per Adam step, so every contraction is a [T, small] x [small, *]
+// product: the step is bound by launch latency and by the strictly sequential GRU recurrence, not by MFMA throughput.
+// Design for that regime (all float32, so parity with the reference is ~1e-6):
+//   * one generic strided GEMM kernel (64x64 tile, 4x4 per thread, bias / tanh / tanh'-mask epilogues) serves every
+//     forward, backward-data and weight-gradient product -- operands are read in place with strides, no padded copies;
+//   * the GRU recurrence (forward and BPTT) runs as ONE persistent workgroup of 1024 threads per direction: h_t lives
+//     in LDS, W_hh streams from L2 (it is re-read every step), the input projections x_t W_ih^T for all t are one GEMM
+//     before the loop, and the weight gradients are two GEMMs over all t after it;
+//   * Adam over the 5 + 2(n_enc + n_dec) tensors is the one fused multi-tensor kernel of the Mult-VAE path (k_adam).
+// User packing (several sequences per launch, MFMA tiles) needs an API change in the sampler and is left for later.
+#include "../../include/rectorch_hip.h"
+#include "rtx_kernels.h"
+
+#include <math.h>
+#include <vector>
+
+#define SV_MAX_LAYERS RTX_MAX_LAYERS
+
+struct SvLayer {
+    int in = 0, out = 0;
+    bool tanh_act = false;
+    float* A = nullptr;     // [Tmax][out] activation (post-tanh, or raw for the linear layers)
+    float* D = nullptr;     // [Tmax][out] gradient w.r.t. the pre-activation
+};
+
+struct rtx_svae {
+    rtx_svae_cfg cfg;
+    int I = 0, E = 0, R = 0, Z = 0, NL = 0, n_enc = 0, Tmax = 0;
+    std::vector<SvLayer> L;          // encoder layers then decoder layers
+    int n_tensors = 0;
+    std::vector<float*> params, grads, m, v;
+    bool bound = false, can_train = false;
+    // activations / scratch (device)
+    float *X = nullptr, *GI = nullptr, *H = nullptr, *Gr = nullptr, *Gz = nullptr, *Gn = nullptr, *Ghn = nullptr;
+    float *mu = nullptr, *lv = nullptr, *eps = nullptr, *zl = nullptr, *dz = nullptr;
+    float *dH = nullptr, *dGI = nullptr, *dGH = nullptr, *dX = nullptr;
+    float *row_loss = nullptr, *tsum = nullptr, *kl_rows = nullptr;
+    std::vector<void*> allocs;
+};
+
+// ------------------------------------------------------------------------------------------------ kernels
+// C[m][n] (ldc) = epi( alpha * sum_k A(m,k) * B(n,k) (+ C if accumulate) ), A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk]
+enum { SV_EPI_NONE = 0, SV_EPI_BIAS = 1, SV_EPI_BIAS_TANH = 2, SV_EPI_TANH_GRAD = 3 };
+struct SvGemm {
+    const float* A; long sam, sak;
+    const float* B; long sbn, sbk;
+    float* C; long ldc;
+    int M, N, K;
+    float alpha;
+    int epi;
+    const float* bias;   // [N]        (SV_EPI_BIAS*)
+    const float* Q;      // [M][ldq]   (SV_EPI_TANH_GRAD: C = acc * (1 - Q^2))
+    long ldq;
+};
+
+__global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
+{
+    __shared__ float sA[16][65], sB[16][65];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        // 64 x 16 elements per operand, 4 per thread; the faster-varying thread index follows the unit-stride axis
+        for (int e = tid; e < 1024; e += 256) {
+            int mm, kk;
+            if (g.sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+            const int m = m0 + mm, k = k0 + kk;
+            sA[kk][mm] = (m < g.M && k < g.K) ? g.A[(size_t)m * g.sam + (size_t)k * g.sak] : 0.f;
+            int nn, k2;
+            if (g.sbk == 1) { k2 = e & 15; nn = e >> 4; } else { nn = e & 63; k2 = e >> 6; }
+            const int n = n0 + nn, kb = k0 + k2;
+            sB[k2][nn] = (n < g.N && kb < g.K) ? g.B[(size_t)n * g.sbn + (size_t)kb * g.sbk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sA[kk][tm + i]; b[i] = sB[kk][tn + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + tm + i;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tn + j;
+            if (n >= g.N) continue;
+            float v = g.alpha * acc[i][j];
+            if (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH) v += g.bias[n];
+            if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
+            if (g.epi == SV_EPI_TANH_GRAD) { const float q = g.Q[(size_t)m * g.ldq + n]; v *= (1.f - q * q); }
+            g.C[(size_t)m * g.ldc + n] = v;
+        }
+    }
+}
+
+// out[n] = sum_t D[t][n]  (bias gradients); one thread per column
+__global__ __launch_bounds__(256) void k_sv_colsum(const float* D, long ld, int T, int N, float* out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += D[(size_t)t * ld + n];
+    out[n] = s;
+}
+
+__global__ __launch_bounds__(256) void k_sv_embed(const int32_t* items, int T, int E, const float* emb, float* X)
+{
+    const int t = blockIdx.x;
+    const float* src = emb + (size_t)items[t] * E;
+    for (int e = threadIdx.x; e < E; e += 256) X[(size_t)t * E + e] = src[e];
+}
+
+__global__ __launch_bounds__(256) void k_sv_embed_grad(const int32_t* items, int T, int E, const float* dX, float* demb)
+{
+    const int t = blockIdx.x;
+    float* dst = demb + (size_t)items[t] * E;
+    for (int e = threadIdx.x; e < E; e += 256) atomicAdd(dst + e, dX[(size_t)t * E + e]);   // an item may repeat in a sequence
+}
+
+__device__ __forceinline__ float sv_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// block-wide reductions for 256-thread blocks; red must hold >= 4 floats; result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// GRU forward, torch.nn.GRU gate order r | z | n (weight_hh_l0 [3R][R], bias_hh_l0 [3R]); GI = x W_ih^T + b_ih [T][3R].
+//   r = sig(gi_r + W_hr h + b_hr), z = sig(gi_z + W_hz h + b_hz), n = tanh(gi_n + r * (W_hn h + b_hn)), h' = (1-z) n + z h
+// One workgroup of 1024 threads; wave w computes the rows w, w+16, ... of W_hh h (lanes split K, DPP reduction).
+__global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                     int T, int R, float* __restrict__ H /* [T+1][R], H[0] = 0 */, float* __restrict__ Gr,
+                                                     float* __restrict__ Gz, float* __restrict__ Gn, float* __restrict__ Ghn)
+{
+    extern __shared__ float sm[];   // h [R] | gh [3R]
+    float* h = sm;
+    float* gh = sm + R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < R; j += 1024) { h[j] = 0.f; H[j] = 0.f; }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        for (int row = wave; row < 3 * R; row += 16) {
+            const float* w = Whh + (size_t)row * R;
+            float s = 0.f;
+            for (int k = lane; k < R; k += 64) s += w[k] * h[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) gh[row] = s + bhh[row];
+        }
+        __syncthreads();
+        const float* gi = GI + (size_t)t * 3 * R;
+        for (int j = tid; j < R; j += 1024) {
+            const float r = sv_sigmoid(gi[j] + gh[j]);
+            const float z = sv_sigmoid(gi[R + j] + gh[R + j]);
+            const float hn = gh[2 * R + j];
+            const float n = tanhf(gi[2 * R + j] + r * hn);
+            const float hp = h[j];
+            const float hv = (1.f - z) * n + z * hp;
+            Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
+            H[(size_t)(t + 1) * R + j] = hv;
+            h[j] = hv;   // element j is read and written by this thread only; the matvec above is behind the barrier
+        }
+        __syncthreads();
+    }
+}
+
+// GRU backward through time.  dHout[t] = gradient w.r.t. the GRU output at step t.  Writes the gate pre-activation
+// gradients dGI [T][3R] (input side) and dGH [T][3R] (hidden side; differs in the n block by the factor r).
+__global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ dHout, const float* __restrict__ Whh, int T, int R,
+                                                     const float* __restrict__ H, const float* __restrict__ Gr, const float* __restrict__ Gz,
+                                                     const float* __restrict__ Gn, const float* __restrict__ Ghn, float* __restrict__ dGI,
+                                                     float* __restrict__ dGH)
+{
+    extern __shared__ float sm[];   // dh [R] | dgh [3R] | part [16][R]
+    float* dh = sm;
+    float* dgh = sm + R;
+    float* part = sm + 4 * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int j = tid; j < R; j += 1024) dh[j] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        for (int j = tid; j < R; j += 1024) {
+            const float d = dh[j] + dHout[(size_t)t * R + j];
+            const float r = Gr[(size_t)t * R + j], z = Gz[(size_t)t * R + j], n = Gn[(size_t)t * R + j], hn = Ghn[(size_t)t * R + j];
+            const float hp = H[(size_t)t * R + j];
+            const float dn = d * (1.f - z);
+            const float dzp = d * (hp - n) * z * (1.f - z);
+            const float dnp = dn * (1.f - n * n);
+            const float drp = dnp * hn * r * (1.f - r);
+            float* gi = dGI + (size_t)t * 3 * R;
+            float* gh = dGH + (size_t)t * 3 * R;
+            gi[j] = drp; gi[R + j] = dzp; gi[2 * R + j] = dnp;
+            gh[j] = drp; gh[R + j] = dzp; gh[2 * R + j] = dnp * r;
+            dgh[j] = drp; dgh[R + j] = dzp; dgh[2 * R + j] = dnp * r;
+            dh[j] = d * z;   // the direct path h_{t-1} -> h_t; the path through the gates is added below
+        }
+        __syncthreads();
+        // dh_prev[k] += sum_i W_hh[i][k] * dgh[i]: wave w accumulates rows w, w+16, ...; lanes own columns k = lane + 64 c
+        for (int c0 = 0; c0 < R; c0 += 64 * 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const int k0 = c0 + lane, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
+            for (int row = wave; row < 3 * R; row += 16) {
+                const float gsc = dgh[row];
+                const float* w = Whh + (size_t)row * R;
+                if (k0 < R) a0 += w[k0] * gsc;
+                if (k1 < R) a1 += w[k1] * gsc;
+                if (k2 < R) a2 += w[k2] * gsc;
+                if (k3 < R) a3 += w[k3] * gsc;
+            }
+            if (k0 < R) part[wave * R + k0] = a0;
+            if (k1 < R) part[wave * R + k1] = a1;
+            if (k2 < R) part[wave * R + k2] = a2;
+            if (k3 < R) part[wave * R + k3] = a3;
+        }
+        __syncthreads();
+        for (int j = tid; j < R; j += 1024) {
+            float s = dh[j];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += part[w * R + j];
+            dh[j] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// encoder head: out [T][2Z] = mu | logvar; z = mu + eps * exp(logvar / 2) with eps injected or Philox (always sampled)
+__global__ __launch_bounds__(256) void k_sv_reparam(const float* out, int T, int Z, const float* eps_in, uint64_t seed, uint64_t offset,
+                                                    float* mu, float* lv, float* eps_out, float* z)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * Z) return;
+    const int t = idx / Z, j = idx % Z;
+    const float m = out[(size_t)t * 2 * Z + j], l = out[(size_t)t * 2 * Z + Z + j];
+    const float e = eps_in ? eps_in[idx] : rtx_normal(seed, offset, (uint64_t)idx);
+    mu[idx] = m; lv[idx] = l; eps_out[idx] = e;
+    z[idx] = m + e * expf(0.5f * l);
+}
+
+// gradient w.r.t. the encoder head output [T][2Z] from dz and the KL term  beta * mean_t(-0.5 sum_j (1 + lv - mu^2 - e^lv));
+// kl_rows[t] = -0.5 sum_j(...)
+__global__ __launch_bounds__(256) void k_sv_reparam_bwd(const float* dz, const float* mu, const float* lv, const float* eps, int T, int Z,
+                                                        float beta_over_T, float* dout, float* kl_rows)
+{
+    __shared__ float red[4];
+    const int t = blockIdx.x;
+    float kl = 0.f;
+    for (int j = threadIdx.x; j < Z; j += 256) {
+        const int idx = t * Z + j;
+        const float m = mu[idx], l = lv[idx], el = expf(l), sd = expf(0.5f * l);
+        kl += -0.5f * (1.f + l - m * m - el);
+        if (dout) {
+            const float d = dz[idx];
+            dout[(size_t)t * 2 * Z + j] = d + beta_over_T * m;
+            dout[(size_t)t * 2 * Z + Z + j] = d * eps[idx] * 0.5f * sd + beta_over_T * 0.5f * (el - 1.f);
+        }
+    }
+    kl = block_sum(kl, red);
+    if (threadIdx.x == 0) kl_rows[t] = kl;
+}
+
+// per time step: log-softmax NLL against the target row (CSR, or dense [T][I]) and the logits gradient
+//   nll_t = -sum_i y_ti (x_ti - lse_t);  dlogits = (s_t softmax - y) * inv_d
+__global__ __launch_bounds__(256) void k_sv_loss(const float* logits, int T, int I, const int64_t* tptr, const int32_t* tidx,
+                                                 const float* ydense, float inv_d, float* dlogits, float* row_loss)
+{
+    __shared__ float red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (size_t)t * I;
+    float mx = -INFINITY;
+    for (int i = tid; i < I; i += 256) mx = fmaxf(mx, x[i]);
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int i = tid; i < I; i += 256) se += expf(x[i] - mx);
+    se = block_sum(se, red);
+    const float lse = mx + logf(se);
+    float s = 0.f, dot = 0.f;
+    if (ydense) {
+        const float* y = ydense + (size_t)t * I;
+        for (int i = tid; i < I; i += 256) { s += y[i]; dot += y[i] * x[i]; }
+    } else {
+        for (int64_t k = tptr[t] + tid; k < tptr[t + 1]; k += 256) { s += 1.f; dot += x[tidx[k]]; }
+    }
+    s = block_sum(s, red);
+    dot = block_sum(dot, red);
+    if (tid == 0) row_loss[t] = s * lse - dot;
+    if (dlogits) {
+        float* d = dlogits + (size_t)t * I;
+        if (ydense) {
+            const float* y = ydense + (size_t)t * I;
+            for (int i = tid; i < I; i += 256) d[i] = (s * expf(x[i] - lse) - y[i]) * inv_d;
+        } else {
+            for (int i = tid; i < I; i += 256) d[i] = s * expf(x[i] - lse) * inv_d;
+            __syncthreads();
+            for (int64_t k = tptr[t] + tid; k < tptr[t + 1]; k += 256) d[tidx[k]] -= inv_d;   // indices are distinct within a row
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sv_final_loss(const float* row_loss, const float* kl_rows, int T, float inv_d, float beta_over_T,
+                                                       float* loss_out, float* loss_accum)
+{
+    __shared__ float red[4];
+    float a = 0.f, b = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { a += row_loss[t]; b += kl_rows[t]; }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        const float l = a * inv_d + beta_over_T * b;
+        if (loss_out) loss_out[0] = l;
+        if (loss_accum) loss_accum[0] += l;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sv_mask_items(const int32_t* items, int T, float* row)
+{
+    for (int t = threadIdx.x; t < T; t += 256) row[items[t]] = -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int sv_alloc(rtx_svae* s, float** p, size_t n)
+{
+    hipError_t rc = hipMalloc((void**)p, sizeof(float) * (n ? n : 4));
+    if (rc != hipSuccess) {
+        rtx_set_error("svae: hipMalloc(%zu floats) failed: %s", n, hipGetErrorString(rc));
+        return RTX_ENOMEM;
+    }
+    s->allocs.push_back(*p);
+    return RTX_OK;
+}
+
+static int sv_gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N,
+                   int K, int epi = SV_EPI_NONE, const float* bias = nullptr, const float* Q = nullptr, long ldq = 0)
+{
+    if (M <= 0 || N <= 0) return RTX_OK;
+    SvGemm g = {A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, 1.f, epi, bias, Q, ldq};
+    hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// parameter order = SVAE_net.parameters(): enc W,b ..., dec W,b ..., item_embed.weight, gru.weight_ih_l0, weight_hh_l0,
+// bias_ih_l0, bias_hh_l0 (VAE_net.__init__ registers the MLPs before SVAE_net adds the embedding and the GRU)
+enum { SV_T_EMB = 0, SV_T_WIH = 1, SV_T_WHH = 2, SV_T_BIH = 3, SV_T_BHH = 4 };
+static int sv_tail(const rtx_svae* s, int which) { return 2 * s->NL + which; }
+
+static void sv_shape(const rtx_svae* s, int t, int* rows, int* cols)
+{
+    if (t < 2 * s->NL) {
+        const SvLayer& l = s->L[t / 2];
+        *rows = l.out;
+        *cols = (t & 1) ? 1 : l.in;
+        return;
+    }
+    switch (t - 2 * s->NL) {
+    case SV_T_EMB: *rows = s->I; *cols = s->E; break;
+    case SV_T_WIH: *rows = 3 * s->R; *cols = s->E; break;
+    case SV_T_WHH: *rows = 3 * s->R; *cols = s->R; break;
+    default: *rows = 3 * s->R; *cols = 1; break;
+    }
+}
+
+// embedding -> GRU -> encoder -> (sampled) z -> decoder; logits of all T steps land in L.back().A
+static int sv_forward(rtx_svae* s, const int32_t* items, int T, const float* eps_in, uint64_t seed, uint64_t offset, hipStream_t st)
+{
+    const int E = s->E, R = s->R, Z = s->Z;
+    hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
+    RTX_TRY(sv_gemm(st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
+                    s->params[sv_tail(s, SV_T_BIH)]));
+    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(1), dim3(1024), sizeof(float) * 4 * R, st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
+                       s->params[sv_tail(s, SV_T_BHH)], T, R, s->H, s->Gr, s->Gz, s->Gn, s->Ghn);
+    const float* in = s->H + R;   // rnn_out[t] = h_{t+1}
+    long ld_in = R;
+    for (int li = 0; li < s->NL; ++li) {
+        SvLayer& l = s->L[li];
+        RTX_TRY(sv_gemm(st, in, ld_in, 1, s->params[2 * li], l.in, 1, l.A, l.out, T, l.out, l.in, l.tanh_act ? SV_EPI_BIAS_TANH : SV_EPI_BIAS,
+                        s->params[2 * li + 1]));
+        in = l.A;
+        ld_in = l.out;
+        if (li == s->n_enc - 1) {
+            hipLaunchKernelGGL(k_sv_reparam, dim3((T * Z + 255) / 256), dim3(256), 0, st, l.A, T, Z, eps_in, seed, offset, s->mu, s->lv, s->eps,
+                               s->zl);
+            in = s->zl;
+            ld_in = Z;
+        }
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+static int sv_check(const rtx_svae* s, const int32_t* items, int T, bool train)
+{
+    RTX_CHECK(s, RTX_EINVAL, "svae: NULL handle");
+    RTX_CHECK(s->bound, RTX_ESTATE, "svae: parameters are not bound (rtx_svae_bind)");
+    RTX_CHECK(!train || s->can_train, RTX_ESTATE, "svae: gradient / Adam buffers are not bound");
+    RTX_CHECK(items && T >= 1 && T <= s->Tmax, RTX_EINVAL, "svae: sequence length %d outside [1, max_len = %d]", T, s->Tmax);
+    return RTX_OK;
+}
+
+extern "C" {
+
+int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
+{
+    RTX_CHECK(cfg && out, RTX_EINVAL, "svae_create: NULL argument");
+    RTX_CHECK(cfg->n_items > 0 && cfg->embed_size > 0 && cfg->rnn_size > 0 && cfg->max_len > 0, RTX_EINVAL, "svae_create: bad sizes");
+    RTX_CHECK(cfg->n_enc >= 1 && cfg->n_dec >= 1 && cfg->n_enc <= SV_MAX_LAYERS && cfg->n_dec <= SV_MAX_LAYERS, RTX_EINVAL,
+              "svae_create: bad layer counts %d/%d", cfg->n_enc, cfg->n_dec);
+    RTX_CHECK(cfg->enc_dims[0] == cfg->rnn_size, RTX_EINVAL, "svae_create: enc_dims[0] = %d must equal rnn_size = %d", cfg->enc_dims[0],
+              cfg->rnn_size);
+    RTX_CHECK(cfg->enc_dims[cfg->n_enc] == cfg->dec_dims[0], RTX_EINVAL, "svae_create: latent size mismatch");
+    RTX_CHECK(cfg->dec_dims[cfg->n_dec] == cfg->n_items, RTX_EINVAL, "svae_create: dec_dims[-1] = %d must equal n_items = %d",
+              cfg->dec_dims[cfg->n_dec], cfg->n_items);
+    RTX_CHECK(cfg->rnn_size <= 1024, RTX_EINVAL, "svae_create: rnn_size %d exceeds the LDS budget of the recurrent kernels (1024)", cfg->rnn_size);
+    RTX_CHECK(2 * (cfg->n_enc + cfg->n_dec) + 5 <= RTX_MAX_TENSORS, RTX_EINVAL, "svae_create: too many parameter tensors for one Adam launch");
+    int ndev = 0;
+    hipError_t h = hipGetDeviceCount(&ndev);
+    RTX_CHECK(h == hipSuccess && ndev > 0, RTX_EHIP, "no HIP device available (%s): librectorch_hip has no CPU path", hipGetErrorString(h));
+    rtx_svae* s = new rtx_svae();
+    s->cfg = *cfg;
+    s->I = cfg->n_items; s->E = cfg->embed_size; s->R = cfg->rnn_size; s->Z = cfg->enc_dims[cfg->n_enc];
+    s->n_enc = cfg->n_enc; s->NL = cfg->n_enc + cfg->n_dec; s->Tmax = cfg->max_len;
+    for (int i = 0; i < cfg->n_enc; ++i) {
+        SvLayer l;
+        l.in = cfg->enc_dims[i];
+        l.out = (i == cfg->n_enc - 1) ? 2 * cfg->enc_dims[i + 1] : cfg->enc_dims[i + 1];   // mu | logvar (nets.py:262-265)
+        l.tanh_act = (i != cfg->n_enc - 1);                                                   // VAE_net.encode (nets.py:287-294)
+        s->L.push_back(l);
+    }
+    for (int i = 0; i < cfg->n_dec; ++i) {
+        SvLayer l;
+        l.in = cfg->dec_dims[i]; l.out = cfg->dec_dims[i + 1];
+        l.tanh_act = (i != cfg->n_dec - 1);                                                   // SVAE_net.decode (nets.py:683-687)
+        s->L.push_back(l);
+    }
+    s->n_tensors = 2 * s->NL + 5;
+    s->params.assign(s->n_tensors, nullptr);
+    s->grads = s->m = s->v = s->params;
+    const size_t T = s->Tmax, R = s->R, E = s->E, Z = s->Z;
+    int rc = RTX_OK;
+#define SV_ALLOC(p, n) do { rc = sv_alloc(s, &(p), (n)); if (rc) { rtx_svae_destroy(s); return rc; } } while (0)
+    SV_ALLOC(s->X, T * E); SV_ALLOC(s->GI, T * 3 * R); SV_ALLOC(s->H, (T + 1) * R);
+    SV_ALLOC(s->Gr, T * R); SV_ALLOC(s->Gz, T * R); SV_ALLOC(s->Gn, T * R); SV_ALLOC(s->Ghn, T * R);
+    SV_ALLOC(s->mu, T * Z); SV_ALLOC(s->lv, T * Z); SV_ALLOC(s->eps, T * Z); SV_ALLOC(s->zl, T * Z); SV_ALLOC(s->dz, T * Z);
+    SV_ALLOC(s->dH, T * R); SV_ALLOC(s->dGI, T * 3 * R); SV_ALLOC(s->dGH, T * 3 * R); SV_ALLOC(s->dX, T * E);
+    SV_ALLOC(s->row_loss, T); SV_ALLOC(s->tsum, T); SV_ALLOC(s->kl_rows, T);
+    for (auto& l : s->L) { SV_ALLOC(l.A, T * l.out); SV_ALLOC(l.D, T * l.out); }
+#undef SV_ALLOC
+    const size_t lds_bwd = sizeof(float) * (4 * R + 16 * R);
+    if (hipFuncSetAttribute((const void*)k_sv_gru_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd) != hipSuccess) {
+        rtx_set_error("svae_create: cannot reserve %zu bytes of LDS for the GRU backward kernel", lds_bwd);
+        rtx_svae_destroy(s);
+        return RTX_EHIP;
+    }
+    *out = s;
+    return RTX_OK;
+}
+
+int rtx_svae_destroy(rtx_svae* s)
+{
+    if (!s) return RTX_OK;
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return RTX_OK;
+}
+
+int32_t rtx_svae_n_tensors(const rtx_svae* s) { return s ? s->n_tensors : 0; }
+
+int rtx_svae_tensor_shape(const rtx_svae* s, int32_t t, int32_t* rows, int32_t* cols)
+{
+    RTX_CHECK(s && t >= 0 && t < s->n_tensors && rows && cols, RTX_EINVAL, "svae_tensor_shape: bad arguments");
+    int r, c;
+    sv_shape(s, t, &r, &c);
+    *rows = r; *cols = c;
+    return RTX_OK;
+}
+
+int rtx_svae_bind(rtx_svae* s, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq)
+{
+    RTX_CHECK(s && params, RTX_EINVAL, "svae_bind: NULL argument");
+    for (int t = 0; t < s->n_tensors; ++t) {
+        RTX_CHECK(params[t], RTX_EINVAL, "svae_bind: parameter %d is NULL", t);
+        s->params[t] = params[t];
+    }
+    s->bound = true;
+    s->can_train = grads && exp_avg && exp_avg_sq;
+    if (s->can_train)
+        for (int t = 0; t < s->n_tensors; ++t) {
+            RTX_CHECK(grads[t] && exp_avg[t] && exp_avg_sq[t], RTX_EINVAL, "svae_bind: training buffer %d is NULL", t);
+            s->grads[t] = grads[t]; s->m[t] = exp_avg[t]; s->v[t] = exp_avg_sq[t];
+        }
+    return RTX_OK;
+}
+
+int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* eps_noise, uint64_t seed, uint64_t offset,
+                     int32_t remove_train, float* logits_all, float* logits_last, float* mu, float* logvar, void* stream)
+{
+    RTX_TRY(sv_check(s, items, T, false));
+    hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(sv_forward(s, items, T, eps_noise, seed, offset, st));
+    const float* Y = s->L.back().A;
+    const size_t I = s->I;
+    if (logits_all) RTX_HIP(hipMemcpyAsync(logits_all, Y, sizeof(float) * T * I, hipMemcpyDeviceToDevice, st));
+    if (logits_last) {
+        RTX_HIP(hipMemcpyAsync(logits_last, Y + (size_t)(T - 1) * I, sizeof(float) * I, hipMemcpyDeviceToDevice, st));
+        if (remove_train) hipLaunchKernelGGL(k_sv_mask_items, dim3(1), dim3(256), 0, st, items, T, logits_last);   // models.py:1633-1634
+    }
+    if (mu) RTX_HIP(hipMemcpyAsync(mu, s->mu, sizeof(float) * T * s->Z, hipMemcpyDeviceToDevice, st));
+    if (logvar) RTX_HIP(hipMemcpyAsync(logvar, s->lv, sizeof(float) * T * s->Z, hipMemcpyDeviceToDevice, st));
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
+                        const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream)
+{
+    RTX_TRY(sv_check(s, items, T, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "svae_train_step: step count must be >= 1");
+    RTX_CHECK((target_indptr && target_indices) || target_dense, RTX_EINVAL, "svae_train_step: no target");
+    hipStream_t st = (hipStream_t)stream;
+    const int E = s->E, R = s->R, Z = s->Z, I = s->I, NL = s->NL;
+    const float inv_d = step->inv_batch;                 // 1 / (number of ones in the target), models.py:1623
+    const float beta_over_T = step->beta / (float)T;     // beta * mean over the time steps, models.py:1624-1625
+    RTX_TRY(sv_forward(s, items, T, step->eps_noise, step->seed, step->offset, st));
+    // ---- loss and dlogits
+    SvLayer& last = s->L[NL - 1];
+    hipLaunchKernelGGL(k_sv_loss, dim3(T), dim3(256), 0, st, last.A, T, I, target_indptr, target_indices, target_dense, inv_d, last.D,
+                       s->row_loss);
+    // ---- backward through decoder and encoder.  D of layer l = gradient w.r.t. its pre-activation
+    for (int li = NL - 1; li >= 0; --li) {
+        SvLayer& l = s->L[li];
+        const float* in;
+        long ld_in;
+        if (li == 0) { in = s->H + R; ld_in = R; }
+        else if (li == s->n_enc) { in = s->zl; ld_in = Z; }
+        else { in = s->L[li - 1].A; ld_in = s->L[li - 1].out; }
+        // dW[out][in] = sum_t D[t][out] * in[t][in];  db = column sums
+        RTX_TRY(sv_gemm(st, l.D, 1, l.out, in, 1, ld_in, s->grads[2 * li], l.in, l.out, l.in, T));
+        hipLaunchKernelGGL(k_sv_colsum, dim3((l.out + 255) / 256), dim3(256), 0, st, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]);
+        // gradient w.r.t. the layer input: [T][in] = D [T][out] x W [out][in]
+        if (li == 0) {
+            RTX_TRY(sv_gemm(st, l.D, l.out, 1, s->params[0], 1, l.in, s->dH, R, T, R, l.out));
+        } else if (li == s->n_enc) {
+            RTX_TRY(sv_gemm(st, l.D, l.out, 1, s->params[2 * li], 1, l.in, s->dz, Z, T, Z, l.out));
+            hipLaunchKernelGGL(k_sv_reparam_bwd, dim3(T), dim3(256), 0, st, s->dz, s->mu, s->lv, s->eps, T, Z, beta_over_T, s->L[li - 1].D,
+                               s->kl_rows);
+        } else {
+            SvLayer& p = s->L[li - 1];   // tanh layer: D_prev = (D W) * (1 - A_prev^2)
+            RTX_TRY(sv_gemm(st, l.D, l.out, 1, s->params[2 * li], 1, l.in, p.D, p.out, T, p.out, l.out, SV_EPI_TANH_GRAD, nullptr, p.A, p.out));
+        }
+    }
+    hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, loss_out, loss_accum);
+    // ---- GRU backward through time, then its weight gradients over all steps at once
+    hipLaunchKernelGGL(k_sv_gru_bwd, dim3(1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], T, R, s->H, s->Gr,
+                       s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
+    RTX_TRY(sv_gemm(st, s->dGH, 1, 3 * R, s->H, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));          // dW_hh = dGH^T H_prev
+    hipLaunchKernelGGL(k_sv_colsum, dim3((3 * R + 255) / 256), dim3(256), 0, st, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]);
+    RTX_TRY(sv_gemm(st, s->dGI, 1, 3 * R, s->X, 1, E, s->grads[sv_tail(s, SV_T_WIH)], E, 3 * R, E, T));          // dW_ih = dGI^T X
+    hipLaunchKernelGGL(k_sv_colsum, dim3((3 * R + 255) / 256), dim3(256), 0, st, s->dGI, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BIH)]);
+    RTX_TRY(sv_gemm(st, s->dGI, 3 * R, 1, s->params[sv_tail(s, SV_T_WIH)], 1, E, s->dX, E, T, E, 3 * R));        // dX = dGI W_ih
+    RTX_HIP(hipMemsetAsync(s->grads[sv_tail(s, SV_T_EMB)], 0, sizeof(float) * (size_t)I * E, st));
+    hipLaunchKernelGGL(k_sv_embed_grad, dim3(T), dim3(256), 0, st, items, T, E, s->dX, s->grads[sv_tail(s, SV_T_EMB)]);
+    RTX_HIP(hipGetLastError());
+    // ---- torch.optim.Adam (coupled weight decay 5e-3, models.py:1618-1620) over every tensor
+    RtxAdamArgs a = {};
+    a.n = 0;
+    for (int t = 0; t < s->n_tensors; ++t) {
+        RtxAdamTensor& w = a.t[a.n++];
+        int r, c;
+        sv_shape(s, t, &r, &c);
+        w.p = s->params[t]; w.g = s->grads[t]; w.g16 = nullptr; w.m = s->m[t]; w.v = s->v[t];
+        w.sh = nullptr; w.shT = nullptr; w.ld_sh = 0; w.ld_shT = 0;
+        if (c == 1) { w.rows = 1; w.cols = r; } else { w.rows = r; w.cols = c; }
+    }
+    a.update = 1;
+    const double bc1 = 1.0 - pow((double)step->beta1, (double)step->step);
+    const double bc2 = 1.0 - pow((double)step->beta2, (double)step->step);
+    a.step_size = (float)((double)step->lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
+    a.grad_scale = 1.f; a.lam = 0.f; a.sumsq = nullptr;
+    return rtx_launch_adam(a, 0, st);
+}
+
+}  // extern "C"

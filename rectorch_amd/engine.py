@@ -363,3 +363,106 @@ def cast_f32_bf16(src, dst):
     """``dst`` (bfloat16) = round-to-nearest-even of ``src`` (float32), same number of elements, on the current stream."""
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
     check(lib().rtx_cast_f32_bf16(_ptr(src), _ptr(dst), src.numel(), stream_ptr()))
+
+
+class SvaeTarget:
+    """Compact loss target of one SVAE sequence: the multi-hot rows of the reference's ``y_batch_s`` [1, T, n_items]
+    (samplers.py:539-562) as a CSR over the T steps, plus the likelihood normaliser ``d`` the reference's training path
+    ends up with (the ones of the FIRST step: ``train_batch`` flattens the target before ``loss_function`` sums
+    ``x[0, :n_items]``, models.py:822 + 1623)."""
+    __slots__ = ("indptr", "indices", "d", "n_steps")
+
+    def __init__(self, rows, device="cuda"):
+        """``rows``: list (one per time step) of distinct item ids"""
+        ptr = np.zeros(len(rows) + 1, dtype=np.int64)
+        for t, r in enumerate(rows):
+            ptr[t + 1] = ptr[t] + len(r)
+        idx = np.fromiter((i for r in rows for i in r), dtype=np.int32, count=int(ptr[-1]))
+        self.indptr = torch.from_numpy(ptr).to(device)
+        self.indices = torch.from_numpy(idx).to(device)
+        self.d = float(len(rows[0])) if rows else 0.0
+        self.n_steps = len(rows)
+
+
+class SvaeEngine:
+    """One ``rtx_svae``: the SVAE network's compute state (embedding -> GRU -> VAE head -> decoder, float32), bound to
+    the network's parameters and, for training, to gradient buffers and the Adam moments (see :class:`Engine`)."""
+
+    def __init__(self, n_items, embed_size, rnn_size, enc_dims, dec_dims, max_len=256):
+        _lib.require_gpu()
+        cfg = _lib.SvaeCfg()
+        cfg.n_items, cfg.embed_size, cfg.rnn_size = int(n_items), int(embed_size), int(rnn_size)
+        if len(enc_dims) - 1 > _lib.MAX_LAYERS or len(dec_dims) - 1 > _lib.MAX_LAYERS:
+            raise _lib.RtxError("at most %d layers per encoder/decoder are supported" % _lib.MAX_LAYERS)
+        cfg.n_enc, cfg.n_dec = len(enc_dims) - 1, len(dec_dims) - 1
+        for i, d in enumerate(enc_dims):
+            cfg.enc_dims[i] = int(d)
+        for i, d in enumerate(dec_dims):
+            cfg.dec_dims[i] = int(d)
+        cfg.max_len = int(max_len)
+        self.max_len, self.n_items, self.latent = int(max_len), int(n_items), int(enc_dims[-1])
+        h = C.c_void_p()
+        check(lib().rtx_svae_create(C.byref(cfg), C.byref(h)))
+        self.handle = h
+        self.n_tensors = lib().rtx_svae_n_tensors(h)
+        self._keep = []
+
+    def bind(self, params, grads=None, exp_avg=None, exp_avg_sq=None):
+        n = self.n_tensors
+        assert len(params) == n, "expected %d parameter tensors, got %d" % (n, len(params))
+        rows, cols = C.c_int32(), C.c_int32()
+        for t, p in enumerate(params):
+            check(lib().rtx_svae_tensor_shape(self.handle, t, C.byref(rows), C.byref(cols)))
+            want = (rows.value,) if cols.value == 1 and p.dim() == 1 else (rows.value, cols.value)
+            if tuple(p.shape) != want or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                raise _lib.RtxError("parameter %d must be a contiguous float32 device tensor of shape %s, got %s %s on %s"
+                                    % (t, want, tuple(p.shape), p.dtype, p.device))
+
+        def arr(ts):
+            if ts is None:
+                return None
+            return (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._keep = [params, grads, exp_avg, exp_avg_sq]
+        check(lib().rtx_svae_bind(self.handle, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq)))
+
+    @staticmethod
+    def _items(x):
+        return x.reshape(-1).to("cuda", torch.int32).contiguous()
+
+    def forward(self, x, noise=None, seed=0, remove_train=False, want_all=True):
+        """SVAE_net.forward on one sequence: (logits [T, n_items] or None, last-step logits [n_items], mu, logvar)."""
+        items = self._items(x)
+        T = int(items.numel())
+        dev = items.device
+        la = torch.empty((T, self.n_items), dtype=torch.float32, device=dev) if want_all else None
+        ll = torch.empty((self.n_items,), dtype=torch.float32, device=dev)
+        mu = torch.empty((T, self.latent), dtype=torch.float32, device=dev)
+        lv = torch.empty_like(mu)
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+        check(lib().rtx_svae_forward(self.handle, _ptr(items), T, _ptr(noise), C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(0),
+                                     int(remove_train), _ptr(la), _ptr(ll), _ptr(mu), _ptr(lv), stream_ptr()))
+        return la, ll, mu, lv
+
+    def train_step(self, x, target, step, loss_out, loss_accum=None):
+        items = self._items(x)
+        T = int(items.numel())
+        if isinstance(target, SvaeTarget):
+            assert target.n_steps == T, "the target has %d steps, the sequence %d" % (target.n_steps, T)
+            ptr, idx, dense = target.indptr, target.indices, None
+        else:
+            dense = target.reshape(T, -1).to(items.device, torch.float32).contiguous()
+            if dense.shape[1] != self.n_items:
+                raise _lib.RtxError("the target must be [1, T, %d], got %s" % (self.n_items, tuple(target.shape)))
+            ptr = idx = None
+        check(lib().rtx_svae_train_step(self.handle, _ptr(items), T, _ptr(ptr), _ptr(idx), _ptr(dense), C.byref(step), _ptr(loss_out),
+                                        _ptr(loss_accum), stream_ptr()))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            try:
+                lib().rtx_svae_destroy(h)
+            except Exception:
+                pass
+            self.handle = None

@@ -19,11 +19,11 @@ import torch
 import torch.optim as optim
 
 from . import _lib
-from .engine import CsrMatrix, EaseSolver, RowBatch, multinomial_loss
+from .engine import CsrMatrix, EaseSolver, RowBatch, SvaeTarget, multinomial_loss
 from .evaluation import ValidFunc, evaluate
 from .samplers import DataSampler
 
-__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE', 'CMultiVAE', 'EASE']
+__all__ = ['RecSysModel', 'TorchNNTrainer', 'AETrainer', 'VAE', 'MultiVAE', 'MultiDAE', 'CMultiVAE', 'EASE', 'SVAE']
 
 logger = logging.getLogger(__name__)
 
@@ -647,3 +647,114 @@ class EASE(RecSysModel):
 
     def __repr__(self):
         return str(self)
+
+
+class SVAE(MultiVAE):
+    r"""Sequential Variational Autoencoders for Collaborative Filtering (reference models.py:1581-1635).
+
+    One user sequence per optimizer step, as in the reference: ``train_batch(x, y)`` with ``x`` the LongTensor
+    ``[1, T]`` of the user's items and ``y`` the multi-hot targets ``[1, T, n_items]`` yielded by
+    :class:`rectorch_amd.samplers.SVAE_Sampler` (or its compact :class:`rectorch_amd.engine.SvaeTarget`).  The whole
+    step -- embedding, GRU, VAE head, decoder, loss, back-propagation through time, Adam with ``weight_decay=5e-3`` --
+    is one call into librectorch_hip (``rtx_svae_train_step``), in float32.
+
+    Parameters
+    ----------
+    svae_net : :class:`rectorch_amd.nets.SVAE_net`
+    beta, anneal_steps, learning_rate
+        As in :class:`MultiVAE`.
+    """
+    def __init__(self,
+                 svae_net,
+                 beta=1.,
+                 anneal_steps=0,
+                 learning_rate=1e-3):
+        super(SVAE, self).__init__(svae_net,
+                                   beta=beta,
+                                   anneal_steps=anneal_steps,
+                                   learning_rate=learning_rate,
+                                   numerics="fp32",
+                                   predict_numerics="fp32")
+        self.optimizer = optim.Adam(self.network.parameters(),
+                                    lr=learning_rate,
+                                    weight_decay=5e-3)
+
+    def loss_function(self, recon_x, x, mu, logvar, beta=1.0):
+        r"""SVAE loss (reference models.py:1622-1626): :math:`\sum_t \mathrm{NLL}_t / d + \beta \cdot
+        \mathrm{mean}_t \mathrm{KL}_t` with :math:`d` = ``sum(x[0, :n_items])`` -- all the ones of a ``[1, T, n_items]``
+        target, but only those of the first time step when the target arrives flattened, as it does from
+        ``train_batch``.  Computed by the HIP multinomial-loss kernel on the ``T`` rows."""
+        T, n_items = recon_x.shape[1], recon_x.shape[2]
+        d = float(torch.sum(x[0, :n_items]))
+        y = x.reshape(T, n_items).to(recon_x.device, torch.float32)
+        scale = T / d
+        return scale * multinomial_loss(recon_x.reshape(T, n_items), y, mu, logvar, beta / scale)
+
+    def train_batch(self, tr_batch, te_batch=None):
+        r"""Training of a single sequence (reference models.py:817-835 with the SVAE loss and optimizer)."""
+        _lib.require_gpu()
+        if te_batch is None:
+            raise ValueError("SVAE.train_batch needs the target sequence (SVAE_Sampler yields it)")
+        st, params, m, v = self._ensure_train_state()
+        T = int(tr_batch.numel())
+        eng = self.network.svae_engine(T, train_buffers=(st.grads, m, v))
+        if isinstance(te_batch, SvaeTarget):
+            d = te_batch.d
+        else:
+            # the reference flattens the target to [1, T * n_items] before loss_function reads x[0, :n_items]
+            d = float(te_batch.reshape(te_batch.shape[0], -1)[0, :eng.n_items].sum())
+        if self.annealing:
+            anneal_beta = min(self.beta, 1. * self.gradient_updates / self.anneal_steps)
+        else:
+            anneal_beta = self.beta
+        g = self.optimizer.param_groups[0]
+        st.adam_step += 1
+        from .nets import draw_seed
+        noise = self._rtx.inject[1] if self._rtx.inject else None     # parity tests: eps captured from the reference's RNG
+        step = _lib.Step()
+        step.beta, step.lam = float(anneal_beta), 0.0
+        step.inv_batch = (1.0 / d) if d != 0 else float("inf")
+        step.lr, step.beta1, step.beta2 = float(g['lr']), float(g['betas'][0]), float(g['betas'][1])
+        step.eps, step.weight_decay = float(g['eps']), float(g['weight_decay'])
+        step.step, step.flags = st.adam_step, 0
+        step.seed, step.offset = draw_seed() & (2 ** 64 - 1), 0
+        step.dropout_mask = None
+        step.eps_noise = None if noise is None else noise.data_ptr()
+        eng.train_step(tr_batch, te_batch, step, st.loss_buf[0:1], st.loss_buf[1:2])
+        self.gradient_updates += 1.
+        return st.loss_buf[0].item()
+
+    def train_epoch(self, epoch, train_loader, verbose=1):
+        r"""One pass over the user sequences (reference models.py:401-422, the loop of ``AETrainer``)."""
+        self.network.train()
+        train_loss = 0
+        partial_loss = 0
+        epoch_start_time = time.time()
+        start_time = time.time()
+        log_delay = max(10, len(train_loader) // 10**verbose)
+        for batch_idx, (data, gt) in enumerate(train_loader):
+            partial_loss += self.train_batch(data, gt)
+            if (batch_idx+1) % log_delay == 0:
+                elapsed = time.time() - start_time
+                logger.info('| epoch %d | %d/%d batches | ms/batch %.2f | loss %.2f |',
+                            epoch, (batch_idx+1), len(train_loader),
+                            elapsed * 1000 / log_delay,
+                            partial_loss / log_delay)
+                train_loss += partial_loss
+                partial_loss = 0.0
+                start_time = time.time()
+        total_loss = (train_loss + partial_loss) / len(train_loader)
+        time_diff = time.time() - epoch_start_time
+        logger.info("| epoch %d | loss %.4f | total time: %.2fs |", epoch, total_loss, time_diff)
+
+    def predict(self, x, remove_train=True):
+        r"""Scores of the step after the sequence ``x`` (reference models.py:1628-1635): ``(recon_x[:, -1, :], mu,
+        logvar)``; with ``remove_train`` the items of ``x`` are scored :math:`-\infty`.  The latent code is sampled
+        (the reference's ``VAE_net._reparameterize`` has no eval branch): seed torch's generator for repeatable scores."""
+        _lib.require_gpu()
+        self.network.eval()
+        from .nets import draw_seed
+        noise = self._rtx.inject[1] if self._rtx.inject else None
+        eng = self.network.svae_engine(int(x.numel()))
+        _, last, mu, logvar = eng.forward(x, noise=noise, seed=draw_seed(), remove_train=remove_train, want_all=False)
+        return last.view(1, -1), mu, logvar

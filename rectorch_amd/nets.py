@@ -20,7 +20,7 @@ from torch.nn.init import normal_ as normal_init
 from . import _lib
 from .engine import Engine
 
-__all__ = ['AE_net', 'MultiDAE_net', 'VAE_net', 'MultiVAE_net']
+__all__ = ['AE_net', 'MultiDAE_net', 'VAE_net', 'MultiVAE_net', 'CMultiVAE_net', 'SVAE_net']
 
 logger = logging.getLogger(__name__)
 
@@ -257,3 +257,81 @@ class CMultiVAE_net(MultiVAE_net):
         self.dec_layers = nn.ModuleList(
             [nn.Linear(d_in, d_out) for d_in, d_out in zip(self.dec_dims[:-1], self.dec_dims[1:])])
         self.init_weights()
+
+
+class SVAE_net(VAE_net):
+    """Sequential Variational Autoencoder network (reference nets.py:624-693): item embedding -> one-layer GRU
+    (batch_first) -> the VAE head of :class:`VAE_net` (tanh hidden layers, linear ``mu | logvar``; **always** sampled,
+    in eval too, because ``_reparameterize`` is the base class's) -> tanh MLP decoder with a linear output.
+
+    The ``nn.Embedding`` / ``nn.GRU`` / ``nn.Linear`` modules hold the parameters (same ``state_dict`` keys as the
+    reference: ``enc_layers.*``, ``dec_layers.*``, ``item_embed.weight``, ``gru.weight_ih_l0`` ...); the computation is
+    the ``rtx_svae`` engine of librectorch_hip.
+
+    Parameters
+    ----------
+    n_items : :obj:`int`
+        Number of items.
+    embed_size : :obj:`int`
+        Size of the embedding for the items.
+    rnn_size : :obj:`int`
+        Size of the recurrent layer of the GRU part of the network.
+    dec_dims, enc_dims : :obj:`list` of :obj:`int`
+        See :class:`AE_net` (``enc_dims[0]`` must be ``rnn_size``).
+    """
+    def __init__(self, n_items, embed_size, rnn_size, dec_dims, enc_dims):
+        super(SVAE_net, self).__init__(dec_dims, enc_dims)
+        self.enc_dims = enc_dims
+        self.dec_dims = dec_dims
+        self.n_items = n_items
+        self.embed_size = embed_size
+        self.rnn_size = rnn_size
+        self.item_embed = nn.Embedding(n_items, embed_size)
+        self.gru = nn.GRU(embed_size, rnn_size, batch_first=True, num_layers=1)
+        self.init_weights()
+        self._svae_engine = None
+
+    def init_weights(self):
+        r"""xavier_normal weights for the encoder / decoder layers, biases left at their defaults (reference
+        nets.py:689-693)."""
+        for layer in self.enc_layers:
+            nn.init.xavier_normal_(layer.weight)
+        for layer in self.dec_layers:
+            nn.init.xavier_normal_(layer.weight)
+
+    def _param_list(self):
+        # the order of SVAE_net.parameters(): the MLPs are registered by VAE_net.__init__, then embedding and GRU
+        ps = []
+        for layer in list(self.enc_layers) + list(self.dec_layers):
+            ps += [layer.weight, layer.bias]
+        return ps + [self.item_embed.weight, self.gru.weight_ih_l0, self.gru.weight_hh_l0, self.gru.bias_ih_l0,
+                     self.gru.bias_hh_l0]
+
+    def svae_engine(self, seq_len=1, train_buffers=None):
+        """The ``rtx_svae`` engine of this network, grown when a longer sequence arrives and re-bound when the parameter
+        (or training-buffer) storage changes.  There are no compute copies: the kernels read the parameters in place."""
+        from .engine import SvaeEngine
+        self._device()
+        eng = self._svae_engine
+        if eng is None or eng.max_len < seq_len:
+            eng = SvaeEngine(self.n_items, self.embed_size, self.rnn_size, self.enc_dims, self.dec_dims,
+                             max_len=max(256, 2 * int(seq_len)))
+            self._svae_engine = eng
+        params = [p.data for p in self._param_list()]
+        pkey = tuple(t.data_ptr() for t in params)
+        tkey = None if train_buffers is None else tuple(t.data_ptr() for ts in train_buffers for t in ts)
+        if getattr(eng, "param_key", None) != pkey or (tkey is not None and getattr(eng, "train_key", None) != tkey):
+            if train_buffers is not None:
+                eng.bind(params, *train_buffers)
+            else:
+                eng.bind(params)
+            eng.param_key, eng.train_key = pkey, tkey
+        return eng
+
+    def _rtx_mark_updated(self, numerics):
+        pass
+
+    def forward(self, x):
+        """``x``: LongTensor [1, T].  Returns ``(dec_out [1, T, n_items], mu [T, latent], logvar [T, latent])``."""
+        la, _, mu, logvar = self.svae_engine(x.numel()).forward(x, seed=draw_seed())
+        return la.view(x.shape[0], x.shape[1], -1), mu, logvar

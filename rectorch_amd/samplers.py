@@ -11,10 +11,10 @@ import numpy as np
 import torch
 from scipy.sparse import csr_matrix, hstack
 
-from .engine import CsrMatrix, RowBatch
+from .engine import CsrMatrix, RowBatch, SvaeTarget
 
 __all__ = ['Sampler', 'DataSampler', 'ConditionedDataSampler', 'BalancedConditionedDataSampler',
-           'EmptyConditionedDataSampler']
+           'EmptyConditionedDataSampler', 'SVAE_Sampler']
 
 
 class Sampler():
@@ -330,3 +330,88 @@ class EmptyConditionedDataSampler(Sampler):
                                torch.arange(len(rows), dtype=torch.int32, device="cuda"))
             else:
                 yield torch.FloatTensor(data_tr.toarray()), torch.FloatTensor(data_te.toarray())
+
+
+class SVAE_Sampler(Sampler):
+    r"""Sampler of user sequences for :class:`rectorch_amd.models.SVAE` (reference samplers.py:446-571): one user per
+    batch, ``x`` = the LongTensor ``[1, T]`` of all but the user's last item, ``y`` = the multi-hot targets
+    ``[1, T, num_items]``: at step *t* the next item (``'next'``), the next ``k`` items (``'next_k'``) or all the
+    remaining ones (``'postfix'``); with ``is_training=False`` a single row ``[1, 1, num_items]`` holding the user's
+    test items.
+
+    With ``sparse=True`` (not in the reference) ``y`` is a :class:`rectorch_amd.engine.SvaeTarget` -- the same rows as
+    a CSR on the device -- so no ``T x num_items`` dense tensor is built or copied per user.
+
+    Parameters
+    ----------
+    num_items : :obj:`int`
+        Number of items.
+    dict_data_tr : :obj:`dict` (key :obj:`int` - value :obj:`list` of :obj:`int`)
+        The users' item sequences (inner ids), keys ``0 .. n_users - 1``.
+    dict_data_te : :obj:`dict` or :obj:`None` [optional]
+        The users' test items (needed when ``is_training`` is ``False``), by default :obj:`None`.
+    pred_type : :obj:`str` in {``'next_k'``, ``'next'``, ``'postfix'``} [optional]
+        The variant of the target, by default ``'next_k'``.
+    k : :obj:`int` [optional]
+        Number of items to predict in the ``'next_k'`` variant, by default 1.
+    shuffle : :obj:`bool` [optional]
+        Whether the users are visited in random order (global numpy RNG), by default ``True``.
+    is_training : :obj:`bool` [optional]
+        Whether the sampler is used during training, by default ``True``.
+    """
+    def __init__(self,
+                 num_items,
+                 dict_data_tr,
+                 dict_data_te=None,
+                 pred_type="next_k",
+                 k=1,
+                 shuffle=True,
+                 is_training=True,
+                 sparse=False):
+        super(SVAE_Sampler, self).__init__()
+        if pred_type == "next_k":
+            assert k >= 1, "If pred_type == 'next_k' then 'k' must be a positive integer."
+        self.pred_type = pred_type
+        self.dict_data_tr = dict_data_tr
+        self.dict_data_te = dict_data_te
+        self.shuffle = shuffle
+        self.num_items = num_items
+        self.k = k
+        self.is_training = is_training
+        self.sparse = sparse
+
+    def __len__(self):
+        return len(self.dict_data_tr)
+
+    def _target_rows(self, user):
+        """the distinct target items of every time step of ``user`` (list of lists)"""
+        seq = self.dict_data_tr[user]
+        if not self.is_training:
+            return [list(dict.fromkeys(self.dict_data_te[user]))]
+        rows = []
+        for t in range(len(seq) - 1):
+            if self.pred_type == 'next':
+                r = [seq[t + 1]]
+            elif self.pred_type == 'next_k':
+                r = seq[t + 1:][:self.k]
+            elif self.pred_type == 'postfix':
+                r = seq[t + 1:]
+            else:
+                r = []
+            rows.append(list(dict.fromkeys(r)))
+        return rows
+
+    def __iter__(self):
+        idxlist = list(range(len(self.dict_data_tr)))
+        if self.shuffle:
+            np.random.shuffle(idxlist)
+        for user in idxlist:
+            rows = self._target_rows(user)
+            x = torch.LongTensor([self.dict_data_tr[user][:-1]])
+            if self.sparse:
+                yield x, SvaeTarget(rows)
+                continue
+            y = torch.zeros(1, len(rows), self.num_items)
+            for t, r in enumerate(rows):
+                y[0, t, r] = 1.
+            yield x, y

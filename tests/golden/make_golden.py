@@ -26,10 +26,10 @@ import torch                             # noqa: E402
 import torch.nn.functional as F          # noqa: E402
 from scipy.sparse import csr_matrix      # noqa: E402
 
-from rectorch.nets import MultiVAE_net, MultiDAE_net, CMultiVAE_net  # noqa: E402
-from rectorch.models import MultiVAE, MultiDAE, EASE, CMultiVAE  # noqa: E402
+from rectorch.nets import MultiVAE_net, MultiDAE_net, CMultiVAE_net, SVAE_net  # noqa: E402
+from rectorch.models import MultiVAE, MultiDAE, EASE, CMultiVAE, SVAE  # noqa: E402
 from rectorch.samplers import DataSampler, ConditionedDataSampler, BalancedConditionedDataSampler, \
-    EmptyConditionedDataSampler                                 # noqa: E402
+    EmptyConditionedDataSampler, SVAE_Sampler                   # noqa: E402
 from rectorch.evaluation import evaluate                        # noqa: E402
 from rectorch.metrics import Metrics                            # noqa: E402
 
@@ -487,7 +487,81 @@ def g11():
     save("g11_conditioned_samplers", **out)
 
 
+def g12():
+    """SVAE (reference nets.py:624-693, models.py:1581-1635, samplers.py:446-571): forward / predict with replayed
+    noise, three train_batch steps (loss, first-step gradients, parameters, Adam moments), sampler targets."""
+    I, E, R, H, L = 40, 6, 10, 8, 4
+    torch.manual_seed(120)
+    net = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, 12, I], enc_dims=[R, H, L])
+    sd0 = sd_np(net)
+    model = SVAE(net, beta=0.4, anneal_steps=2)
+    out = dict(flat("sd0__", sd0))
+    out["dims"] = np.array([I, E, R, H, L, 12])
+    out["meta"] = np.array([0.4, 2, 1e-3, 5e-3], dtype=np.float64)
+    out["param_names"] = np.array([k for k, _ in net.named_parameters()])
+    rng = np.random.default_rng(12)
+    seqs = {0: rng.integers(0, I, size=9).tolist(), 1: rng.integers(0, I, size=14).tolist(),
+            2: [3, 7, 3, 11, 7, 2]}                                   # repeated items: embedding-gradient accumulation
+    sampler = SVAE_Sampler(num_items=I, dict_data_tr=seqs, dict_data_te=None, pred_type="next_k", k=2, shuffle=False,
+                           is_training=True)
+    batches = [(x.clone(), y.clone()) for x, y in sampler]
+    # predict before training, noise replayed from the seed (the VAE head samples in eval too)
+    xq = torch.LongTensor([[5, 1, 30, 5]])
+    torch.manual_seed(7)
+    eps_q = torch.randn(4, L).numpy()
+    torch.manual_seed(7)
+    pr, pmu, plv = model.predict(xq, remove_train=True)
+    out.update(pred_x=xq.numpy(), pred_eps=eps_q, pred=pr.numpy(), pred_mu=pmu.numpy(), pred_logvar=plv.numpy())
+    names = [k for k, _ in net.named_parameters()]
+    for t, (x, y) in enumerate(batches):
+        T = x.shape[1]
+        seed = 200 + t
+        torch.manual_seed(seed)
+        eps = torch.randn(T, L).numpy()
+        out["x_%d" % t] = x.numpy()
+        out["y_%d" % t] = y.numpy()
+        out["eps_%d" % t] = eps
+        ab = min(model.beta, model.gradient_updates / model.anneal_steps)
+        torch.manual_seed(seed)
+        net.train()
+        recon, mu, logvar = net(x)
+        # train_batch hands the target flattened to [1, T * n_items] (models.py:822), so likelihood_d (models.py:1623)
+        # counts the ones of the FIRST time step only
+        l_side = model.loss_function(recon, y.view(1, -1), mu, logvar, ab)
+        grads = torch.autograd.grad(l_side, list(net.parameters()))
+        for n, g in zip(names, grads):
+            out["grad_%d__%s" % (t, n.replace(".", "__"))] = g.numpy().copy()
+        out["logits_%d" % t] = recon.detach().numpy().copy()
+        out["likelihood_d_%d" % t] = np.float64(float(torch.sum(y.view(1, -1)[0, :I])))
+        torch.manual_seed(seed)
+        loss = model.train_batch(x, y)
+        assert abs(loss - l_side.item()) <= 1e-6 * max(1.0, abs(loss)), (loss, l_side.item())
+        out["loss_%d" % t] = np.float32(loss)
+        out["anneal_beta_%d" % t] = np.float32(ab)
+        out.update(flat("sd_%d__" % t, sd_np(net)))
+    out["n_steps"] = np.int64(len(batches))
+    save("g12_svae_steps", **out)
+    # sampler targets for the three prediction types and the test mode
+    so = {}
+    for pt in ("next", "next_k", "postfix"):
+        smp = SVAE_Sampler(num_items=I, dict_data_tr=seqs, dict_data_te=None, pred_type=pt, k=3, shuffle=False, is_training=True)
+        for u, (x, y) in enumerate(smp):
+            so["%s_x_%d" % (pt, u)] = x.numpy()
+            so["%s_y_%d" % (pt, u)] = y.numpy().astype(np.uint8)
+    te = {0: [1, 2], 1: [39], 2: [0, 5, 9]}
+    smp = SVAE_Sampler(num_items=I, dict_data_tr=seqs, dict_data_te=te, pred_type="next_k", k=1, shuffle=False, is_training=False)
+    for u, (x, y) in enumerate(smp):
+        so["test_x_%d" % u] = x.numpy()
+        so["test_y_%d" % u] = y.numpy().astype(np.uint8)
+    np.random.seed(3)
+    smp = SVAE_Sampler(num_items=I, dict_data_tr=seqs, dict_data_te=None, pred_type="next", shuffle=True, is_training=True)
+    so["shuffled_first_items"] = np.array([int(x[0, 0]) for x, _ in smp])
+    for u in seqs:
+        so["seq_%d" % u] = np.array(seqs[u])
+    save("g12_svae_sampler", **so)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
-        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11}[w]()
+        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}[w]()

@@ -778,3 +778,117 @@ def test_dp_path_world1_rccl():
     out = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "dp_world1_check.py"), str(port)],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DP_WORLD1_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+# ------------------------------------------------------------------------------------------------ SVAE
+def make_svae(g, **kw):
+    from rectorch_amd.nets import SVAE_net
+    from rectorch_amd.models import SVAE
+    I, E, R, H, L, D = [int(v) for v in g["dims"]]
+    net = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_from(g, "sd0__").items()})
+    net.to("cuda")
+    return net, SVAE(net, **kw)
+
+
+def test_g12_svae_predict_and_train_steps():
+    """float32 throughout: logits within 1e-5 of the reference, parameters after Adam (weight decay 5e-3) within 5e-6"""
+    g = load_golden("g12_svae_steps")
+    beta, anneal, lr, wd = [float(v) for v in g["meta"]]
+    net, model = make_svae(g, beta=beta, anneal_steps=int(anneal), learning_rate=lr)
+    assert [k for k, _ in net.named_parameters()] == list(g["param_names"])
+    assert model.optimizer.param_groups[0]["weight_decay"] == wd
+    model._rtx.inject = (None, dev(g["pred_eps"]))
+    pr, mu, lv = model.predict(torch.from_numpy(g["pred_x"]), remove_train=True)
+    assert pr.shape == (1, int(g["dims"][0])) and mu.shape == g["pred_mu"].shape
+    pr = pr.cpu().numpy()
+    assert np.array_equal(np.isneginf(pr), np.isneginf(g["pred"]))
+    fin = np.isfinite(pr)
+    assert rel(pr[fin], g["pred"][fin]) < 1e-5 and rel(mu.cpu(), g["pred_mu"]) < 1e-5 and rel(lv.cpu(), g["pred_logvar"]) < 1e-5
+    names = list(g["param_names"])
+    for t in range(int(g["n_steps"])):
+        model._rtx.inject = (None, dev(g["eps_%d" % t]))
+        loss = model.train_batch(torch.from_numpy(g["x_%d" % t]), torch.from_numpy(g["y_%d" % t]))
+        assert abs(loss - float(g["loss_%d" % t])) < 1e-5 * abs(float(g["loss_%d" % t])), (t, loss, float(g["loss_%d" % t]))
+        for k, prm in zip(names, net._param_list()):
+            gref = g["grad_%d__%s" % (t, k.replace(".", "__"))]
+            assert rel(prm.grad.cpu(), gref) < 2e-4, (t, k)
+            ref = g["sd_%d__%s" % (t, k.replace(".", "__"))]
+            assert float(np.max(np.abs(prm.detach().cpu().numpy() - ref))) < 5e-6, (t, k)
+    assert model.gradient_updates == float(g["n_steps"])
+    model._rtx.inject = None
+
+
+def test_svae_reference_api_train_save_load():
+    """the reference's own test_SVAE (tests/test_models.py:491-546), with the network on the MI355X, plus the compact
+    target form of the sampler"""
+    from rectorch_amd.nets import SVAE_net
+    from rectorch_amd.models import SVAE
+    from rectorch_amd.samplers import SVAE_Sampler
+    total_items = 7
+    net = SVAE_net(n_items=total_items, embed_size=2, rnn_size=2, dec_dims=[2, total_items], enc_dims=[2, 2]).to("cuda")
+    model = SVAE(net)
+    assert model.learning_rate == 1e-3 and model.network == net and isinstance(model.optimizer, torch.optim.Adam)
+    assert str(model) == repr(model)
+    tr = {0: [0, 1, 2, 3, 4, 5, 6], 1: [6, 5, 4, 3, 2, 1, 0], 2: [2, 1, 6, 0, 3]}
+    sampler = SVAE_Sampler(num_items=total_items, dict_data_tr=tr, dict_data_te=None, pred_type="next", k=2, shuffle=False,
+                           is_training=True)
+    x = torch.LongTensor([[1, 2, 5]])
+    pr = model.predict(x, True)[0]
+    assert pr.shape == (1, total_items) and torch.isneginf(pr[0, [1, 2, 5]]).all()
+    torch.manual_seed(12345)
+    out_1 = model.predict(x, False)[0]
+    model.train(sampler, num_epochs=10, verbose=4)
+    torch.manual_seed(12345)
+    out_2 = model.predict(x, False)[0]
+    assert not torch.all(out_1.eq(out_2))
+    tmp = tempfile.NamedTemporaryFile()
+    model.save_model(tmp.name, 1)
+    net2 = SVAE_net(n_items=total_items, embed_size=2, rnn_size=2, dec_dims=[2, total_items], enc_dims=[2, 2]).to("cuda")
+    model2 = SVAE(net2)
+    model2.load_model(tmp.name)
+    torch.manual_seed(12345)
+    out_1 = model.predict(x, False)[0]
+    torch.manual_seed(12345)
+    out_2 = model2.predict(x, False)[0]
+    assert torch.all(out_1.eq(out_2))
+    # compact targets drive the same step as the dense ones
+    losses = {}
+    for sparse in (False, True):
+        torch.manual_seed(5)
+        n = SVAE_net(n_items=total_items, embed_size=2, rnn_size=2, dec_dims=[2, total_items], enc_dims=[2, 2])
+        n.load_state_dict(net2.state_dict())
+        m = SVAE(n.to("cuda"))
+        smp = SVAE_Sampler(total_items, tr, None, pred_type="next_k", k=2, shuffle=False, sparse=sparse)
+        losses[sparse] = [m.train_batch(a, b) for a, b in smp]
+    np.testing.assert_allclose(losses[True], losses[False], rtol=1e-6)
+
+
+def test_svae_vs_oracle_longer_sequences():
+    """ml-1m-like widths (embedding 64, GRU 96, latent 32) and sequences of 1..300 steps against the numpy oracle"""
+    from oracle.svae_oracle import SvaeOracle
+    from rectorch_amd.nets import SVAE_net
+    from rectorch_amd.models import SVAE
+    torch.manual_seed(3)
+    I, E, R, H, L, D = 500, 64, 96, 80, 32, 72
+    net = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=0)
+    orc = SvaeOracle(sd, n_enc=2, n_dec=2, beta=0.2)
+    rng = np.random.RandomState(9)
+    for T in (1, 37, 300):
+        items = rng.randint(0, I, size=T)
+        y = np.zeros((T, I), dtype=np.float32)
+        for t in range(T):
+            y[t, rng.choice(I, size=3, replace=False)] = 1.0
+        eps = rng.randn(T, L).astype(np.float32)
+        model._rtx.inject = (None, dev(eps))
+        loss = model.train_batch(torch.from_numpy(items[None, :]), torch.from_numpy(y[None]))
+        lo = orc.train_batch(items, y.astype(np.float64), eps.astype(np.float64))
+        assert abs(loss - lo) < 2e-5 * abs(lo), (T, loss, lo)
+        for k, prm in zip(orc.keys, net._param_list()):
+            assert rel(prm.grad.cpu(), orc.last_grads[k]) < 5e-4, (T, k)
+            # Adam's normalised step turns a gradient that is round-off noise around zero into a +-lr move, so single
+            # elements may differ by a fraction of lr = 1e-3; everything else agrees to float32 round-off
+            dlt = np.abs(prm.detach().cpu().numpy() - orc.p[k])
+            assert float(dlt.max()) < 1e-3 and float(np.mean(dlt > 2e-5)) < 1e-4, (T, k, float(dlt.max()))

@@ -329,3 +329,34 @@ def test_conditioned_samplers_match_reference_g11():
         assert np.array_equal(a.numpy(), g["emp_tr_%d" % i]) and np.array_equal(b.numpy(), g["emp_te_%d" % i])
         n += 1
     assert n == int(g["emp_n_batches"])
+
+
+def test_svae_sampler_matches_reference_g12():
+    """x / y of every user for the three target types, the test mode and the shuffled order (reference
+    samplers.py:517-571), and the compact CSR form of the same targets"""
+    from rectorch_amd.samplers import SVAE_Sampler
+    g = load_golden("g12_svae_sampler")
+    seqs = {u: g["seq_%d" % u].tolist() for u in range(3)}
+    I = 40
+    for pt in ("next", "next_k", "postfix"):
+        smp = SVAE_Sampler(I, seqs, None, pred_type=pt, k=3, shuffle=False, is_training=True)
+        assert len(smp) == 3
+        for u, (x, y) in enumerate(smp):
+            assert isinstance(x, torch.LongTensor) and x.shape == (1, len(seqs[u]) - 1)
+            assert np.array_equal(x.numpy(), g["%s_x_%d" % (pt, u)])
+            assert np.array_equal(y.numpy().astype(np.uint8), g["%s_y_%d" % (pt, u)])
+            rows = smp._target_rows(u)
+            dense = np.zeros((len(rows), I), dtype=np.uint8)
+            for t, r in enumerate(rows):
+                assert len(set(r)) == len(r)
+                dense[t, r] = 1
+            assert np.array_equal(dense, g["%s_y_%d" % (pt, u)][0])
+    te = {0: [1, 2], 1: [39], 2: [0, 5, 9]}
+    smp = SVAE_Sampler(I, seqs, te, pred_type="next_k", k=1, shuffle=False, is_training=False)
+    for u, (x, y) in enumerate(smp):
+        assert np.array_equal(x.numpy(), g["test_x_%d" % u]) and np.array_equal(y.numpy().astype(np.uint8), g["test_y_%d" % u])
+    np.random.seed(3)
+    smp = SVAE_Sampler(I, seqs, None, pred_type="next", shuffle=True, is_training=True)
+    assert [int(x[0, 0]) for x, _ in smp] == g["shuffled_first_items"].tolist()
+    with pytest.raises(AssertionError):
+        SVAE_Sampler(I, seqs, None, pred_type="next_k", k=0)
