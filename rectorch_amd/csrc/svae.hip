@@ -19,6 +19,7 @@
 #include "rtx_kernels.h"
 
 #include <math.h>
+#include <algorithm>
 #include <vector>
 
 #define SV_MAX_LAYERS RTX_MAX_LAYERS
@@ -42,6 +43,8 @@ struct rtx_svae {
     float *mu = nullptr, *lv = nullptr, *eps = nullptr, *zl = nullptr, *dz = nullptr;
     float *dH = nullptr, *dGI = nullptr, *dGH = nullptr, *dX = nullptr;
     float *row_loss = nullptr, *tsum = nullptr, *kl_rows = nullptr;
+    float* part = nullptr;           // split-K partial sums
+    size_t part_elems = 0;
     std::vector<void*> allocs;
 };
 
@@ -58,6 +61,8 @@ struct SvGemm {
     const float* bias;   // [N]        (SV_EPI_BIAS*)
     const float* Q;      // [M][ldq]   (SV_EPI_TANH_GRAD: C = acc * (1 - Q^2))
     long ldq;
+    int kchunk;          // split-K: workgroup z handles k in [z * kchunk, (z + 1) * kchunk) and stores its raw partial
+    float* part;         //          sums to part[z][M][N]; k_sv_splitk_reduce then applies the epilogue (0 / NULL = off)
 };
 
 __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
@@ -67,17 +72,19 @@ __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const int kbeg = g.kchunk ? blockIdx.z * g.kchunk : 0;
+    const int kend = g.kchunk ? min(g.K, kbeg + g.kchunk) : g.K;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
         // 64 x 16 elements per operand, 4 per thread; the faster-varying thread index follows the unit-stride axis
         for (int e = tid; e < 1024; e += 256) {
             int mm, kk;
             if (g.sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
             const int m = m0 + mm, k = k0 + kk;
-            sA[kk][mm] = (m < g.M && k < g.K) ? g.A[(size_t)m * g.sam + (size_t)k * g.sak] : 0.f;
+            sA[kk][mm] = (m < g.M && k < kend) ? g.A[(size_t)m * g.sam + (size_t)k * g.sak] : 0.f;
             int nn, k2;
             if (g.sbk == 1) { k2 = e & 15; nn = e >> 4; } else { nn = e & 63; k2 = e >> 6; }
             const int n = n0 + nn, kb = k0 + k2;
-            sB[k2][nn] = (n < g.N && kb < g.K) ? g.B[(size_t)n * g.sbn + (size_t)kb * g.sbk] : 0.f;
+            sB[k2][nn] = (n < g.N && kb < kend) ? g.B[(size_t)n * g.sbn + (size_t)kb * g.sbk] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -101,6 +108,10 @@ __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
             const int n = n0 + tn + j;
             if (n >= g.N) continue;
             float v = g.alpha * acc[i][j];
+            if (g.kchunk) {
+                g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
+                continue;
+            }
             if (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH) v += g.bias[n];
             if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
             if (g.epi == SV_EPI_TANH_GRAD) { const float q = g.Q[(size_t)m * g.ldq + n]; v *= (1.f - q * q); }
@@ -109,14 +120,29 @@ __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
     }
 }
 
-// out[n] = sum_t D[t][n]  (bias gradients); one thread per column
+__global__ __launch_bounds__(256) void k_sv_splitk_reduce(const SvGemm g, int splits)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)g.M * g.N) return;
+    const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += g.part[(size_t)z * g.M * g.N + idx];
+    if (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH) v += g.bias[n];
+    if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
+    if (g.epi == SV_EPI_TANH_GRAD) { const float q = g.Q[(size_t)m * g.ldq + n]; v *= (1.f - q * q); }
+    g.C[(size_t)m * g.ldc + n] = v;
+}
+
+// out[n] = sum_t D[t][n]  (bias gradients): a workgroup sums 32 time steps of 256 columns; the row blocks meet through
+// atomicAdd on the zeroed output
 __global__ __launch_bounds__(256) void k_sv_colsum(const float* D, long ld, int T, int N, float* out)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
+    const int t0 = blockIdx.y * 32, t1 = min(T, t0 + 32);
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += D[(size_t)t * ld + n];
-    out[n] = s;
+    for (int t = t0; t < t1; ++t) s += D[(size_t)t * ld + n];
+    atomicAdd(out + n, s);
 }
 
 __global__ __launch_bounds__(256) void k_sv_embed(const int32_t* items, int T, int E, const float* emb, float* X)
@@ -157,38 +183,67 @@ __device__ __forceinline__ float block_max(float v, float* red)
 
 // GRU forward, torch.nn.GRU gate order r | z | n (weight_hh_l0 [3R][R], bias_hh_l0 [3R]); GI = x W_ih^T + b_ih [T][3R].
 //   r = sig(gi_r + W_hr h + b_hr), z = sig(gi_z + W_hz h + b_hz), n = tanh(gi_n + r * (W_hn h + b_hn)), h' = (1-z) n + z h
-// One workgroup of 1024 threads; wave w computes the rows w, w+16, ... of W_hh h (lanes split K, DPP reduction).
+// One persistent workgroup of 1024 threads; the recurrence is a chain of T dependent mat-vecs, so what matters is the
+// latency of ONE step.  Thread `row` streams its own row of W_hh (float4 loads, all independent: the only dependent
+// chain is the FMA accumulation) against h broadcast from LDS -- no cross-lane reduction, one barrier per phase.
+// Measured per step at R = 200: 27 us with one wave per row + shuffle reduction (37 dependent L2 round trips), 8.7 us in
+// this form.  Splitting the hidden units over 2 workgroups with W_hh resident in registers and an exchange of h through
+// L2 per step was SLOWER (10.8 us): device-scope release/acquire between compute units costs microseconds on a
+// multi-XCD part, more than re-reading 480 KB from L2.
 __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
                                                      int T, int R, float* __restrict__ H /* [T+1][R], H[0] = 0 */, float* __restrict__ Gr,
                                                      float* __restrict__ Gz, float* __restrict__ Gn, float* __restrict__ Ghn)
 {
-    extern __shared__ float sm[];   // h [R] | gh [3R]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h [Rp] | gh [3R]   (Rp = R rounded up to 4)
+    const int Rp = (R + 3) & ~3;
     float* h = sm;
-    float* gh = sm + R;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < R; j += 1024) { h[j] = 0.f; H[j] = 0.f; }
+    float* gh = sm + Rp;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < Rp; j += 1024) h[j] = 0.f;
+    for (int j = tid; j < R; j += 1024) H[j] = 0.f;
     __syncthreads();
+    const bool vec = (R & 3) == 0;
     for (int t = 0; t < T; ++t) {
-        for (int row = wave; row < 3 * R; row += 16) {
+        // this step's input projections are independent of h: fetch them before the mat-vec, not after its barrier
+        const float* gi = GI + (size_t)t * 3 * R;
+        float gir = 0.f, giz = 0.f, gin = 0.f;
+        if (tid < R) { gir = gi[tid]; giz = gi[R + tid]; gin = gi[2 * R + tid]; }
+        for (int row = tid; row < 3 * R; row += 1024) {
             const float* w = Whh + (size_t)row * R;
-            float s = 0.f;
-            for (int k = lane; k < R; k += 64) s += w[k] * h[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) gh[row] = s + bhh[row];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            if (vec) {
+                const float4* w4 = (const float4*)w;
+                const float4* h4 = (const float4*)h;
+                const int n4 = R >> 2;
+                int k = 0;
+                for (; k + 4 <= n4; k += 4) {
+                    const float4 a0 = w4[k], a1 = w4[k + 1], a2 = w4[k + 2], a3 = w4[k + 3];
+                    const float4 b0 = h4[k], b1 = h4[k + 1], b2 = h4[k + 2], b3 = h4[k + 3];
+                    s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+                    s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+                    s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+                    s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+                }
+                for (; k < n4; ++k) {
+                    const float4 a0 = w4[k], b0 = h4[k];
+                    s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+                }
+            } else {
+                for (int k = 0; k < R; ++k) s0 += w[k] * h[k];
+            }
+            gh[row] = (s0 + s1) + (s2 + s3) + bhh[row];
         }
         __syncthreads();
-        const float* gi = GI + (size_t)t * 3 * R;
-        for (int j = tid; j < R; j += 1024) {
-            const float r = sv_sigmoid(gi[j] + gh[j]);
-            const float z = sv_sigmoid(gi[R + j] + gh[R + j]);
+        for (int j = tid; j < R; j += 1024) {   // R <= 1024: one pass, j == tid
+            const float r = sv_sigmoid(gir + gh[j]);
+            const float z = sv_sigmoid(giz + gh[R + j]);
             const float hn = gh[2 * R + j];
-            const float n = tanhf(gi[2 * R + j] + r * hn);
+            const float n = tanhf(gin + r * hn);
             const float hp = h[j];
             const float hv = (1.f - z) * n + z * hp;
             Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
             H[(size_t)(t + 1) * R + j] = hv;
-            h[j] = hv;   // element j is read and written by this thread only; the matvec above is behind the barrier
+            h[j] = hv;   // element j is read and written by this thread only; the mat-vec above is behind the barrier
         }
         __syncthreads();
     }
@@ -196,16 +251,20 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ G
 
 // GRU backward through time.  dHout[t] = gradient w.r.t. the GRU output at step t.  Writes the gate pre-activation
 // gradients dGI [T][3R] (input side) and dGH [T][3R] (hidden side; differs in the n block by the factor r).
+// dh_{t-1} += W_hh^T dgh: thread (column k, row chunk c) sums W_hh[i][k] dgh[i] over its chunk of rows -- consecutive
+// lanes read consecutive k (coalesced rows), every load is independent -- and the chunks meet in LDS (5.5 us per step).
 __global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ dHout, const float* __restrict__ Whh, int T, int R,
                                                      const float* __restrict__ H, const float* __restrict__ Gr, const float* __restrict__ Gz,
                                                      const float* __restrict__ Gn, const float* __restrict__ Ghn, float* __restrict__ dGI,
                                                      float* __restrict__ dGH)
 {
-    extern __shared__ float sm[];   // dh [R] | dgh [3R] | part [16][R]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dh [R] | dgh [3R] | part [NC][R]
     float* dh = sm;
     float* dgh = sm + R;
     float* part = sm + 4 * R;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    const int NC = max(1, min(16, 1024 / R));     // row chunks: as many as the workgroup has threads for
+    const int rows_per = (3 * R + NC - 1) / NC;
     for (int j = tid; j < R; j += 1024) dh[j] = 0.f;
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
@@ -225,28 +284,26 @@ __global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ d
             dh[j] = d * z;   // the direct path h_{t-1} -> h_t; the path through the gates is added below
         }
         __syncthreads();
-        // dh_prev[k] += sum_i W_hh[i][k] * dgh[i]: wave w accumulates rows w, w+16, ...; lanes own columns k = lane + 64 c
-        for (int c0 = 0; c0 < R; c0 += 64 * 4) {
+        for (int e = tid; e < NC * R; e += 1024) {
+            const int c = e / R, k = e - c * R;
+            const int i0 = c * rows_per, i1 = min(3 * R, i0 + rows_per);
+            const float* w = Whh + (size_t)i0 * R + k;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            const int k0 = c0 + lane, k1 = k0 + 64, k2 = k0 + 128, k3 = k0 + 192;
-            for (int row = wave; row < 3 * R; row += 16) {
-                const float gsc = dgh[row];
-                const float* w = Whh + (size_t)row * R;
-                if (k0 < R) a0 += w[k0] * gsc;
-                if (k1 < R) a1 += w[k1] * gsc;
-                if (k2 < R) a2 += w[k2] * gsc;
-                if (k3 < R) a3 += w[k3] * gsc;
+            int i = i0;
+            for (; i + 4 <= i1; i += 4) {
+                a0 += w[0] * dgh[i];
+                a1 += w[R] * dgh[i + 1];
+                a2 += w[2 * (size_t)R] * dgh[i + 2];
+                a3 += w[3 * (size_t)R] * dgh[i + 3];
+                w += 4 * (size_t)R;
             }
-            if (k0 < R) part[wave * R + k0] = a0;
-            if (k1 < R) part[wave * R + k1] = a1;
-            if (k2 < R) part[wave * R + k2] = a2;
-            if (k3 < R) part[wave * R + k3] = a3;
+            for (; i < i1; ++i) { a0 += w[0] * dgh[i]; w += R; }
+            part[c * R + k] = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
         for (int j = tid; j < R; j += 1024) {
             float s = dh[j];
-#pragma unroll
-            for (int w = 0; w < 16; ++w) s += part[w * R + j];
+            for (int c = 0; c < NC; ++c) s += part[c * R + j];
             dh[j] = s;
         }
         __syncthreads();
@@ -358,12 +415,36 @@ static int sv_alloc(rtx_svae* s, float** p, size_t n)
     return RTX_OK;
 }
 
-static int sv_gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M, int N,
-                   int K, int epi = SV_EPI_NONE, const float* bias = nullptr, const float* Q = nullptr, long ldq = 0)
+static int sv_gemm(rtx_svae* s, hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M,
+                   int N, int K, int epi = SV_EPI_NONE, const float* bias = nullptr, const float* Q = nullptr, long ldq = 0)
 {
     if (M <= 0 || N <= 0) return RTX_OK;
-    SvGemm g = {A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, 1.f, epi, bias, Q, ldq};
-    hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+    SvGemm g = {A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, 1.f, epi, bias, Q, ldq, 0, nullptr};
+    const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+    // few output tiles and a long K (the [T, hidden] = [T, n_items] x [n_items, hidden] backward-data product): split K
+    // so that a few hundred workgroups share the reduction instead of a handful walking it end to end
+    int splits = 1;
+    if (tiles < 64 && K >= 512) {
+        splits = std::min((K + 255) / 256, std::max(1, 256 / tiles));
+        if ((size_t)splits * M * N > s->part_elems) splits = (int)(s->part_elems / ((size_t)M * N));
+    }
+    if (splits > 1) {
+        g.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+        splits = (K + g.kchunk - 1) / g.kchunk;
+        g.part = s->part;
+        hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_sv_splitk_reduce, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, st, g, splits);
+    } else {
+        hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+static int sv_colsum(hipStream_t st, const float* D, long ld, int T, int N, float* out)
+{
+    RTX_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, st));
+    hipLaunchKernelGGL(k_sv_colsum, dim3((N + 255) / 256, (T + 31) / 32), dim3(256), 0, st, D, ld, T, N, out);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -394,15 +475,15 @@ static int sv_forward(rtx_svae* s, const int32_t* items, int T, const float* eps
 {
     const int E = s->E, R = s->R, Z = s->Z;
     hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
-    RTX_TRY(sv_gemm(st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
+    RTX_TRY(sv_gemm(s, st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
                     s->params[sv_tail(s, SV_T_BIH)]));
-    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(1), dim3(1024), sizeof(float) * 4 * R, st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
+    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
                        s->params[sv_tail(s, SV_T_BHH)], T, R, s->H, s->Gr, s->Gz, s->Gn, s->Ghn);
     const float* in = s->H + R;   // rnn_out[t] = h_{t+1}
     long ld_in = R;
     for (int li = 0; li < s->NL; ++li) {
         SvLayer& l = s->L[li];
-        RTX_TRY(sv_gemm(st, in, ld_in, 1, s->params[2 * li], l.in, 1, l.A, l.out, T, l.out, l.in, l.tanh_act ? SV_EPI_BIAS_TANH : SV_EPI_BIAS,
+        RTX_TRY(sv_gemm(s, st, in, ld_in, 1, s->params[2 * li], l.in, 1, l.A, l.out, T, l.out, l.in, l.tanh_act ? SV_EPI_BIAS_TANH : SV_EPI_BIAS,
                         s->params[2 * li + 1]));
         in = l.A;
         ld_in = l.out;
@@ -472,6 +553,12 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
     SV_ALLOC(s->mu, T * Z); SV_ALLOC(s->lv, T * Z); SV_ALLOC(s->eps, T * Z); SV_ALLOC(s->zl, T * Z); SV_ALLOC(s->dz, T * Z);
     SV_ALLOC(s->dH, T * R); SV_ALLOC(s->dGI, T * 3 * R); SV_ALLOC(s->dGH, T * 3 * R); SV_ALLOC(s->dX, T * E);
     SV_ALLOC(s->row_loss, T); SV_ALLOC(s->tsum, T); SV_ALLOC(s->kl_rows, T);
+    {
+        size_t widest = std::max((size_t)std::max(R, E), Z);
+        for (auto& l : s->L) widest = std::max(widest, (size_t)std::min(l.in, l.out));
+        s->part_elems = 16 * T * widest;   // up to 16 K-splits of the widest [T, hidden] product
+        SV_ALLOC(s->part, s->part_elems);
+    }
     for (auto& l : s->L) { SV_ALLOC(l.A, T * l.out); SV_ALLOC(l.D, T * l.out); }
 #undef SV_ALLOC
     const size_t lds_bwd = sizeof(float) * (4 * R + 16 * R);
@@ -563,29 +650,29 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
         else if (li == s->n_enc) { in = s->zl; ld_in = Z; }
         else { in = s->L[li - 1].A; ld_in = s->L[li - 1].out; }
         // dW[out][in] = sum_t D[t][out] * in[t][in];  db = column sums
-        RTX_TRY(sv_gemm(st, l.D, 1, l.out, in, 1, ld_in, s->grads[2 * li], l.in, l.out, l.in, T));
-        hipLaunchKernelGGL(k_sv_colsum, dim3((l.out + 255) / 256), dim3(256), 0, st, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]);
+        RTX_TRY(sv_gemm(s, st, l.D, 1, l.out, in, 1, ld_in, s->grads[2 * li], l.in, l.out, l.in, T));
+        RTX_TRY(sv_colsum(st, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]));
         // gradient w.r.t. the layer input: [T][in] = D [T][out] x W [out][in]
         if (li == 0) {
-            RTX_TRY(sv_gemm(st, l.D, l.out, 1, s->params[0], 1, l.in, s->dH, R, T, R, l.out));
+            RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[0], 1, l.in, s->dH, R, T, R, l.out));
         } else if (li == s->n_enc) {
-            RTX_TRY(sv_gemm(st, l.D, l.out, 1, s->params[2 * li], 1, l.in, s->dz, Z, T, Z, l.out));
+            RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[2 * li], 1, l.in, s->dz, Z, T, Z, l.out));
             hipLaunchKernelGGL(k_sv_reparam_bwd, dim3(T), dim3(256), 0, st, s->dz, s->mu, s->lv, s->eps, T, Z, beta_over_T, s->L[li - 1].D,
                                s->kl_rows);
         } else {
             SvLayer& p = s->L[li - 1];   // tanh layer: D_prev = (D W) * (1 - A_prev^2)
-            RTX_TRY(sv_gemm(st, l.D, l.out, 1, s->params[2 * li], 1, l.in, p.D, p.out, T, p.out, l.out, SV_EPI_TANH_GRAD, nullptr, p.A, p.out));
+            RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[2 * li], 1, l.in, p.D, p.out, T, p.out, l.out, SV_EPI_TANH_GRAD, nullptr, p.A, p.out));
         }
     }
     hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, loss_out, loss_accum);
     // ---- GRU backward through time, then its weight gradients over all steps at once
     hipLaunchKernelGGL(k_sv_gru_bwd, dim3(1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], T, R, s->H, s->Gr,
                        s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
-    RTX_TRY(sv_gemm(st, s->dGH, 1, 3 * R, s->H, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));          // dW_hh = dGH^T H_prev
-    hipLaunchKernelGGL(k_sv_colsum, dim3((3 * R + 255) / 256), dim3(256), 0, st, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]);
-    RTX_TRY(sv_gemm(st, s->dGI, 1, 3 * R, s->X, 1, E, s->grads[sv_tail(s, SV_T_WIH)], E, 3 * R, E, T));          // dW_ih = dGI^T X
-    hipLaunchKernelGGL(k_sv_colsum, dim3((3 * R + 255) / 256), dim3(256), 0, st, s->dGI, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BIH)]);
-    RTX_TRY(sv_gemm(st, s->dGI, 3 * R, 1, s->params[sv_tail(s, SV_T_WIH)], 1, E, s->dX, E, T, E, 3 * R));        // dX = dGI W_ih
+    RTX_TRY(sv_gemm(s, st, s->dGH, 1, 3 * R, s->H, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));          // dW_hh = dGH^T H_prev
+    RTX_TRY(sv_colsum(st, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]));
+    RTX_TRY(sv_gemm(s, st, s->dGI, 1, 3 * R, s->X, 1, E, s->grads[sv_tail(s, SV_T_WIH)], E, 3 * R, E, T));          // dW_ih = dGI^T X
+    RTX_TRY(sv_colsum(st, s->dGI, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BIH)]));
+    RTX_TRY(sv_gemm(s, st, s->dGI, 3 * R, 1, s->params[sv_tail(s, SV_T_WIH)], 1, E, s->dX, E, T, E, 3 * R));        // dX = dGI W_ih
     RTX_HIP(hipMemsetAsync(s->grads[sv_tail(s, SV_T_EMB)], 0, sizeof(float) * (size_t)I * E, st));
     hipLaunchKernelGGL(k_sv_embed_grad, dim3(T), dim3(256), 0, st, items, T, E, s->dX, s->grads[sv_tail(s, SV_T_EMB)]);
     RTX_HIP(hipGetLastError());

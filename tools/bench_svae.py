@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""SVAE training throughput at an ml-1m-like shape (BASELINE.json configs[4]; reference rectorch/models.py:1609-1635):
+one user sequence per Adam step, embedding 256 -> GRU 200 -> [150] -> latent 64 -> [150] -> n_items, 'next_k' targets.
+
+    python tools/bench_svae.py [--users 6040] [--items 3416] [--mean-len 165] [--steps 2000] [--cpu-seconds 15]
+
+Prints one JSON line: sequences/s and time steps/s on the MI355X (inputs resident: the sampler's compact targets are
+uploaded before the timed region), the per-kernel HIP time if rocprofv3 wraps the run, and the numpy-oracle baseline on
+a bounded sample of the same users."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from rectorch_amd.models import SVAE                       # noqa: E402
+from rectorch_amd.nets import SVAE_net                     # noqa: E402
+from rectorch_amd.samplers import SVAE_Sampler             # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=6040)
+    ap.add_argument("--items", type=int, default=3416)
+    ap.add_argument("--mean-len", type=float, default=165.0)
+    ap.add_argument("--max-len", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    a = ap.parse_args()
+    rng = np.random.RandomState(1)
+    lens = np.clip(rng.lognormal(np.log(a.mean_len) - 0.5, 1.0, size=a.users).astype(int), 5, a.max_len)
+    pop = rng.zipf(1.3, size=int(lens.sum()) * 2)
+    pop = pop[pop <= a.items][: int(lens.sum())] - 1
+    seqs, o = {}, 0
+    for u in range(a.users):
+        seqs[u] = pop[o:o + lens[u]].tolist()
+        o += lens[u]
+    torch.manual_seed(0)
+    net = SVAE_net(n_items=a.items, embed_size=256, rnn_size=200, dec_dims=[64, 150, a.items], enc_dims=[200, 150, 64])
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=20000)
+    np.random.seed(0)
+    smp = SVAE_Sampler(a.items, seqs, None, pred_type="next_k", k=a.k, shuffle=True, sparse=True)
+    batches = []
+    for i, (x, y) in enumerate(smp):
+        batches.append((x.to("cuda"), y))
+        if i + 1 >= a.steps + a.warmup:
+            break
+    n = len(batches)
+    w = min(a.warmup, n // 2)
+    for x, y in batches[:w]:
+        model.train_batch(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps_t = 0
+    for x, y in batches[w:]:
+        model.train_batch(x, y)          # returns loss.item(): one host sync per user, as in the reference
+        steps_t += x.numel()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "SVAE train, synthetic ml-1m shape: %d items, embed 256, GRU 200, enc [200,150,64], dec [64,150,I], "
+                       "next_k k=%d, one user per Adam step" % (a.items, a.k),
+           "users_per_s": (n - w) / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / (n - w) * 1e3,
+           "mean_len": steps_t / (n - w), "users_timed": n - w, "dtype": "f32"}
+    if a.cpu_seconds > 0:
+        from oracle.svae_oracle import SvaeOracle
+        orc = SvaeOracle(sd, n_enc=2, n_dec=2, beta=0.2, anneal_steps=20000)
+        t0 = time.perf_counter()
+        done = ts = 0
+        for x, y in batches[w:]:
+            items = x.cpu().numpy().reshape(-1)
+            T = len(items)
+            yd = np.zeros((T, a.items))
+            ptr, idx = y.indptr.cpu().numpy(), y.indices.cpu().numpy()
+            for t in range(T):
+                yd[t, idx[ptr[t]:ptr[t + 1]]] = 1.0
+            orc.train_batch(items, yd, rng.randn(T, 64))
+            done += 1
+            ts += T
+            if time.perf_counter() - t0 > a.cpu_seconds:
+                break
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"users_per_s": done / cdt, "timesteps_per_s": ts / cdt, "kind": "port", "cores": os.cpu_count(),
+                               "sample": "%d users (numpy float64 restatement, BLAS threads as configured)" % done}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
