@@ -3,6 +3,7 @@ import ctypes
 import glob
 import os
 import re
+import sys
 
 from conftest import ROOT
 
@@ -62,3 +63,13 @@ def test_product_package_does_not_import_the_oracle():
             src = open(path).read()
             assert "oracle" not in src.replace("the oracle", "").lower() or "import oracle" not in src, path
             assert "from oracle" not in src and "import oracle" not in src and "mvae_oracle" not in src, path
+
+
+def test_graft_entry_build_succeeds():
+    """the driver's build check: __graft_entry__.build() (make is a no-op when everything is up to date)"""
+    import importlib
+    sys_path_added = ROOT not in sys.path
+    if sys_path_added:
+        sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.build()
