@@ -561,7 +561,81 @@ def g12():
     save("g12_svae_sampler", **so)
 
 
+def g13():
+    """On-disk formats: the preprocessed files the reference's DataProcessing.process writes (data.py:199-219:
+    train.csv, {validation,test}_{tr,te}.csv with header uid,iid[,rating,timestamp], unique_{iid,uid}.txt) read back by the
+    reference's own DataReader / DatasetManager (data.py:312-557).  DataProcessing itself does not run with the pandas of
+    this image, so the small fixture files are written here, in that layout."""
+    import json
+    import pandas as pd
+    from rectorch.data import DataReader, DatasetManager
+    rng = np.random.RandomState(13)
+    NI = 40
+    pdir = os.path.join(HERE, "g13_preproc")
+    os.makedirs(pdir, exist_ok=True)
+
+    def users(lo, hi):
+        rows = []
+        for u in range(lo, hi):
+            n = rng.randint(4, 15)
+            for i in rng.choice(NI, size=n, replace=False):
+                rows.append((u, int(i), float(rng.randint(1, 6)), int(rng.randint(1e6, 2e6))))
+        return pd.DataFrame(rows, columns=["uid", "iid", "rating", "timestamp"])
+
+    def split(df):
+        tr, te = [], []
+        for _, g in df.groupby("uid"):
+            k = max(int(0.2 * len(g)), 1)
+            idx = np.zeros(len(g), bool)
+            idx[rng.choice(len(g), k, replace=False)] = True
+            tr.append(g[~idx])
+            te.append(g[idx])
+        return pd.concat(tr), pd.concat(te)
+
+    users(0, 44).to_csv(os.path.join(pdir, "train.csv"), index=False)
+    va = users(44, 52)
+    va = va[va["uid"] != 47]                                  # a user id missing from the validation block
+    a, b = split(va)
+    a.to_csv(os.path.join(pdir, "validation_tr.csv"), index=False)
+    b.to_csv(os.path.join(pdir, "validation_te.csv"), index=False)
+    a, b = split(users(52, 60))
+    a.to_csv(os.path.join(pdir, "test_tr.csv"), index=False)
+    b.to_csv(os.path.join(pdir, "test_te.csv"), index=False)
+    with open(os.path.join(pdir, "unique_iid.txt"), "w") as f:
+        f.write("".join("%d\n" % (500 + i) for i in range(NI)))
+    with open(os.path.join(pdir, "unique_uid.txt"), "w") as f:
+        f.write("".join("%d\n" % (100 + u) for u in range(60)))
+    out = {}
+    for topn in (1, 0):
+        cfgp = os.path.join(tempfile.gettempdir(), "g13_cfg%d.json" % topn)
+        json.dump({"proc_path": pdir, "topn": topn, "seed": 98765, "test_prop": 0.2}, open(cfgp, "w"))
+        r = DataReader(cfgp)
+        k = "topn%d_" % topn
+        out[k + "n_items"] = np.int64(r.n_items)
+        out[k + "train"] = r.load_data("train").toarray()
+        for dt in ("validation", "test"):
+            x, y = r.load_data(dt)
+            out[k + dt + "_tr"] = x.toarray()
+            out[k + dt + "_te"] = y.toarray()
+        out[k + "full"] = r.load_data("full").toarray()
+        dm = DatasetManager(cfgp)
+        x, y = dm.get_train_and_test()
+        out[k + "tt_tr"] = x.toarray()
+        out[k + "tt_te"] = y.toarray()
+        if topn:
+            def pack(d):
+                keys = sorted(d)
+                return np.array(keys), np.array([len(d[u]) for u in keys]), np.array([i for u in keys for i in d[u]])
+            for name, d in (("dict_train", r.load_data_as_dict("train")), ("dict_full", r.load_data_as_dict("full"))):
+                out[name + "_keys"], out[name + "_lens"], out[name + "_items"] = pack(d)
+            for dt in ("validation", "test"):
+                d1, d2 = r.load_data_as_dict(dt)
+                out["dict_%s_tr_keys" % dt], out["dict_%s_tr_lens" % dt], out["dict_%s_tr_items" % dt] = pack(d1)
+                out["dict_%s_te_keys" % dt], out["dict_%s_te_lens" % dt], out["dict_%s_te_items" % dt] = pack(d2)
+    save("g13_data_reader", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
-        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}[w]()
+        {"g1": g1_g7, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}[w]()

@@ -360,3 +360,57 @@ def test_svae_sampler_matches_reference_g12():
     assert [int(x[0, 0]) for x, _ in smp] == g["shuffled_first_items"].tolist()
     with pytest.raises(AssertionError):
         SVAE_Sampler(I, seqs, None, pred_type="next_k", k=0)
+
+
+# ------------------------------------------------------------------------------------------ on-disk formats (8f-4)
+@pytest.mark.parametrize("topn", [1, 0])
+def test_data_reader_matches_reference_g13(topn):
+    """train / validation / test / full matrices and DatasetManager.get_train_and_test from the reference's file
+    layout, equal to the reference's own DataReader (shapes, row order, values, dtype)"""
+    from rectorch_amd.data import DataReader, DatasetManager
+    g = load_golden("g13_data_reader")
+    cfg = {"proc_path": os.path.join(GOLDEN, "g13_preproc"), "topn": topn, "seed": 98765, "test_prop": 0.2}
+    k = "topn%d_" % topn
+    r = DataReader(cfg)
+    assert r.n_items == int(g[k + "n_items"])
+    tr = r.load_data("train")
+    assert tr.dtype == np.float64 and np.array_equal(tr.toarray(), g[k + "train"])
+    for dt in ("validation", "test"):
+        a, b = r.load_data(dt)
+        assert np.array_equal(a.toarray(), g[k + dt + "_tr"]) and np.array_equal(b.toarray(), g[k + dt + "_te"])
+    assert np.array_equal(r.load_data("full").toarray(), g[k + "full"])
+    with pytest.raises(ValueError):
+        r.load_data("valid")
+    dm = DatasetManager(cfg)
+    assert dm.n_items == r.n_items and dm.training_set[1] is None
+    a, b = dm.get_train_and_test()
+    assert np.array_equal(a.toarray(), g[k + "tt_tr"]) and np.array_equal(b.toarray(), g[k + "tt_te"])
+    # a configuration file path and an attribute object work as well
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        import json
+        json.dump(cfg, f)
+    try:
+        assert DataReader(f.name).n_items == r.n_items
+    finally:
+        os.remove(f.name)
+    with pytest.raises(TypeError):
+        DataReader(3)
+
+
+def test_data_reader_dicts_match_reference_g13():
+    from rectorch_amd.data import DataReader
+    g = load_golden("g13_data_reader")
+    r = DataReader({"proc_path": os.path.join(GOLDEN, "g13_preproc"), "topn": 1, "seed": 98765, "test_prop": 0.2})
+
+    def check(d, name):
+        keys = sorted(d)
+        assert keys == g[name + "_keys"].tolist()
+        assert [len(d[u]) for u in keys] == g[name + "_lens"].tolist()
+        assert [int(i) for u in keys for i in d[u]] == g[name + "_items"].tolist()
+
+    check(r.load_data_as_dict("train"), "dict_train")
+    check(r.load_data_as_dict("full"), "dict_full")
+    for dt in ("validation", "test"):
+        d1, d2 = r.load_data_as_dict(dt)
+        check(d1, "dict_%s_tr" % dt)
+        check(d2, "dict_%s_te" % dt)
