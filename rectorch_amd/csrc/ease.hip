@@ -165,6 +165,12 @@ static int dgemm(const double* A, long lda, const double* B, long ldb, int m_til
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb; g.m_tiles = m_tiles; g.n_tiles = n_tiles; g.k_slices = k_slices;
     g.C = C; g.ldc = ldc; g.CT = CT; g.ldct = ldct; g.alpha = alpha; g.beta = beta; g.lower_only = lower_only;
     g.k_lo = k_lo; g.k_hi = k_hi;
+    // all but the top two levels of the recursion have too few 128x128 tiles to fill 256 compute units: quarter tiles
+    // put them on 4x as many (the triangular K ranges and the lower-only rule are tile-relative, so they carry over
+    // with the finer grid).  Measured fit time by threshold: 0 -> 252.7 ms, 16 -> 241.4, 400..1600 -> 230.8, all -> 238.3
+    static int small_max = -1;
+    if (small_max < 0) { const char* v = getenv("RTX_EASE_SMALL_TILES"); small_max = v ? atoi(v) : 1024; }
+    if (m_tiles * n_tiles <= small_max) { g.small_tile = 1; g.m_tiles = 2 * m_tiles; g.n_tiles = 2 * n_tiles; }
     return rtx_dgemm_launch(g, st);
 }
 

@@ -2,7 +2,7 @@
 //
 //   C[m][n] = beta * C[m][n] + alpha * sum_{k0(m,n) <= k < k1(m,n)} A[m][k] * B[n][k]
 //
-// v_mfma_f64_16x16x4_f64; 128x128 tile, 4 waves, 64x64 of C per wave as 4x4 blocks of 16x16; K consumed in
+// v_mfma_f64_16x16x4_f64; 128x128 tile (or 64x64 for the small nodes), 4 waves, 64x64 of C per wave as 4x4 blocks of 16x16; K consumed in
 // 128-byte slices (16 doubles) through the same global->VGPR->LDS staging as the bf16/f32 GEMM (144-B padded rows,
 // conflict-free ds_read_b64 fragment reads).  All dimensions are multiples of 128 (the solver pads the Gram matrix
 // with an identity block), so there are no bounds checks.
@@ -26,6 +26,7 @@ struct RtxDgemm {
     // triangular operands: the K range of tile (tm, tn) starts at 128 * {0, tm, tn, max(tm, tn)}  (k_lo) and ends
     // at 128 * ({tm, tn} + 1) (k_hi: RTX_DK_TM / RTX_DK_TN) instead of covering all of K
     int k_lo, k_hi;
+    int small_tile;    // 1: 64x64 workgroup tiles (m_tiles / n_tiles and the tile-relative K ranges count 64s)
 };
 
 int rtx_dgemm_launch(const RtxDgemm& g, hipStream_t stream);
