@@ -44,6 +44,7 @@ struct rtx_svae {
     float *dH = nullptr, *dGI = nullptr, *dGH = nullptr, *dX = nullptr;
     float *row_loss = nullptr, *tsum = nullptr, *kl_rows = nullptr;
     float* part = nullptr;           // split-K partial sums
+    float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t part_elems = 0;
     std::vector<void*> allocs;
 };
@@ -159,6 +160,22 @@ __global__ __launch_bounds__(256) void k_sv_embed_grad(const int32_t* items, int
     for (int e = threadIdx.x; e < E; e += 256) atomicAdd(dst + e, dX[(size_t)t * E + e]);   // an item may repeat in a sequence
 }
 
+// out[c][r] = in[r][c]  (W_hh -> W_hh^T once per sequence for the forward recurrence)
+__global__ __launch_bounds__(256) void k_sv_transpose(const float* __restrict__ in, int rows, int cols, float* __restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int e = tid; e < 4096; e += 256) {
+        const int rr = e >> 6, cc = e & 63;
+        tile[rr][cc] = (r0 + rr < rows && c0 + cc < cols) ? in[(size_t)(r0 + rr) * cols + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+        const int cc = e >> 6, rr = e & 63;
+        if (r0 + rr < rows && c0 + cc < cols) out[(size_t)(c0 + cc) * rows + r0 + rr] = tile[rr][cc];
+    }
+}
+
 __device__ __forceinline__ float sv_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // block-wide reductions for 256-thread blocks; red must hold >= 4 floats; result broadcast to all threads
@@ -184,13 +201,14 @@ __device__ __forceinline__ float block_max(float v, float* red)
 // GRU forward, torch.nn.GRU gate order r | z | n (weight_hh_l0 [3R][R], bias_hh_l0 [3R]); GI = x W_ih^T + b_ih [T][3R].
 //   r = sig(gi_r + W_hr h + b_hr), z = sig(gi_z + W_hz h + b_hz), n = tanh(gi_n + r * (W_hn h + b_hn)), h' = (1-z) n + z h
 // One persistent workgroup of 1024 threads; the recurrence is a chain of T dependent mat-vecs, so what matters is the
-// latency of ONE step.  Thread `row` streams its own row of W_hh (float4 loads, all independent: the only dependent
-// chain is the FMA accumulation) against h broadcast from LDS -- no cross-lane reduction, one barrier per phase.
+// latency of ONE step.  Thread `row` streams its own row of W_hh (all loads independent: the only dependent chain is the
+// FMA accumulation) against h broadcast from LDS -- no cross-lane reduction, one barrier per phase.  The weights are read
+// from a transposed copy made once per sequence, so that a wave's load is 256 contiguous bytes.
 // Measured per step at R = 200: 27 us with one wave per row + shuffle reduction (37 dependent L2 round trips), 8.7 us in
 // this form.  Splitting the hidden units over 2 workgroups with W_hh resident in registers and an exchange of h through
 // L2 per step was SLOWER (10.8 us): device-scope release/acquire between compute units costs microseconds on a
 // multi-XCD part, more than re-reading 480 KB from L2.
-__global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+__global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ GI, const float* __restrict__ WhhT, const float* __restrict__ bhh,
                                                      int T, int R, float* __restrict__ H /* [T+1][R], H[0] = 0 */, float* __restrict__ Gr,
                                                      float* __restrict__ Gz, float* __restrict__ Gn, float* __restrict__ Ghn)
 {
@@ -202,35 +220,27 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ G
     for (int j = tid; j < Rp; j += 1024) h[j] = 0.f;
     for (int j = tid; j < R; j += 1024) H[j] = 0.f;
     __syncthreads();
-    const bool vec = (R & 3) == 0;
     for (int t = 0; t < T; ++t) {
         // this step's input projections are independent of h: fetch them before the mat-vec, not after its barrier
         const float* gi = GI + (size_t)t * 3 * R;
         float gir = 0.f, giz = 0.f, gin = 0.f;
         if (tid < R) { gir = gi[tid]; giz = gi[R + tid]; gin = gi[2 * R + tid]; }
         for (int row = tid; row < 3 * R; row += 1024) {
-            const float* w = Whh + (size_t)row * R;
+            // WhhT is [R][3R]: consecutive lanes (rows) read consecutive addresses -- 4 cache lines per wave load instead
+            // of the 64 a row-major W_hh costs when every lane walks its own row
+            const float* w = WhhT + row;
+            const size_t ld = (size_t)3 * R;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            if (vec) {
-                const float4* w4 = (const float4*)w;
-                const float4* h4 = (const float4*)h;
-                const int n4 = R >> 2;
-                int k = 0;
-                for (; k + 4 <= n4; k += 4) {
-                    const float4 a0 = w4[k], a1 = w4[k + 1], a2 = w4[k + 2], a3 = w4[k + 3];
-                    const float4 b0 = h4[k], b1 = h4[k + 1], b2 = h4[k + 2], b3 = h4[k + 3];
-                    s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
-                    s1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
-                    s2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
-                    s3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
-                }
-                for (; k < n4; ++k) {
-                    const float4 a0 = w4[k], b0 = h4[k];
-                    s0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
-                }
-            } else {
-                for (int k = 0; k < R; ++k) s0 += w[k] * h[k];
+            int k = 0;
+            for (; k + 8 <= R; k += 8) {
+                const float w0 = w[(k + 0) * ld], w1 = w[(k + 1) * ld], w2 = w[(k + 2) * ld], w3 = w[(k + 3) * ld];
+                const float w4 = w[(k + 4) * ld], w5 = w[(k + 5) * ld], w6 = w[(k + 6) * ld], w7 = w[(k + 7) * ld];
+                s0 += w0 * h[k] + w4 * h[k + 4];
+                s1 += w1 * h[k + 1] + w5 * h[k + 5];
+                s2 += w2 * h[k + 2] + w6 * h[k + 6];
+                s3 += w3 * h[k + 3] + w7 * h[k + 7];
             }
+            for (; k < R; ++k) s0 += w[k * ld] * h[k];
             gh[row] = (s0 + s1) + (s2 + s3) + bhh[row];
         }
         __syncthreads();
@@ -477,8 +487,10 @@ static int sv_forward(rtx_svae* s, const int32_t* items, int T, const float* eps
     hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
     RTX_TRY(sv_gemm(s, st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
                     s->params[sv_tail(s, SV_T_BIH)]));
-    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
-                       s->params[sv_tail(s, SV_T_BHH)], T, R, s->H, s->Gr, s->Gz, s->Gn, s->Ghn);
+    hipLaunchKernelGGL(k_sv_transpose, dim3((R + 63) / 64, (3 * R + 63) / 64), dim3(256), 0, st, s->params[sv_tail(s, SV_T_WHH)], 3 * R, R,
+                       s->WhhT);
+    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->WhhT, s->params[sv_tail(s, SV_T_BHH)], T, R,
+                       s->H, s->Gr, s->Gz, s->Gn, s->Ghn);
     const float* in = s->H + R;   // rnn_out[t] = h_{t+1}
     long ld_in = R;
     for (int li = 0; li < s->NL; ++li) {
@@ -553,6 +565,7 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
     SV_ALLOC(s->mu, T * Z); SV_ALLOC(s->lv, T * Z); SV_ALLOC(s->eps, T * Z); SV_ALLOC(s->zl, T * Z); SV_ALLOC(s->dz, T * Z);
     SV_ALLOC(s->dH, T * R); SV_ALLOC(s->dGI, T * 3 * R); SV_ALLOC(s->dGH, T * 3 * R); SV_ALLOC(s->dX, T * E);
     SV_ALLOC(s->row_loss, T); SV_ALLOC(s->tsum, T); SV_ALLOC(s->kl_rows, T);
+    SV_ALLOC(s->WhhT, 3 * R * R);
     {
         size_t widest = std::max((size_t)std::max(R, E), Z);
         for (auto& l : s->L) widest = std::max(widest, (size_t)std::min(l.in, l.out));
