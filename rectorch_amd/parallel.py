@@ -168,12 +168,13 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RTX_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that): smoke tests of the N > 1 path
+            backend = os.environ.get("RTX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % torch.cuda.device_count())   # (tests: two gloo ranks may share one device)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     return rank, world, local
 
 

@@ -1,0 +1,69 @@
+"""Run by test_gpu_parity.py::test_dp_world2_on_one_gpu under torch.distributed.run with TWO ranks sharing the one MI355X
+of the test box (gloo carries the device tensors; RCCL refuses two ranks on one device).  Each rank feeds ITS rows of the
+golden G2 batches (with its rows of the reference's dropout masks and noise); after three data-parallel steps every
+rank must hold the reference's parameters -- the sum of the two partial gradients equals the full-batch gradient."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import load_golden, sd_from, params_in_order          # noqa: E402
+from rectorch_amd import parallel                                   # noqa: E402
+from rectorch_amd.models import MultiVAE                            # noqa: E402
+from rectorch_amd.nets import MultiVAE_net                          # noqa: E402
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def main():
+    rank, world, _ = parallel.init_from_env(backend="gloo")
+    assert world == 2
+    for name, comm, bucket_adam, tol in (("g2b_mvae_train_step_te", torch.float32, True, 5e-6),
+                                         ("g2c_mvae_train_step_deep", torch.float32, False, 5e-6),
+                                         ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5)):
+        g = load_golden(name)
+        enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
+        beta, anneal, p, lr = [float(v) for v in g["meta"]]
+        net = MultiVAE_net(dec, enc, dropout=p)
+        sd = sd_from(g, "sd0__")
+        if rank == 1:                                   # attach() must overwrite rank 1's parameters with rank 0's
+            sd = {k: v + 1.0 for k, v in sd.items()}
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.to("cuda")
+        model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
+        parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam)
+        _, keys = params_in_order(sd_from(g, "sd0__"))
+        for t in range(g["xs"].shape[0]):
+            B = g["xs"][t].shape[0]
+            s, e = parallel.shard_rows(B, rank, world)
+            model._rtx.inject = (dev(g["mask_%d" % t][s:e], torch.uint8), dev(g["eps_%d" % t][s:e]))
+            gt = torch.from_numpy(g["gts"][t][s:e]) if "gts" in g else None
+            loss = model.train_batch(torch.from_numpy(g["xs"][t][s:e]), gt)
+            ref = float(g["loss_%d" % t])
+            assert abs(loss - ref) < (1e-5 if comm == torch.float32 else 1e-5) * abs(ref), (name, t, loss, ref)
+            sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
+            for k, prm, want in zip(keys, net._param_list(), sd_t):
+                dl = np.abs(prm.detach().cpu().numpy() - want)
+                if comm == torch.float32:
+                    assert float(dl.max()) < tol, (name, str(comm), t, k, float(dl.max()))
+                else:
+                    # the two ranks' partial gradients are rounded to bf16 before they are summed: where they nearly
+                    # cancel, the sign of the sum -- and with it Adam's +-lr move -- can flip on a few elements
+                    assert float(dl.max()) <= (t + 1) * 2.1e-3 and float(np.mean(dl > tol)) < 0.03, \
+                        (name, str(comm), t, k, float(dl.max()), float(np.mean(dl > tol)))
+    dist.barrier()
+    if rank == 0:
+        print("DP_WORLD2_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

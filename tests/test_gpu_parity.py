@@ -892,3 +892,17 @@ def test_svae_vs_oracle_longer_sequences():
             # elements may differ by a fraction of lr = 1e-3; everything else agrees to float32 round-off
             dlt = np.abs(prm.detach().cpu().numpy() - orc.p[k])
             assert float(dlt.max()) < 1e-3 and float(np.mean(dlt > 2e-5)) < 1e-4, (T, k, float(dlt.max()))
+
+
+def test_dp_world2_on_one_gpu():
+    """two data-parallel ranks (gloo over device tensors) on the one GPU of the box: row sharding, bucketed exchange
+    (float32 and bf16), per-bucket Adam -- three steps must land on the reference's parameters on both ranks"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [os.sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dp_world2_onegpu_check.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DP_WORLD2_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
