@@ -52,6 +52,12 @@ def main():
     out["gram_tflops_bf16"] = round(2.0 * npad * npad * up / (best["gram_ms"] * 1e-3) / 1e12, 1)
     out["factor_tflops_f64"] = round((2.0 * npad ** 3 / 3.0) / (best["chol_ms"] * 1e-3) / 1e12, 2)   # Cholesky + inverse of L
     out["wtw_tflops_f64"] = round((npad ** 3 / 3.0) / (best["inv_ms"] * 1e-3) / 1e12, 2)            # P = W^T W
+    # roofline of the dominant kernel: rtx_dgemm_nt (v_mfma_f64_16x16x4_f64).  P = W^T W is ONE launch of it bracketed by
+    # the solver's HIP events (inv_ms): n^3 / 3 flops (only the lower tiles, K from the diagonal block on)
+    peak_f64 = 78.6
+    out["roofline"] = {"kernel": "rtx_dgemm_nt<4> (P = W^T W launch)", "bound": "mfma", "achieved": out["wtw_tflops_f64"],
+                       "peak": peak_f64, "unit": "TFLOP/s", "frac": round(out["wtw_tflops_f64"] / peak_f64, 3), "traffic": None,
+                       "algorithmic_flops_per_launch": npad ** 3 / 3.0, "avg_us": best["inv_ms"] * 1e3}
     # property check at full size: (G + lam I)(I - B) is diagonal; sampled columns, G columns from the sparse matrix
     B = s.weights()
     rng = np.random.RandomState(0)

@@ -70,6 +70,15 @@ def main():
                        "next_k k=%d, one user per Adam step" % (a.items, a.k),
            "users_per_s": (n - w) / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / (n - w) * 1e3,
            "mean_len": steps_t / (n - w), "users_timed": n - w, "dtype": "f32"}
+    # the dominant kernels are the two GRU recurrences: ONE workgroup each, a chain of T dependent mat-vecs that re-read
+    # W_hh (3R x R floats) from L2 every step.  Against the HBM roofline that is a tiny fraction by construction (one CU of
+    # 256, latency-bound); the figure that matters is microseconds per time step.
+    eng = net._svae_engine
+    whh_bytes = 3 * 200 * 200 * 4
+    out["roofline"] = {"kernel": "k_sv_gru_fwd + k_sv_gru_bwd (persistent single-workgroup recurrences)", "bound": "hbm",
+                       "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                       "algorithmic_bytes_per_time_step": 2 * whh_bytes,
+                       "note": "per-step latency bound on one CU; see profiles/r1_svae_kernel_stats.txt for us per launch"}
     if a.cpu_seconds > 0:
         from oracle.svae_oracle import SvaeOracle
         orc = SvaeOracle(sd, n_enc=2, n_dec=2, beta=0.2, anneal_steps=20000)
