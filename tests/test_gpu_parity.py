@@ -906,3 +906,67 @@ def test_dp_world2_on_one_gpu():
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_world2_onegpu_check.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DP_WORLD2_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_architectures_vs_oracle(seed):
+    """randomly drawn networks (depths 1..3 per side, widths that are not multiples of anything, VAE / DAE / conditioned,
+    ragged batches, dropout on or off, explicit targets or not): two training steps and a prediction against the C oracle"""
+    from oracle import c_oracle
+    from rectorch_amd.utils import hash_state_dict
+    rng = np.random.RandomState(1000 + seed)
+    I = int(rng.randint(70, 700))
+    n_enc, n_dec = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+    L = int(rng.randint(3, 40))
+    enc = [I] + [int(rng.randint(5, 150)) for _ in range(n_enc - 1)] + [L]
+    dec = [L] + [int(rng.randint(5, 150)) for _ in range(n_dec - 1)] + [I]
+    variant = "vae" if seed % 2 else "dae"
+    cond = int(rng.randint(1, 9)) if (variant == "vae" and seed % 3 == 0) else 0
+    p = float(rng.choice([0.0, 0.3, 0.5]))
+    B = int(rng.randint(1, 140))
+    use_gt = bool(cond) or bool(rng.randint(0, 2))
+    enc_full = [I + cond] + enc[1:]
+    sd = hash_state_dict(enc_full, dec, variant, 77 + seed, bias_std=0.2)
+    params, keys = params_in_order(sd)
+    if cond:
+        net, model = make_cvae(cond, enc, dec, p, sd, beta=0.3, numerics="fp32")
+        ref = c_oracle.OracleTrainer(enc, dec, params, "vae", p, 0.3, 0, lr=1e-3, cond_dim=cond)
+    elif variant == "vae":
+        net, model = make_vae(enc, dec, p, sd, beta=0.3, numerics="fp32")
+        ref = c_oracle.OracleTrainer(enc, dec, params, "vae", p, 0.3, 0, lr=1e-3)
+    else:
+        net, model = make_dae(enc, dec, p, sd, lam=0.1, numerics="fp32")
+        ref = c_oracle.OracleTrainer(enc, dec, params, "dae", p, lam=0.1, lr=1e-3)
+    for t in range(2):
+        x = (rng.rand(B, I) < 0.15).astype(np.float32) * rng.choice([1.0, 1.0, 2.0, 0.5], size=(B, I)).astype(np.float32)
+        x[0, :] = 0.0                                                   # an empty row
+        xin = x
+        if cond:
+            c = np.zeros((B, cond), dtype=np.float32)
+            c[np.arange(B), rng.randint(0, cond, size=B)] = 1.0
+            xin = np.concatenate([x, c], axis=1)
+        gt = (x * (rng.rand(B, I) < 0.6)).astype(np.float32) if use_gt else None
+        if variant == "dae":
+            gt = None                                                   # MultiDAE.train_batch ignores te_batch
+        mask = (rng.rand(B, I) >= p).astype(np.uint8)
+        eps = rng.randn(B, L).astype(np.float32)
+        model._rtx.inject = (dev(mask, torch.uint8), dev(eps) if variant == "vae" else None)
+        loss = model.train_batch(torch.from_numpy(xin), None if gt is None else torch.from_numpy(gt))
+        ref_loss = ref.train_batch(xin, gt, mask, eps if variant == "vae" else None)
+        assert abs(loss - ref_loss) < 3e-5 * max(1.0, abs(ref_loss)), (seed, t, loss, ref_loss)
+        for k, prm, gr in zip(keys, net._param_list(), ref.last["grads"]):
+            if variant == "dae":
+                break        # the engine folds the gradient of lam * sum ||W||_2 into its Adam kernel: p.grad holds the
+                             # likelihood part only (the parameters below include it)
+            scale = max(1e-6, float(np.max(np.abs(gr))))
+            assert float(np.max(np.abs(prm.grad.cpu().numpy() - gr))) < 3e-4 * scale + 1e-7, (seed, t, k)
+    for prm, r, k in zip(net._param_list(), ref.params, keys):
+        d = np.abs(prm.detach().cpu().numpy() - r)
+        assert float(d.max()) < 2.1e-3 and float(np.mean(d > 2e-5)) < 2e-3, (seed, k, float(d.max()), float(np.mean(d > 2e-5)))
+    model._rtx.inject = None
+    pred = model.predict(torch.from_numpy(xin), remove_train=True)[0].cpu().numpy()
+    pref = ref.predict(xin, True)[0]
+    assert np.array_equal(np.isneginf(pred), np.isneginf(pref))
+    fin = np.isfinite(pred)
+    # after two independent Adam trajectories the parameters differ by the few +-lr elements above: compare loosely
+    assert rel(pred[fin], pref[fin]) < 5e-3
