@@ -258,20 +258,26 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
         if (gram != RTX_DT_F32) {
             const int esz = (gram == RTX_DT_FP8) ? 1 : 2;
             const long Up = ((U + 127) / 128) * 128;
+            const long np256 = ((np + 255) / 256) * 256;   // the Gram kernel works on 256-row tiles
             void* XT = nullptr;
             float* G32 = nullptr;
-            EASE_TRY(dalloc(&XT, (size_t)esz * np * Up, pool));
-            EASE_TRY(dalloc((void**)&G32, sizeof(float) * (size_t)np * np, pool));
-            EASE_HIP(hipMemsetAsync(XT, 0, (size_t)esz * np * Up, st));
+            EASE_TRY(dalloc(&XT, (size_t)esz * np256 * Up, pool));
+            EASE_TRY(dalloc((void**)&G32, sizeof(float) * (size_t)np256 * np, pool));
+            EASE_HIP(hipMemsetAsync(XT, 0, (size_t)esz * np256 * Up, st));
             if (gram == RTX_DT_FP8)
                 hipLaunchKernelGGL(k_ease_scatter_T8, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, (uint8_t*)XT);
             else
                 hipLaunchKernelGGL(k_ease_scatter_T16, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, (bf16_t*)XT);
-            RtxGemm g = {};
-            g.A = XT; g.B = XT; g.lda = Up; g.ldb = Up; g.tile_shape = RTX_TILE_128x128;
-            g.m_tiles = KB; g.n_tiles = KB; g.k_slices = (int)(Up * esz / 128); g.splits = 1; g.syrk_lower = 1;
-            g.C = G32; g.ldc = np; g.slab_stride = 0; g.M_real = np; g.N_real = np;
-            EASE_TRY(rtx_gemm_launch(g, gram, RTX_EPI_STORE, st));
+            const char* sy = getenv("RTX_EASE_SYRK");   // "0": the general GEMM with its lower-triangle patch order (measurement switch)
+            if (sy && !strcmp(sy, "0")) {
+                RtxGemm g = {};
+                g.A = XT; g.B = XT; g.lda = Up; g.ldb = Up; g.tile_shape = RTX_TILE_128x128;
+                g.m_tiles = KB; g.n_tiles = KB; g.k_slices = (int)(Up * esz / 128); g.splits = 1; g.syrk_lower = 1;
+                g.C = G32; g.ldc = np; g.slab_stride = 0; g.M_real = np; g.N_real = np;
+                EASE_TRY(rtx_gemm_launch(g, gram, RTX_EPI_STORE, st));
+            } else {
+                EASE_TRY(rtx_syrk_lower_launch(XT, Up * esz, 128, (int)(np256 / 256), KB, (int)(Up * esz / 128), gram == RTX_DT_FP8, G32, np, st));
+            }
             hipLaunchKernelGGL(k_ease_init<float>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G32, (long)np, A, n, np, lam);
         } else {
             const long Up = ((U + 15) / 16) * 16;

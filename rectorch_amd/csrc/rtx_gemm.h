@@ -71,3 +71,10 @@ struct RtxGemm {
 enum RtxDtype { RTX_DT_F32 = 0, RTX_DT_BF16 = 1, RTX_DT_FP8 = 2 };
 
 int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t stream);
+
+// Gram matrix of the EASE solver (syrk.hip): C[m][n] = sum_k A[m][k] A[n][k] for the 128-column tiles on or below the
+// diagonal; A has 256 * rows256 zero-padded rows of k_slices * 128 bytes (fp8 e4m3 or bf16; element (row, slice ks) at
+// A + row * row_bytes + ks * slice_bytes), C is [256 * rows256][ldc]
+// with cols128 * 128 <= ldc valid columns.
+int rtx_syrk_lower_launch(const void* A, long row_bytes, long slice_bytes, int rows256, int cols128, int k_slices, int fp8, float* C, long ldc,
+                          hipStream_t stream);
