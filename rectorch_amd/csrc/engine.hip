@@ -528,6 +528,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     e->vae = cfg->variant == RTX_VAE;
     e->esz = e->bf16 ? 2 : 4;
     e->Bp_alloc = rtx_pad_batch(cfg->max_batch);
+    if (const char* v = getenv("RTX_SPLITK")) e->cfg.splitk = atoi(v);   // measurement switch: split-K factor of the two K = n_items GEMMs
     if (const char* v = getenv("RTX_OVERLAP_ADAM")) e->overlap_adam = atoi(v) != 0;
     if (const char* v = getenv("RTX_FUSE_ADAM")) e->fuse_adam = atoi(v) != 0;
     if (const char* v = getenv("RTX_LSE_FUSE")) e->no_lse_fuse = atoi(v) == 0;
