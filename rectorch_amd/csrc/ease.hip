@@ -299,8 +299,9 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
         EASE_TRY(dalloc((void**)&WT, sizeof(double) * (size_t)np * np, pool));
         EASE_TRY(dalloc((void**)&d_status, sizeof(int), pool));
         EASE_HIP(hipMemsetAsync(d_status, 0, sizeof(int), st));
-        EASE_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)np * np, st));
-        EASE_HIP(hipMemsetAsync(WT, 0, sizeof(double) * (size_t)np * np, st));
+        // W (lower) and WT (upper) need no zero fill: every block that is read -- W11 / W22 up to the diagonal (k_hi), WT11
+        // from the diagonal on (k_lo), WT from max(tm, tn) on in the final product -- is written first, by a leaf (full
+        // 128x128 diagonal blocks) or by a merge (W21 and its transpose)
         {
             EaseWork w = {A, L, W, WT, np, d_status, st};
             EASE_TRY(ease_factor(w, 0, KB));
