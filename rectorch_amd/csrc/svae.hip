@@ -44,6 +44,9 @@ struct rtx_svae {
     float *dH = nullptr, *dGI = nullptr, *dGH = nullptr, *dX = nullptr;
     float *row_loss = nullptr, *tsum = nullptr, *kl_rows = nullptr;
     float* part = nullptr;           // split-K partial sums
+    float* part2 = nullptr;          // ... of the GEMMs on the side stream
+    hipStream_t side = nullptr;      // weight-gradient GEMMs of the MLPs: they overlap the single-workgroup GRU backward
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t part_elems = 0;
     std::vector<void*> allocs;
@@ -426,7 +429,7 @@ static int sv_alloc(rtx_svae* s, float** p, size_t n)
 }
 
 static int sv_gemm(rtx_svae* s, hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M,
-                   int N, int K, int epi = SV_EPI_NONE, const float* bias = nullptr, const float* Q = nullptr, long ldq = 0)
+                   int N, int K, int epi = SV_EPI_NONE, const float* bias = nullptr, const float* Q = nullptr, long ldq = 0, int lane = 0)
 {
     if (M <= 0 || N <= 0) return RTX_OK;
     SvGemm g = {A, sam, sak, B, sbn, sbk, C, ldc, M, N, K, 1.f, epi, bias, Q, ldq, 0, nullptr};
@@ -441,7 +444,7 @@ static int sv_gemm(rtx_svae* s, hipStream_t st, const float* A, long sam, long s
     if (splits > 1) {
         g.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
         splits = (K + g.kchunk - 1) / g.kchunk;
-        g.part = s->part;
+        g.part = lane ? s->part2 : s->part;   // the side stream sums into its own buffer
         hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, g);
         hipLaunchKernelGGL(k_sv_splitk_reduce, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, st, g, splits);
     } else {
@@ -571,12 +574,19 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
         for (auto& l : s->L) widest = std::max(widest, (size_t)std::min(l.in, l.out));
         s->part_elems = 16 * T * widest;   // up to 16 K-splits of the widest [T, hidden] product
         SV_ALLOC(s->part, s->part_elems);
+        SV_ALLOC(s->part2, s->part_elems);
     }
     for (auto& l : s->L) { SV_ALLOC(l.A, T * l.out); SV_ALLOC(l.D, T * l.out); }
 #undef SV_ALLOC
     const size_t lds_bwd = sizeof(float) * (4 * R + 16 * R);
     if (hipFuncSetAttribute((const void*)k_sv_gru_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd) != hipSuccess) {
         rtx_set_error("svae_create: cannot reserve %zu bytes of LDS for the GRU backward kernel", lds_bwd);
+        rtx_svae_destroy(s);
+        return RTX_EHIP;
+    }
+    if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+        rtx_set_error("svae_create: cannot create the side stream");
         rtx_svae_destroy(s);
         return RTX_EHIP;
     }
@@ -587,6 +597,9 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
 int rtx_svae_destroy(rtx_svae* s)
 {
     if (!s) return RTX_OK;
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     for (void* p : s->allocs) (void)hipFree(p);
     delete s;
     return RTX_OK;
@@ -654,17 +667,10 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
     SvLayer& last = s->L[NL - 1];
     hipLaunchKernelGGL(k_sv_loss, dim3(T), dim3(256), 0, st, last.A, T, I, target_indptr, target_indices, target_dense, inv_d, last.D,
                        s->row_loss);
-    // ---- backward through decoder and encoder.  D of layer l = gradient w.r.t. its pre-activation
+    // ---- backward through decoder and encoder.  D of layer l = gradient w.r.t. its pre-activation.  Only the chain of
+    //      input gradients is on the critical path (it feeds the GRU's backward pass) ...
     for (int li = NL - 1; li >= 0; --li) {
         SvLayer& l = s->L[li];
-        const float* in;
-        long ld_in;
-        if (li == 0) { in = s->H + R; ld_in = R; }
-        else if (li == s->n_enc) { in = s->zl; ld_in = Z; }
-        else { in = s->L[li - 1].A; ld_in = s->L[li - 1].out; }
-        // dW[out][in] = sum_t D[t][out] * in[t][in];  db = column sums
-        RTX_TRY(sv_gemm(s, st, l.D, 1, l.out, in, 1, ld_in, s->grads[2 * li], l.in, l.out, l.in, T));
-        RTX_TRY(sv_colsum(st, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]));
         // gradient w.r.t. the layer input: [T][in] = D [T][out] x W [out][in]
         if (li == 0) {
             RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[0], 1, l.in, s->dH, R, T, R, l.out));
@@ -677,6 +683,22 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
             RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[2 * li], 1, l.in, p.D, p.out, T, p.out, l.out, SV_EPI_TANH_GRAD, nullptr, p.A, p.out));
         }
     }
+    // ... the weight gradients of the MLPs only feed Adam: on a side stream they run under the GRU's backward pass, which
+    //     is ONE workgroup for ~0.85 ms while 255 compute units would otherwise idle
+    RTX_HIP(hipEventRecord(s->ev_fork, st));
+    RTX_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    for (int li = NL - 1; li >= 0; --li) {
+        SvLayer& l = s->L[li];
+        const float* in;
+        long ld_in;
+        if (li == 0) { in = s->H + R; ld_in = R; }
+        else if (li == s->n_enc) { in = s->zl; ld_in = Z; }
+        else { in = s->L[li - 1].A; ld_in = s->L[li - 1].out; }
+        // dW[out][in] = sum_t D[t][out] * in[t][in];  db = column sums
+        RTX_TRY(sv_gemm(s, s->side, l.D, 1, l.out, in, 1, ld_in, s->grads[2 * li], l.in, l.out, l.in, T, SV_EPI_NONE, nullptr, nullptr, 0, 1));
+        RTX_TRY(sv_colsum(s->side, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]));
+    }
+    RTX_HIP(hipEventRecord(s->ev_join, s->side));
     hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, loss_out, loss_accum);
     // ---- GRU backward through time, then its weight gradients over all steps at once
     hipLaunchKernelGGL(k_sv_gru_bwd, dim3(1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], T, R, s->H, s->Gr,
@@ -689,6 +711,7 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
     RTX_HIP(hipMemsetAsync(s->grads[sv_tail(s, SV_T_EMB)], 0, sizeof(float) * (size_t)I * E, st));
     hipLaunchKernelGGL(k_sv_embed_grad, dim3(T), dim3(256), 0, st, items, T, E, s->dX, s->grads[sv_tail(s, SV_T_EMB)]);
     RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
     // ---- torch.optim.Adam (coupled weight decay 5e-3, models.py:1618-1620) over every tensor
     RtxAdamArgs a = {};
     a.n = 0;
