@@ -93,6 +93,16 @@ def cpu_baseline(X, dims, batch, seconds):
                           "ms_sampler": smp8 * 1e3, "ms_step_only": (per8 - smp8) * 1e3}}
 
 
+def _flush_c_stdio():
+    """RCCL writes an informational line through C stdio, which (not a tty) sits in libc's buffer until exit and would land
+    AFTER the result line: flush libc early (every rank, once the communicator exists) and again before the JSON."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def main():
     args = parse()
     from rectorch_amd import parallel
@@ -146,6 +156,8 @@ def main():
             model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
 
     run(args.warmup, 0)
+    torch.cuda.synchronize()
+    _flush_c_stdio()
     eng = net._rtx_engines[args.numerics]
     eng.set_timing("adam", True)            # HIP events around the dominant kernel, on the compute stream
     torch.cuda.synchronize()
@@ -210,9 +222,11 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline and not Cd:
         out["cpu_baseline"] = cpu_baseline(X, (I, H, L), B, args.cpu_seconds)
-    print(json.dumps(out))
     if dist.is_initialized():
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # RCCL may print while it shuts down: keep the JSON line the last one
+    _flush_c_stdio()
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
