@@ -150,7 +150,8 @@ struct RtxAdamTensor {
     void* sh;    // T [rows_p][ld_sh]   compute copy, same orientation   (nullable)
     void* shT;   // T [cols_p][ld_shT]  compute copy, transposed          (nullable)
     int rows, cols, ld_sh, ld_shT;
-    int tile_start;  // first 64x64 tile of this tensor in the launch
+    int tile_start;  // first tile of this tensor in the launch
+    int flat;        // filled by rtx_launch_adam: walked as one contiguous array in chunks of 4096 elements (see k_adam)
 };
 struct RtxAdamArgs {
     RtxAdamTensor t[RTX_MAX_TENSORS];
