@@ -42,7 +42,7 @@ struct rtx_svae {
     float *X = nullptr, *GI = nullptr, *H = nullptr, *Gr = nullptr, *Gz = nullptr, *Gn = nullptr, *Ghn = nullptr;
     float *mu = nullptr, *lv = nullptr, *eps = nullptr, *zl = nullptr, *dz = nullptr;
     float *dH = nullptr, *dGI = nullptr, *dGH = nullptr, *dX = nullptr;
-    float *row_loss = nullptr, *tsum = nullptr, *kl_rows = nullptr;
+    float *row_loss = nullptr, *kl_rows = nullptr;
     float* part = nullptr;           // split-K partial sums
     float* part2 = nullptr;          // ... of the GEMMs on the side stream
     hipStream_t side = nullptr;      // weight-gradient GEMMs of the MLPs: they overlap the single-workgroup GRU backward
@@ -567,7 +567,7 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
     SV_ALLOC(s->Gr, T * R); SV_ALLOC(s->Gz, T * R); SV_ALLOC(s->Gn, T * R); SV_ALLOC(s->Ghn, T * R);
     SV_ALLOC(s->mu, T * Z); SV_ALLOC(s->lv, T * Z); SV_ALLOC(s->eps, T * Z); SV_ALLOC(s->zl, T * Z); SV_ALLOC(s->dz, T * Z);
     SV_ALLOC(s->dH, T * R); SV_ALLOC(s->dGI, T * 3 * R); SV_ALLOC(s->dGH, T * 3 * R); SV_ALLOC(s->dX, T * E);
-    SV_ALLOC(s->row_loss, T); SV_ALLOC(s->tsum, T); SV_ALLOC(s->kl_rows, T);
+    SV_ALLOC(s->row_loss, T); SV_ALLOC(s->kl_rows, T);
     SV_ALLOC(s->WhhT, 3 * R * R);
     {
         size_t widest = std::max((size_t)std::max(R, E), Z);

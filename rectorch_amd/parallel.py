@@ -20,7 +20,6 @@ each already scaled by 1/B_global.  One exchange per step:
 Small layers are coalesced into one message (``min_bucket_bytes``).  Works with any torch.distributed
 backend: "nccl" (= RCCL on ROCm) for device tensors, "gloo" for the CPU tests of the plan itself.
 """
-import numpy as np
 import torch
 import torch.distributed as dist
 
