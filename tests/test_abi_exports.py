@@ -73,3 +73,14 @@ def test_graft_entry_build_succeeds():
         sys.path.insert(0, ROOT)
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_integration_stub_structs_match_the_binding():
+    """the ctypes structs shown in INTEGRATION.md list the same fields, in the same order, as rectorch_amd/_lib.py"""
+    from rectorch_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, struct in (("Cfg", _lib.Cfg), ("Batch", _lib.Batch), ("Step", _lib.Step)):
+        m = re.search(r"class %s\(C\.Structure\):.*?_fields_ = \[(.*?)\]\s*(?:#.*)?\n(?:class|\n|def)" % name, text, re.S)
+        assert m, "struct %s not found in INTEGRATION.md" % name
+        fields = re.findall(r'\("(\w+)"', m.group(1))
+        assert fields == [f[0] for f in struct._fields_], (name, fields)
