@@ -84,3 +84,27 @@ def test_integration_stub_structs_match_the_binding():
         assert m, "struct %s not found in INTEGRATION.md" % name
         fields = re.findall(r'\("(\w+)"', m.group(1))
         assert fields == [f[0] for f in struct._fields_], (name, fields)
+
+
+def _header_struct_fields(name):
+    text = open(os.path.join(ROOT, "include", "rectorch_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    bodies = {n: b for b, n in re.findall(r"typedef struct \{([^{}]*)\}\s*(\w+);", text)}
+    assert name in bodies, name
+    out = []
+    for decl in bodies[name].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        # drop the type: everything up to the last space before the first declarator
+        decl = re.sub(r"^(?:const\s+)?\w+(?:\s*\*)?\s+", "", decl)
+        for d in decl.split(","):
+            out.append(re.sub(r"[\*\s]|\[.*?\]", "", d))
+    return out
+
+
+def test_header_struct_fields_match_the_binding():
+    """field names and order of the C structs in include/rectorch_hip.h equal the ctypes mirrors"""
+    from rectorch_amd import _lib
+    for cname, struct in (("rtx_cfg", _lib.Cfg), ("rtx_batch", _lib.Batch), ("rtx_step", _lib.Step), ("rtx_svae_cfg", _lib.SvaeCfg)):
+        assert _header_struct_fields(cname) == [f[0] for f in struct._fields_], cname
