@@ -6,7 +6,8 @@
 // GEMM of this library (gemm.hip, 64x64 of C per wave) is bound by LDS bandwidth there: a wave reads 16 KB of LDS per
 // 128-byte K slice for 32 MFMAs.  This kernel gives each wave 128x64 of C (4x2 MFMA 32x32 accumulators, 128 VGPRs): 24 KB
 // of LDS reads per slice feed 64 MFMAs -- 1.33x the flops per LDS byte -- on a 256x128 workgroup tile (4 waves), with
-// the same global -> register -> LDS staging, two register sets in flight and one barrier per slice.
+// the same global -> register -> LDS staging, two register sets in flight and one barrier per slice (rtx_syrk_lower), or
+// -- the default -- LDS-DMA staging through a ring of three stages with counted waits (rtx_syrk_lower_dma, below).
 // (A slice-major operand layout, [K / 128 B][row][128 B], was measured as well -- the K-contiguous rows put the 384 rows a
 // workgroup touches per slice on 384 different pages -- and made no difference; the kernel takes either through
 // row_bytes / slice_bytes.)  With the 32x32x16 fp8 MFMA the kernel runs at 1.4 PFLOP/s on the lower triangle, 56 % of
@@ -215,6 +216,131 @@ __global__ __launch_bounds__(256, 1) void rtx_syrk_lower(const RtxSyrk p)
             for (int e = 0; e < 16; ++e) cp[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldc + j * 32] = acc[i][j][e];
 }
 
+// ---- LDS-DMA variant ------------------------------------------------------------------------------------------------
+// Same tile geometry, but the operand slices go global -> LDS directly (global_load_lds_dwordx4: no staging registers,
+// no ds_write pass), through a ring of THREE stages, with counted waits: at the top of iteration t a wave waits for its
+// own loads of slice t (vmcnt(12): the 12 loads of slice t+1 stay in flight across the barrier), the workgroup barrier
+// makes everybody's slice t visible and retires everybody's reads of slice t-1, whose stage is then refilled with
+// slice t+2.  The DMA writes LDS lane-linear (wave-uniform base + lane * 16 B), so rows are 128 B apart with no padding;
+// bank conflicts of the fragment reads are avoided by an XOR swizzle of the 16-byte chunk index with (row & 7), applied
+// to the per-lane GLOBAL address (the 8 lanes of a row still read one 128-byte line) and to the ds_read address.
+#define SYG_STAGE ((256 + 128) * 128)
+
+template <int FP8>
+__global__ __launch_bounds__(256, 1) void rtx_syrk_lower_dma(const RtxSyrk p)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 3 * SYG_STAGE
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, g = lane >> 5;
+    int tm, tn;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int patch = xcd + 8 * (j >> 5), within = j & 31;
+        int pm = (int)((sqrtf(8.f * (float)patch + 1.f) - 1.f) * 0.5f);
+        while ((pm + 1) * (pm + 2) / 2 <= patch) ++pm;
+        while (pm * (pm + 1) / 2 > patch) --pm;
+        const int pn = patch - pm * (pm + 1) / 2;
+        tm = pm * 4 + (within & 3);
+        tn = pn * 8 + (within >> 2);
+        if (tm >= p.m_tiles || tn >= p.n_tiles || tn > 2 * tm + 1) return;
+    }
+    const size_t rowb = (size_t)p.row_bytes, sliceb = (size_t)p.slice_bytes;
+    // lane -> (row within an 8-row block, swizzled chunk) of the 1-KB block a wave instruction moves
+    const int brow = lane >> 3, chunk = (lane & 7) ^ brow;
+    const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * 256 + wave * 8 + brow) * rowb + chunk * 16;   // + 32 rows per block step
+    const unsigned char* gB = (const unsigned char*)p.A + ((size_t)tn * 128 + wave * 8 + brow) * rowb + chunk * 16;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    lds_byte* lbase = (lds_byte*)smem;
+
+    sy_f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // wave w moves the 8-row blocks w, w+4, ... : 8 blocks of A (256 rows) and 4 of B (128 rows) per slice
+#define SYG_LOAD(stage, ks)                                                                                          \
+    {                                                                                                                \
+        lds_byte* sb = lbase + (stage) * SYG_STAGE + wave * 1024;                                                    \
+        const unsigned char* a_ = gA + (size_t)(ks) * sliceb;                                                        \
+        const unsigned char* b_ = gB + (size_t)(ks) * sliceb;                                                        \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                                \
+            __builtin_amdgcn_global_load_lds((const void*)(a_ + (size_t)q * 32 * rowb), (void __attribute__((address_space(3)))*)(sb + q * 4096), 16, 0, 0); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                \
+            __builtin_amdgcn_global_load_lds((const void*)(b_ + (size_t)q * 32 * rowb), (void __attribute__((address_space(3)))*)(sb + 256 * 128 + q * 4096), 16, 0, 0); \
+    }
+    // fragment reads: row R of the tile at R * 128, 16-byte chunk c at slot c ^ (R & 7); R & 7 == r & 7 for every fragment row
+// The fragment reads are inline asm: a compiler-visible LDS read placed after an LDS-DMA in flight gets an
+// `s_waitcnt vmcnt(0)` in front of it (the DMA could alias it), which would drain the ring every iteration.  The asm reads
+// are ordered by hand: LDS operations retire in order, so `lgkmcnt(6)` after issuing the next set of six means "the previous
+// set has arrived"; a sched_barrier behind the wait keeps the machine scheduler from hoisting the MFMAs above it.
+#define SYG_RD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+#define SYG_FRAG(F, kk)                                                                               \
+    {                                                                                                 \
+        const unsigned sl = (unsigned)(((g + 2 * (kk)) ^ (r & 7)) * 16);                              \
+        SYG_RD(F##b0, sB + sl) SYG_RD(F##b1, sB + 32 * 128 + sl)                                      \
+        SYG_RD(F##a0, sA + sl) SYG_RD(F##a1, sA + 32 * 128 + sl)                                      \
+        SYG_RD(F##a2, sA + 64 * 128 + sl) SYG_RD(F##a3, sA + 96 * 128 + sl)                           \
+    }
+#define SYG_WAIT(F, n)                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);
+#define SYG_MMA(F)                                                                                    \
+    SyMma<FP8>::run(acc[0][0], F##a0, F##b0); SyMma<FP8>::run(acc[0][1], F##a0, F##b1);               \
+    SyMma<FP8>::run(acc[1][0], F##a1, F##b0); SyMma<FP8>::run(acc[1][1], F##a1, F##b1);               \
+    SyMma<FP8>::run(acc[2][0], F##a2, F##b0); SyMma<FP8>::run(acc[2][1], F##a2, F##b1);               \
+    SyMma<FP8>::run(acc[3][0], F##a3, F##b0); SyMma<FP8>::run(acc[3][1], F##a3, F##b1);
+
+    const int nk = p.k_slices;
+    SYG_LOAD(0, 0)
+    SYG_LOAD(1, min(1, nk - 1))
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // my loads of slice t have landed (slice t+1 may be in flight)
+        __builtin_amdgcn_s_barrier();                        // everybody's have; everybody is done reading slice t-1
+        {
+            const int nst = stage == 0 ? 2 : stage - 1;      // (t + 2) % 3 == (t - 1) % 3: the stage just released
+            SYG_LOAD(nst, min(t + 2, nk - 1))                // past the end: a harmless reload, keeps the counts static
+        }
+        {
+            // LDS byte addresses (the asm reads take the 32-bit LDS offset)
+            const unsigned sA = (unsigned)(size_t)(lbase + stage * SYG_STAGE + (wm * 128 + r) * 128);
+            const unsigned sB = (unsigned)(size_t)(lbase + stage * SYG_STAGE + (256 + wn * 64 + r) * 128);
+            uint4 xa0, xa1, xa2, xa3, xb0, xb1, ya0, ya1, ya2, ya3, yb0, yb1;
+            SYG_FRAG(x, 0)
+            SYG_FRAG(y, 1)
+            SYG_WAIT(x, 6)
+            SYG_MMA(x)
+            SYG_FRAG(x, 2)
+            SYG_WAIT(y, 6)
+            SYG_MMA(y)
+            SYG_FRAG(y, 3)
+            SYG_WAIT(x, 6)
+            SYG_MMA(x)
+            SYG_WAIT(y, 0)
+            SYG_MMA(y)
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the two reloads past the end
+#undef SYG_LOAD
+#undef SYG_FRAG
+#undef SYG_MMA
+#undef SYG_RD
+#undef SYG_WAIT
+    float* cp = p.C + ((size_t)tm * 256 + wm * 128 + 4 * g) * p.ldc + (size_t)tn * 128 + wn * 64 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cp[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldc + j * 32] = acc[i][j][e];
+}
+
 int rtx_syrk_lower_launch(const void* A, long row_bytes, long slice_bytes, int rows256, int cols128, int k_slices, int fp8, float* C, long ldc, hipStream_t stream)
 {
     RTX_CHECK(A && C && rows256 > 0 && k_slices > 0, RTX_EINVAL, "syrk: bad arguments");
@@ -229,6 +355,21 @@ int rtx_syrk_lower_launch(const void* A, long row_bytes, long slice_bytes, int r
     const int pr = (rows256 + 3) / 4;                 // 1024-row patch rows
     const int patches = pr * (pr + 1) / 2;
     const dim3 grid((unsigned)(8 * ((patches + 7) / 8) * 32));
+    static int dma = -1;
+    if (dma < 0) {
+        const char* v = getenv("RTX_SYRK_DMA");
+        dma = v ? atoi(v) : 1;   // default; 0 selects the register-staged kernel above (measurement switch)
+        if (dma) {
+            RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SYG_STAGE));
+            RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SYG_STAGE));
+        }
+    }
+    if (dma) {
+        if (fp8) hipLaunchKernelGGL(rtx_syrk_lower_dma<1>, grid, dim3(256), 3 * SYG_STAGE, stream, p);
+        else hipLaunchKernelGGL(rtx_syrk_lower_dma<0>, grid, dim3(256), 3 * SYG_STAGE, stream, p);
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
+    }
     static int k64 = -1;
     if (k64 < 0) { const char* v = getenv("RTX_SYRK_FP8_K64"); k64 = (v && atoi(v)) ? 1 : 0; }   // 1: v_mfma_f32_32x32x64_f8f6f4
     if (fp8 && k64)
