@@ -341,6 +341,150 @@ __global__ __launch_bounds__(256, 1) void rtx_syrk_lower_dma(const RtxSyrk p)
             for (int e = 0; e < 16; ++e) cp[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldc + j * 32] = acc[i][j][e];
 }
 
+// ---- 256 x 256 tile, 8 waves ------------------------------------------------------------------------------------------
+// Same per-wave work (128 x 64 of C) and the same LDS-DMA staging, but eight waves share a 256 x 256 tile: two waves per
+// SIMD, so one wave's barrier / fragment-read phases run under the other's MFMAs, and a slice of operand bytes feeds twice
+// the flops.  Two LDS stages of 64 KB: slice t+1 is requested right behind the barrier of slice t and has that whole
+// slice's compute time to land, so the wait at the top of an iteration is a plain vmcnt(0).
+#define SY8_STAGE (512 * 128)
+
+template <int FP8>
+__global__ __launch_bounds__(512, 1) void rtx_syrk_lower_dma8(const RtxSyrk p)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 * SY8_STAGE
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, g = lane >> 5;
+    // patches of 8 x 4 tiles (2048 rows x 1024 columns of C) over the lower triangle: 32 tiles = one per CU of an XCD
+    int tm, tn;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int patch = xcd + 8 * (j >> 5), within = j & 31;
+        int pm = (int)((sqrtf(4.f * (float)patch + 1.f) - 1.f) * 0.5f);
+        while ((pm + 1) * (pm + 2) <= patch) ++pm;
+        while (pm * (pm + 1) > patch) --pm;
+        const int pn = patch - pm * (pm + 1);      // 0 .. 2 pm + 1
+        tm = pm * 8 + (within & 7);
+        tn = pn * 4 + (within >> 3);
+        if (tm >= p.m_tiles || tn > tm) return;    // m_tiles = 256-row tiles; C is square
+    }
+    const size_t rowb = (size_t)p.row_bytes, sliceb = (size_t)p.slice_bytes;
+    const int brow = lane >> 3, chunk = (lane & 7) ^ brow;
+    const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * 256 + wave * 8 + brow) * rowb + chunk * 16;   // + 64 rows per block step
+    const unsigned char* gB = (const unsigned char*)p.A + ((size_t)tn * 256 + wave * 8 + brow) * rowb + chunk * 16;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    lds_byte* lbase = (lds_byte*)smem;
+
+    sy_f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // wave w moves the 8-row blocks w, w+8, w+16, w+24 of A and of B (256 rows each) per slice
+#define SY8_LOAD(stage, ks)                                                                                          \
+    {                                                                                                                \
+        lds_byte* sb = lbase + (stage) * SY8_STAGE + wave * 1024;                                                    \
+        const unsigned char* a_ = gA + (size_t)(ks) * sliceb;                                                        \
+        const unsigned char* b_ = gB + (size_t)(ks) * sliceb;                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+            __builtin_amdgcn_global_load_lds((const void*)(a_ + (size_t)q * 64 * rowb), (void __attribute__((address_space(3)))*)(sb + q * 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const void*)(b_ + (size_t)q * 64 * rowb), (void __attribute__((address_space(3)))*)(sb + 256 * 128 + q * 8192), 16, 0, 0); \
+        }                                                                                                            \
+    }
+#define SY8_RD(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+#define SY8_FRAG(F, kk)                                                                               \
+    {                                                                                                 \
+        const unsigned sl = (unsigned)(((g + 2 * (kk)) ^ (r & 7)) * 16);                              \
+        SY8_RD(F##b0, sB + sl) SY8_RD(F##b1, sB + 32 * 128 + sl)                                      \
+        SY8_RD(F##a0, sA + sl) SY8_RD(F##a1, sA + 32 * 128 + sl)                                      \
+        SY8_RD(F##a2, sA + 64 * 128 + sl) SY8_RD(F##a3, sA + 96 * 128 + sl)                           \
+    }
+#define SY8_WAIT(n)                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);
+#define SY8_MMA(F)                                                                                    \
+    SyMma<FP8>::run(acc[0][0], F##a0, F##b0); SyMma<FP8>::run(acc[0][1], F##a0, F##b1);               \
+    SyMma<FP8>::run(acc[1][0], F##a1, F##b0); SyMma<FP8>::run(acc[1][1], F##a1, F##b1);               \
+    SyMma<FP8>::run(acc[2][0], F##a2, F##b0); SyMma<FP8>::run(acc[2][1], F##a2, F##b1);               \
+    SyMma<FP8>::run(acc[3][0], F##a3, F##b0); SyMma<FP8>::run(acc[3][1], F##a3, F##b1);
+
+    const int nk = p.k_slices;
+    SY8_LOAD(0, 0)
+    for (int t = 0; t < nk; ++t) {
+        const int stage = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my loads of slice t have landed
+        __builtin_amdgcn_s_barrier();                        // everybody's have; everybody is done reading slice t-1
+        SY8_LOAD(1 - stage, min(t + 1, nk - 1))              // past the end: a harmless reload
+        {
+            const unsigned sA = (unsigned)(size_t)(lbase + stage * SY8_STAGE + (wm * 128 + r) * 128);
+            const unsigned sB = (unsigned)(size_t)(lbase + stage * SY8_STAGE + (256 + wn * 64 + r) * 128);
+            if constexpr (FP8 == 2) {
+                // v_mfma_f32_32x32x64_f8f6f4: a lane feeds 32 bytes (chunks 2c, 2c+1 with c = g + 2 kk) per operand
+                uint4 xa0l, xa0h, xa1l, xa1h, xa2l, xa2h, xa3l, xa3h, xb0l, xb0h, xb1l, xb1h;
+                uint4 ya0l, ya0h, ya1l, ya1h, ya2l, ya2h, ya3l, ya3h, yb0l, yb0h, yb1l, yb1h;
+#define SY8_FRAG2(F, kk)                                                                              \
+    {                                                                                                 \
+        const unsigned s0 = (unsigned)((((2 * g + 4 * (kk)) ^ (r & 7)) * 16));                        \
+        const unsigned s1 = (unsigned)((((2 * g + 4 * (kk) + 1) ^ (r & 7)) * 16));                    \
+        SY8_RD(F##b0l, sB + s0) SY8_RD(F##b0h, sB + s1)                                               \
+        SY8_RD(F##b1l, sB + 32 * 128 + s0) SY8_RD(F##b1h, sB + 32 * 128 + s1)                         \
+        SY8_RD(F##a0l, sA + s0) SY8_RD(F##a0h, sA + s1)                                               \
+        SY8_RD(F##a1l, sA + 32 * 128 + s0) SY8_RD(F##a1h, sA + 32 * 128 + s1)                         \
+        SY8_RD(F##a2l, sA + 64 * 128 + s0) SY8_RD(F##a2h, sA + 64 * 128 + s1)                         \
+        SY8_RD(F##a3l, sA + 96 * 128 + s0) SY8_RD(F##a3h, sA + 96 * 128 + s1)                         \
+    }
+#define SY8_MMA2(F)                                                                                   \
+    sy_mma_k64(acc[0][0], F##a0l, F##a0h, F##b0l, F##b0h); sy_mma_k64(acc[0][1], F##a0l, F##a0h, F##b1l, F##b1h); \
+    sy_mma_k64(acc[1][0], F##a1l, F##a1h, F##b0l, F##b0h); sy_mma_k64(acc[1][1], F##a1l, F##a1h, F##b1l, F##b1h); \
+    sy_mma_k64(acc[2][0], F##a2l, F##a2h, F##b0l, F##b0h); sy_mma_k64(acc[2][1], F##a2l, F##a2h, F##b1l, F##b1h); \
+    sy_mma_k64(acc[3][0], F##a3l, F##a3h, F##b0l, F##b0h); sy_mma_k64(acc[3][1], F##a3l, F##a3h, F##b1l, F##b1h);
+                SY8_FRAG2(x, 0)
+                SY8_FRAG2(y, 1)
+                SY8_WAIT(12)
+                SY8_MMA2(x)
+                SY8_WAIT(0)
+                SY8_MMA2(y)
+#undef SY8_FRAG2
+#undef SY8_MMA2
+            } else {
+                uint4 xa0, xa1, xa2, xa3, xb0, xb1, ya0, ya1, ya2, ya3, yb0, yb1;
+                SY8_FRAG(x, 0)
+                SY8_FRAG(y, 1)
+                SY8_WAIT(6)
+                SY8_MMA(x)
+                SY8_FRAG(x, 2)
+                SY8_WAIT(6)
+                SY8_MMA(y)
+                SY8_FRAG(y, 3)
+                SY8_WAIT(6)
+                SY8_MMA(x)
+                SY8_WAIT(0)
+                SY8_MMA(y)
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef SY8_LOAD
+#undef SY8_RD
+#undef SY8_FRAG
+#undef SY8_WAIT
+#undef SY8_MMA
+    const int ncols = p.n_tiles * 128;
+    float* cp = p.C + ((size_t)tm * 256 + wm * 128 + 4 * g) * p.ldc + (size_t)tn * 256 + wn * 64 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (tn * 256 + wn * 64 + j * 32 >= ncols) continue;   // the last 256-column tile may overhang an odd number of 128-blocks
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cp[(size_t)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.ldc + j * 32] = acc[i][j][e];
+        }
+}
+
 int rtx_syrk_lower_launch(const void* A, long row_bytes, long slice_bytes, int rows256, int cols128, int k_slices, int fp8, float* C, long ldc, hipStream_t stream)
 {
     RTX_CHECK(A && C && rows256 > 0 && k_slices > 0, RTX_EINVAL, "syrk: bad arguments");
@@ -358,11 +502,30 @@ int rtx_syrk_lower_launch(const void* A, long row_bytes, long slice_bytes, int r
     static int dma = -1;
     if (dma < 0) {
         const char* v = getenv("RTX_SYRK_DMA");
-        dma = v ? atoi(v) : 1;   // default; 0 selects the register-staged kernel above (measurement switch)
+        dma = v ? atoi(v) : 8;   // default 8: 256x256 tiles / 8 waves; 1: 256x128 / 4 waves; 0: register-staged (measurement switch)
         if (dma) {
             RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SYG_STAGE));
             RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SYG_STAGE));
         }
+    }
+    if (dma == 8) {   // 256 x 256 tiles, 8 waves
+        static bool conf8 = false;
+        if (!conf8) {
+            RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma8<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SY8_STAGE));
+            RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma8<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SY8_STAGE));
+            RTX_HIP(hipFuncSetAttribute((const void*)rtx_syrk_lower_dma8<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SY8_STAGE));
+            conf8 = true;
+        }
+        const int pm8 = (rows256 + 7) / 8;
+        const int patches8 = pm8 * (pm8 + 1);
+        const dim3 grid8((unsigned)(8 * ((patches8 + 7) / 8) * 32));
+        static int k64_8 = -1;
+        if (k64_8 < 0) { const char* v = getenv("RTX_SYRK_FP8_K64"); k64_8 = v ? (atoi(v) ? 1 : 0) : 1; }   // default: the double-rate instruction
+        if (fp8 && k64_8) hipLaunchKernelGGL(rtx_syrk_lower_dma8<2>, grid8, dim3(512), 2 * SY8_STAGE, stream, p);
+        else if (fp8) hipLaunchKernelGGL(rtx_syrk_lower_dma8<1>, grid8, dim3(512), 2 * SY8_STAGE, stream, p);
+        else hipLaunchKernelGGL(rtx_syrk_lower_dma8<0>, grid8, dim3(512), 2 * SY8_STAGE, stream, p);
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
     }
     if (dma) {
         if (fp8) hipLaunchKernelGGL(rtx_syrk_lower_dma<1>, grid, dim3(256), 3 * SYG_STAGE, stream, p);
