@@ -166,7 +166,8 @@ int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_i
 /* ---- EASE closed-form model (rectorch/models.py:1003-1069) ------------------------------------------
  * rtx_ease_fit replaces EASE.train (models.py:1015-1025: G = X^T X; G[diag] += lam; P = inv(G); B = P / (-diag P);
  * B[diag] = 0) with the Gram matrix, a blocked f64 Cholesky, the triangular inverse and P = W^T W all on f64 MFMA
- * (Gram matrix on bf16 MFMA when that is exact: integer-valued data, max|x|^2 * n_users < 2^24).  The item-item
+ * (Gram matrix on fp8 / bf16 MFMA when that is exact: data that are integers after a power-of-two scale <= 8, with
+ * max|s x|^2 * n_users < 2^24; float64 MFMA otherwise).  The item-item
  * matrix B stays in HBM as double [n_items][n_items]; rtx_ease_scores replaces `model = X.dot(B)` + the look-up of
  * EASE.predict (models.py:1025, 1054-1057): rows `row_ids` (nullable = 0..batch-1) of X times B into out (device
  * double [batch][n_items]), with -inf at the non-zero entries of row b (or mask_row_ids[b]) of `mask` when given.

@@ -36,18 +36,20 @@ struct rtx_ease {
 };
 
 // ------------------------------------------------------------------------------------------------ kernels
-__global__ __launch_bounds__(256) void k_ease_scatter_T16(const int64_t* indptr, const int32_t* indices, const float* values, long ldu, bf16_t* XT)
+__global__ __launch_bounds__(256) void k_ease_scatter_T16(const int64_t* indptr, const int32_t* indices, const float* values, float vscale, long ldu,
+                                                          bf16_t* XT)
 {
     const int64_t u = blockIdx.x;
     for (int64_t k = indptr[u] + threadIdx.x; k < indptr[u + 1]; k += 256)
-        XT[(size_t)indices[k] * ldu + u] = f32_to_bf16(values ? values[k] : 1.f);
+        XT[(size_t)indices[k] * ldu + u] = f32_to_bf16(values ? values[k] * vscale : 1.f);
 }
 // fp8 flavour: the hardware conversion produces the encoding the MFMA consumes (exact for integers |v| <= 16)
-__global__ __launch_bounds__(256) void k_ease_scatter_T8(const int64_t* indptr, const int32_t* indices, const float* values, long ldu, uint8_t* XT)
+__global__ __launch_bounds__(256) void k_ease_scatter_T8(const int64_t* indptr, const int32_t* indices, const float* values, float vscale, long ldu,
+                                                         uint8_t* XT)
 {
     const int64_t u = blockIdx.x;
     for (int64_t k = indptr[u] + threadIdx.x; k < indptr[u + 1]; k += 256)
-        XT[(size_t)indices[k] * ldu + u] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(values ? values[k] : 1.f, 0.f, 0, false) & 0xff);
+        XT[(size_t)indices[k] * ldu + u] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(values ? values[k] * vscale : 1.f, 0.f, 0, false) & 0xff);
 }
 __global__ __launch_bounds__(256) void k_ease_scatter_T64(const int64_t* indptr, const int32_t* indices, const float* values, long ldu, double* XT)
 {
@@ -58,14 +60,14 @@ __global__ __launch_bounds__(256) void k_ease_scatter_T64(const int64_t* indptr,
 
 // A (f64 [np][np]) = G (+ lam on the real diagonal, 1 on the padded diagonal, 0 elsewhere in the pad)
 template <typename TG>
-__global__ __launch_bounds__(256) void k_ease_init(const TG* G, long ldg, double* A, int n, int np, double lam)
+__global__ __launch_bounds__(256) void k_ease_init(const TG* G, long ldg, double* A, int n, int np, double lam, double ginv)
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)np * np) return;
     const int i = (int)(idx / np), j = (int)(idx % np);
     double v = 0.0;
     if (i < n && j < n) {   // the Gram kernels fill the lower triangle and the whole diagonal tiles
-        if (i >= j || (i >> 7) == (j >> 7)) v = (double)G[(size_t)i * ldg + j] + (i == j ? lam : 0.0);
+        if (i >= j || (i >> 7) == (j >> 7)) v = (double)G[(size_t)i * ldg + j] * ginv + (i == j ? lam : 0.0);   // ginv = 1 / s^2: a power of two
     }
     else if (i == j) v = 1.0;
     A[idx] = v;
@@ -234,16 +236,25 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
         // ---- exactness test for the low-precision Gram paths (host pass over the values; binary data has values == NULL):
         //      integer-valued entries whose products sum below 2^24 are exact in f32 accumulators; the operands are exact
         //      in fp8 e4m3 up to |v| = 16 and in bf16 up to |v| = 256
+        //      Dyadic ratings (half or quarter stars) become integers after a power-of-two scale s: G = (sX)^T (sX) / s^2,
+        //      with the division exact in float64 -- so explicit-feedback data take the MFMA path too.
         int gram = RTX_DT_FP8;   // RTX_DT_FP8 / RTX_DT_BF16, or RTX_DT_F32 meaning "no: use the f64 path"
+        float vscale = 1.f;      // s
         {
             double mx = 1.0;
             if (X->values && X->nnz > 0) {
                 std::vector<float> hv((size_t)X->nnz);
                 EASE_HIP(hipMemcpy(hv.data(), X->values, sizeof(float) * X->nnz, hipMemcpyDeviceToHost));
-                mx = 0;
-                for (float v : hv) {
-                    if (v != rintf(v) || fabsf(v) > 256.f) { gram = RTX_DT_F32; break; }
-                    mx = fmax(mx, fabs((double)v));
+                gram = RTX_DT_F32;
+                for (float s : {1.f, 2.f, 4.f, 8.f}) {
+                    bool ok = true;
+                    double m = 0;
+                    for (float v : hv) {
+                        const float sv = v * s;
+                        if (sv != rintf(sv) || fabsf(sv) > 256.f) { ok = false; break; }
+                        m = fmax(m, fabs((double)sv));
+                    }
+                    if (ok) { gram = RTX_DT_FP8; vscale = s; mx = m; break; }
                 }
             }
             if (gram != RTX_DT_F32 && mx * mx * (double)U >= 16777216.0) gram = RTX_DT_F32;
@@ -251,6 +262,7 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             const char* force = getenv("RTX_EASE_GRAM");   // "bf16" / "f64": measurement switch
             if (force && gram == RTX_DT_FP8 && !strcmp(force, "bf16")) gram = RTX_DT_BF16;
             if (force && !strcmp(force, "f64")) gram = RTX_DT_F32;
+            if (gram == RTX_DT_F32) vscale = 1.f;
         }
         EASE_TRY(dalloc((void**)&A, sizeof(double) * (size_t)np * np, pool));
         EASE_HIP(hipEventRecord(e0, st));
@@ -265,9 +277,9 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             EASE_TRY(dalloc((void**)&G32, sizeof(float) * (size_t)np256 * np, pool));
             EASE_HIP(hipMemsetAsync(XT, 0, (size_t)esz * np256 * Up, st));
             if (gram == RTX_DT_FP8)
-                hipLaunchKernelGGL(k_ease_scatter_T8, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, (uint8_t*)XT);
+                hipLaunchKernelGGL(k_ease_scatter_T8, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, vscale, Up, (uint8_t*)XT);
             else
-                hipLaunchKernelGGL(k_ease_scatter_T16, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, (bf16_t*)XT);
+                hipLaunchKernelGGL(k_ease_scatter_T16, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, vscale, Up, (bf16_t*)XT);
             const char* sy = getenv("RTX_EASE_SYRK");   // "0": the general GEMM with its lower-triangle patch order (measurement switch)
             if (sy && !strcmp(sy, "0")) {
                 RtxGemm g = {};
@@ -278,7 +290,8 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             } else {
                 EASE_TRY(rtx_syrk_lower_launch(XT, Up * esz, 128, (int)(np256 / 256), KB, (int)(Up * esz / 128), gram == RTX_DT_FP8, G32, np, st));
             }
-            hipLaunchKernelGGL(k_ease_init<float>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G32, (long)np, A, n, np, lam);
+            hipLaunchKernelGGL(k_ease_init<float>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G32, (long)np, A, n, np, lam,
+                               1.0 / ((double)vscale * vscale));
         } else {
             const long Up = ((U + 15) / 16) * 16;
             double* XT = nullptr;
@@ -289,7 +302,7 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             hipLaunchKernelGGL(k_ease_scatter_T64, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, Up, XT);
             EASE_TRY(dgemm(XT, Up, XT, Up, KB, KB, (int)(Up / 16), G64, np, nullptr, 0, 1.0, 0.0, 1, RTX_DK_ALL, RTX_DK_ALL, st));
             // mirror is not needed: only the lower triangle of A is read below; init copies what is there
-            hipLaunchKernelGGL(k_ease_init<double>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G64, (long)np, A, n, np, lam);
+            hipLaunchKernelGGL(k_ease_init<double>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G64, (long)np, A, n, np, lam, 1.0);
         }
         EASE_HIP(hipGetLastError());
         EASE_HIP(hipEventRecord(e1, st));

@@ -970,3 +970,16 @@ def test_random_architectures_vs_oracle(seed):
     fin = np.isfinite(pred)
     # after two independent Adam trajectories the parameters differ by the few +-lr elements above: compare loosely
     assert rel(pred[fin], pref[fin]) < 5e-3
+
+
+@pytest.mark.parametrize("unit,U,I", [(0.25, 500, 260), (0.125, 300, 140), (0.3, 400, 200)])
+def test_ease_fractional_ratings(unit, U, I):
+    """dyadic rating steps (quarter / eighth stars) are scaled to integers and take the MFMA Gram path; a step of 0.3 is not
+    representable that way and takes the float64 path -- all equal to the numpy oracle"""
+    from oracle.ease_oracle import ease_fit
+    from rectorch_amd.engine import EaseSolver
+    rng = np.random.RandomState(int(unit * 1000))
+    X = ((rng.rand(U, I) < 0.12) * rng.randint(1, 9, size=(U, I))).astype(np.float32) * np.float32(unit)
+    B = EaseSolver(csr_matrix(X.astype(np.float64)), 20.0).weights().cpu().numpy()
+    Bo = ease_fit(X.astype(np.float64), 20.0)
+    assert np.max(np.abs(B - Bo)) <= 1e-10 * max(1.0, np.max(np.abs(Bo)))
