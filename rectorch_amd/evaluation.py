@@ -51,23 +51,36 @@ def _to_numpy(t):
     return t.cpu().numpy()
 
 
+class _PerUserResults:
+    """per-metric lists of per-batch arrays -> one array per metric, in loader order (reference evaluation.py:104-109)"""
+    def __init__(self, metric_list):
+        self._parts = {m: [] for m in metric_list}
+
+    def add(self, batch_result):
+        for m, values in batch_result.items():
+            self._parts[m].append(values)
+
+    def finish(self):
+        return {m: np.concatenate(parts) for m, parts in self._parts.items()}
+
+
+def _predict_numpy(model, data_tr):
+    """scores of one batch as a host array; the resident-rows shortcut of the device sampler survives the reshape"""
+    data_tensor = data_tr.view(data_tr.shape[0], -1)
+    rows = getattr(data_tr, "_rtx_rows", None)
+    if rows is not None:
+        data_tensor._rtx_rows = rows
+    return model.predict(data_tensor)[0].cpu().numpy()
+
+
 def evaluate(model, test_loader, metric_list):
     r"""Evaluate ``model`` on every batch of ``test_loader`` with every metric of ``metric_list``
     (``"name@k"`` strings).  Returns ``dict metric -> per-user numpy array`` in loader order
     (reference evaluation.py:67-110)."""
-    results = {m: [] for m in metric_list}
-    for _, (data_tr, heldout) in enumerate(test_loader):
-        data_tensor = data_tr.view(data_tr.shape[0], -1)
-        if getattr(data_tr, "_rtx_rows", None) is not None:
-            data_tensor._rtx_rows = data_tr._rtx_rows       # keep the resident-rows shortcut across .view()
-        recon_batch = model.predict(data_tensor)[0].cpu().numpy()
-        heldout = _to_numpy(heldout)
-        res = Metrics.compute(recon_batch, heldout, metric_list)
-        for m in res:
-            results[m].append(res[m])
-    for m in results:
-        results[m] = np.concatenate(results[m])
-    return results
+    out = _PerUserResults(metric_list)
+    for data_tr, heldout in test_loader:
+        out.add(Metrics.compute(_predict_numpy(model, data_tr), _to_numpy(heldout), metric_list))
+    return out.finish()
 
 
 def evaluate_device(model, test_loader, metric_list):
@@ -93,16 +106,13 @@ def evaluate_device(model, test_loader, metric_list):
     if not parsed or not resident:
         return evaluate(model, test_loader, metric_list)
     ks = sorted({k for _, _, k in parsed})
-    results = {m: [] for m in metric_list}
+    out = _PerUserResults(metric_list)
     for rb in test_loader.iter_rows():
         scores = model.predict(rb)[0]                    # HIP forward on the sparse rows, -inf at the train items
         ndcg, recall = topk_metrics(scores, rb.te, rb.rows, ks)
         ndcg, recall = ndcg.cpu().numpy(), recall.cpu().numpy()
-        for m, name, k in parsed:
-            results[m].append((ndcg if name == "ndcg" else recall)[ks.index(k)])
-    for m in results:
-        results[m] = np.concatenate(results[m])
-    return results
+        out.add({m: (ndcg if name == "ndcg" else recall)[ks.index(k)] for m, name, k in parsed})
+    return out.finish()
 
 
 def one_plus_random(model, test_loader, metric_list, r=1000):
@@ -110,24 +120,17 @@ def one_plus_random(model, test_loader, metric_list, r=1000):
     user, rank it against ``r`` random items the user has not interacted with in the held-out part and
     compute the metrics on those ``r + 1`` scores (the positive is column 0).  Raises ``ValueError`` when
     fewer than ``r`` negatives exist."""
-    results = {m: [] for m in metric_list}
-    for _, (data_tr, heldout) in enumerate(test_loader):
-        tot = set(range(heldout.shape[1]))
-        data_tensor = data_tr.view(data_tr.shape[0], -1)
-        recon_batch = model.predict(data_tensor)[0].cpu().numpy()
+    out = _PerUserResults(metric_list)
+    for data_tr, heldout in test_loader:
+        scores = _predict_numpy(model, data_tr)
         heldout = _to_numpy(heldout)
-        users, items = heldout.nonzero()
-        rows = []
-        for u, i in zip(users, items):
-            negatives = sorted(tot - set(heldout[u].nonzero()[0].tolist()))
-            rnd = random.sample(negatives, r)
-            rows.append(list(recon_batch[u][[i] + list(rnd)]))
-        pred = np.array(rows)
-        ground_truth = np.zeros_like(pred)
-        ground_truth[:, 0] = 1
-        res = Metrics.compute(pred, ground_truth, metric_list)
-        for m in res:
-            results[m].append(res[m])
-    for m in results:
-        results[m] = np.concatenate(results[m])
-    return results
+        all_items = set(range(heldout.shape[1]))
+        contests = []
+        for u, i in zip(*heldout.nonzero()):                 # one contest per held-out positive, in row-major order
+            negatives = sorted(all_items - set(heldout[u].nonzero()[0].tolist()))
+            contests.append(scores[u][[i] + random.sample(negatives, r)])   # the same draws as the reference's sampler
+        pred = np.array(contests)
+        truth = np.zeros_like(pred)
+        truth[:, 0] = 1
+        out.add(Metrics.compute(pred, truth, metric_list))
+    return out.finish()
