@@ -78,9 +78,9 @@ typedef struct {
     const float* eps_noise;      /* injected N(0,1) draws [batch][latent]  (NULL -> Philox)          */
 } rtx_step;
 
-/* rtx_engine_train_step fuses the Adam update of the large weight matrices into the epilogue of their
- * weight-gradient GEMM, so those gradients are never written to HBM; set this bit to ALSO store them in the
- * bound gradient buffers (p.grad in the Python mirror). */
+/* In bf16 numerics rtx_engine_train_step runs the Adam update of every weight matrix inside its weight-gradient
+ * kernel (dw_adam.hip), so those gradients are never written to HBM; set this bit to ALSO store them in the bound
+ * gradient buffers (p.grad in the Python mirror).  float32 numerics and rtx_engine_loss_grads always store them. */
 #define RTX_STEP_KEEP_GRADS 1
 
 /* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
@@ -213,6 +213,12 @@ int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* 
  * either a CSR over the T steps (device int64 indptr [T+1], int32 indices, implicit ones) or a dense device [T][n_items]. */
 int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
                         const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream);
+
+/* measurement knobs of one engine (the defaults are the shipped configuration): key "fuse_adam" (0/1, bf16 step:
+ * Adam inside the weight-gradient kernels), "lse_fuse" (0/1: log-sum-exp partials from the logits GEMM epilogue),
+ * "dw_cfg" (0..2: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs,
+ * 0 = automatic).  Replaces round 1's RTX_* environment switches. */
+int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
 int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);

@@ -1,0 +1,291 @@
+// dw_adam.hip -- weight gradient of one Linear layer fused with its torch.optim.Adam update (gfx950, bf16 operands).
+//
+//   dW[m][n] = sum_b D[b][m] * Act[b][n]          ("TN": both operands are the ROW-MAJOR batch matrices the forward and
+//                                                  backward passes produce; no transposed copies exist any more)
+//   column n == N_real of Act is a column of ones  -> dW[:, N_real] is the bias gradient
+//
+// Reference: autograd of nn.Linear (rectorch/nets.py:265-269) + optimizer.step() (rectorch/models.py:833, Adam built at
+// models.py:768-770 / 657-659).
+//
+// Why this is its own kernel and not "a GEMM with an epilogue".  At a B = 500 step the contraction length is 512: the
+// product needs 35 flop per byte of optimizer traffic (p, exp_avg, exp_avg_sq read and written: 24 B per parameter + the
+// 2-B compute copy), a tenth of what the MFMA pipes can do per HBM byte.  The kernel is an HBM STREAMING kernel that
+// happens to produce its gradient on the matrix cores:
+//   * small tiles (64 x 128 or 32 x 128 of dW per workgroup), thousands of workgroups, 2-4 resident per CU, so some
+//     workgroups are always in their load / store phases while others multiply;
+//   * a workgroup issues the loads of its p / m / v tile FIRST (12 x 16 B per thread in flight), then walks K with the
+//     operand slices arriving by LDS-DMA (global_load_lds, ring of three stages, counted vmcnt, raw s_barrier): the
+//     optimizer state lands under the matrix work;
+//   * operand fragments come out of the row-major slices through ds_read_b64_tr_b16 (transposing LDS read): the [k][m] /
+//     [k][n] images need no transposition anywhere (64-byte granules XOR-swizzled on the DMA source side against bank
+//     conflicts of the 4-row reads);
+//   * the f32 gradient tile is parked in LDS and walked row-major: 512-byte runs of p / m / v per row, 16 B per lane;
+//   * tiles are ordered with the SHORT matrix dimension fastest and every XCD gets one contiguous run of them, so the
+//     128-byte lines that straddle neighbouring tiles (rows are 2400 B / 80432 B long: never line-aligned) are merged in
+//     one L2, and the operand panel shared by a run stays in that L2.
+// The gradient never reaches HBM (RTX_DW_ADAM).  RTX_DW_GRAD stores it instead (float32 and / or a bf16 image) for the
+// data-parallel path, rtx_engine_loss_grads and tensors whose rows are not 16-byte periodic.
+#include "rtx_gemm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float dw_f32x16;
+typedef __attribute__((ext_vector_type(4))) float dw_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned dw_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned dw_u32x2;
+typedef __attribute__((address_space(3))) unsigned char dw_lds_byte;
+
+template <int OFF> __device__ __forceinline__ void dw_rdtr(dw_u32x2& dst, unsigned addr)
+{
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void dw_wait_lgkm()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> __device__ __forceinline__ void dw_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct DwFrag {
+    dw_u32x2 alo, ahi, blo, bhi;
+};
+
+template <int TMW, int NS, int EPI>
+__global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
+{
+    constexpr int NW = TMW * 4, NTH = NW * 64, TM = TMW * 32;
+    constexpr int SA = TM * 2, SBB = 256;                       // bytes of one k-row of the A / B slice images
+    constexpr int ABYTES = 64 * SA, STAGE = ABYTES + 64 * SBB;  // 4 or 8 KB + 16 KB
+    constexpr int QB = 16 / NW, LPS = 1 + QB;
+    constexpr int RPP = NTH / 32;                               // tile rows per epilogue pass (4 passes)
+    static_assert(TM * 128 * 4 <= NS * STAGE, "the parked gradient tile must fit in the stages");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, g = lane >> 5;
+
+    // tile order: short dimension fastest, one contiguous run per XCD (workgroup b runs on XCD b % 8: speed only)
+    int tm, tn;
+    {
+        const int total = p.m_tiles * p.n_tiles;
+        const int per_xcd = (total + 7) / 8;
+        const int id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        if (id >= total) return;
+        if (p.n_tiles <= p.m_tiles) { tm = id / p.n_tiles; tn = id % p.n_tiles; }
+        else { tn = id / p.m_tiles; tm = id % p.m_tiles; }
+    }
+
+    // ---- optimizer state of this tile: issued before anything else, consumed after the K walk -------------------------
+    const int col4 = (tid & 31) * 4, rowl = tid >> 5;
+    const int col = tn * 128 + col4;
+    dw_f32x4 pv[4], mv[4], vv[4];
+    if constexpr (EPI == RTX_DW_ADAM) {
+        // out-of-range threads load a clamped (valid) address instead of branching around the load: a branch per load
+        // makes hipcc wait vmcnt(0) behind each one
+        const int colc = min(col, p.N_real - 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
+            const size_t off = (size_t)rowc * p.N_real + colc;
+            pv[q] = *(const dw_f32x4*)(p.adam.p + off);
+            mv[q] = *(const dw_f32x4*)(p.adam.m + off);
+            vv[q] = *(const dw_f32x4*)(p.adam.v + off);
+        }
+    }
+
+    // ---- DMA source addresses ---------------------------------------------------------------------------------------------
+    const size_t rowA = (size_t)p.lda * 2, rowB = (size_t)p.ldb * 2;
+    const unsigned char* gA;
+    {
+        const int o = wave * 1024 + lane * 16;          // physical byte of this lane's piece in the A slice image
+        const int rr = o / SA, ww = o % SA;
+        const int cc = (SA == 128) ? ((ww >> 6) ^ ((rr >> 1) & 1)) : 0;
+        gA = (const unsigned char*)p.A + (size_t)rr * rowA + (size_t)tm * TM * 2 + (cc << 6) + (ww & 63);
+    }
+    const unsigned char* gB[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int o = (wave + q * NW) * 1024 + lane * 16;
+        const int rr = o / SBB, ww = o % SBB;
+        const int cc = (ww >> 6) ^ (rr & 3);
+        gB[q] = (const unsigned char*)p.B + (size_t)rr * rowB + (size_t)tn * 256 + (cc << 6) + (ww & 63);
+    }
+    dw_lds_byte* lbase = (dw_lds_byte*)smem;
+    auto load_slice = [&](int stage, int t) __attribute__((always_inline)) {
+        dw_lds_byte* sb = lbase + stage * STAGE + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const void*)(gA + (size_t)t * 64 * rowA), (void __attribute__((address_space(3)))*)sb, 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(gB[q] + (size_t)t * 64 * rowB),
+                                             (void __attribute__((address_space(3)))*)(sb + ABYTES + q * NW * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing: a transposing read hands the 16 lanes of a group a [4 k][16 x] block (lane p fetches 8 bytes
+    //      at k-row p >> 2, column (p & 3) * 4; lane i receives column i of the 4 rows).  Group g4 = lane >> 4: column half
+    //      g4 & 1, k-group g4 >> 1 -- the MFMA 32x32x16 operand layout (lane = (row & 31, k-group)). ---------------------------
+    unsigned offA, offB;
+    {
+        const int p16 = lane & 15, g4 = lane >> 4, s = p16 >> 2;
+        const int ca = (SA == 128) ? (wm ^ (s >> 1)) : 0;
+        offA = (unsigned)(((g4 >> 1) * 8 + s) * SA + (ca << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
+        offB = (unsigned)(ABYTES + ((g4 >> 1) * 8 + s) * SBB + ((wn ^ s) << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
+    }
+    dw_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+#define DW_FRAG(F, kk)                                                   \
+    dw_rdtr<((kk)*16) * SA>(F.alo, sbase + offA);                         \
+    dw_rdtr<((kk)*16 + 4) * SA>(F.ahi, sbase + offA);                     \
+    dw_rdtr<((kk)*16) * SBB>(F.blo, sbase + offB);                        \
+    dw_rdtr<((kk)*16 + 4) * SBB>(F.bhi, sbase + offB);
+#define DW_MMA(F)                                                                                                        \
+    {                                                                                                                    \
+        dw_u32x4 a_, b_;                                                                                                 \
+        a_[0] = F.alo[0]; a_[1] = F.alo[1]; a_[2] = F.ahi[0]; a_[3] = F.ahi[1];                                          \
+        b_[0] = F.blo[0]; b_[1] = F.blo[1]; b_[2] = F.bhi[0]; b_[3] = F.bhi[1];                                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dw_bf16x8, a_), __builtin_bit_cast(dw_bf16x8, b_), acc, 0, 0, 0); \
+    }
+
+    const int nk = p.k_slices;   // >= 2
+    load_slice(0, 0);
+    if (NS == 3) load_slice(1, 1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (NS == 3 && nk - t >= 2) dw_wait_vm<LPS>();   // my pieces of slice t have landed (slice t+1 may be in flight; p / m / v are older)
+        else dw_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();         // everybody's have; everybody is done reading slice t-1
+        if (t + NS - 1 < nk) {                // refill the stage slice t-1 just released
+            int nst = stage + NS - 1;
+            if (nst >= NS) nst -= NS;
+            load_slice(nst, t + NS - 1);
+        }
+        {
+            const unsigned sbase = (unsigned)(size_t)(lbase + stage * STAGE);
+            DwFrag x, y;
+            DW_FRAG(x, 0)
+            DW_FRAG(y, 1)
+            dw_wait_lgkm<4>();
+            DW_MMA(x)
+            DW_FRAG(x, 2)
+            dw_wait_lgkm<4>();
+            DW_MMA(y)
+            DW_FRAG(y, 3)
+            dw_wait_lgkm<4>();
+            DW_MMA(x)
+            dw_wait_lgkm<0>();
+            DW_MMA(y)
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+#undef DW_FRAG
+#undef DW_MMA
+    dw_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // every fragment read is done: the stages become the gradient tile's parking space
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* tile = (float*)smem;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tile[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * 128 + wn * 32 + r] = acc[e];
+    __syncthreads();
+
+    float reg = 0.f;
+    if constexpr (EPI == RTX_DW_ADAM) {
+        if (p.adam.sumsq && p.adam.lam != 0.f) {
+            const float nrm = sqrtf(*p.adam.sumsq);
+            reg = nrm > 0.f ? p.adam.lam / nrm : 0.f;
+        }
+    }
+    const bool vec = (p.N_real & 3) == 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int lr = q * RPP + rowl;
+        const int row = tm * TM + lr;
+        const dw_f32x4 g4 = *(const dw_f32x4*)(tile + lr * 128 + col4);
+        if (row >= p.M_real) continue;
+        // the bias gradient is the column just past the real ones (ones-column of the activations)
+        if (p.gbias && p.N_real >= col && p.N_real < col + 4) p.gbias[row] = g4[p.N_real - col];
+        if (col >= p.N_real) continue;
+        const size_t off = (size_t)row * p.N_real + col;
+        if constexpr (EPI == RTX_DW_ADAM) {
+            const RtxAdamEpi& A = p.adam;
+            dw_f32x4 pn, mn, vn;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gg = g4[k] + reg * pv[q][k];
+                if (A.weight_decay != 0.f) gg += A.weight_decay * pv[q][k];
+                const float m1 = mv[q][k] + (gg - mv[q][k]) * (1.f - A.beta1);
+                const float v1 = vv[q][k] * A.beta2 + (1.f - A.beta2) * gg * gg;
+                const float denom = sqrtf(v1) / A.bc2_sqrt + A.eps;
+                pn[k] = pv[q][k] - A.step_size * (m1 / denom);
+                mn[k] = m1;
+                vn[k] = v1;
+            }
+            *(dw_f32x4*)(A.p + off) = pn;
+            *(dw_f32x4*)(A.m + off) = mn;
+            *(dw_f32x4*)(A.v + off) = vn;
+            if (A.gkeep) *(dw_f32x4*)(A.gkeep + off) = g4;
+            if (A.sh) store4<bf16_t>((bf16_t*)A.sh + (size_t)row * A.ld_sh + col, pn[0], pn[1], pn[2], pn[3]);
+        } else {
+            const int nv = min(4, p.N_real - col);
+            if (p.gW) {
+                if (vec) *(dw_f32x4*)(p.gW + off) = g4;
+                else
+                    for (int k = 0; k < nv; ++k) p.gW[off + k] = g4[k];
+            }
+            if (p.g16) {
+                if (vec) store4<bf16_t>(p.g16 + off, g4[0], g4[1], g4[2], g4[3]);
+                else
+                    for (int k = 0; k < nv; ++k) p.g16[off + k] = f32_to_bf16(g4[k]);
+            }
+        }
+    }
+}
+
+template <int TMW, int NS, int EPI> static int dw_launch(const RtxDw& d, hipStream_t stream)
+{
+    constexpr int TM = TMW * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
+    static bool configured = false;
+    if (!configured) {
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<TMW, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured = true;
+    }
+    const int total = d.m_tiles * d.n_tiles;
+    const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
+    hipLaunchKernelGGL((rtx_dw_tn<TMW, NS, EPI>), grid, dim3(TMW * 256), LDS, stream, d);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : 32; }
+
+template <int EPI> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
+{
+    switch (cfg) {
+    case RTX_DW_32x128: return dw_launch<1, 3, EPI>(d, stream);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
+    case RTX_DW_32x128_S2: return dw_launch<1, 2, EPI>(d, stream);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
+    default: return dw_launch<2, 3, EPI>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
+    }
+}
+
+// d.m_tiles = M_pad / rtx_dw_tile_rows(cfg), d.n_tiles = N_pad / 128, d.k_slices = K_pad / 64 (K_pad a multiple of 128)
+int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
+{
+    RTX_CHECK(d.A && d.B && d.m_tiles > 0 && d.n_tiles > 0 && d.k_slices >= 2, RTX_EINVAL, "dw: bad problem (%d x %d tiles, %d K slices)", d.m_tiles, d.n_tiles,
+              d.k_slices);
+    RTX_CHECK(epilogue == RTX_DW_GRAD || epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw: bad epilogue %d", epilogue);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_32x128_S2, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
+    if (epilogue == RTX_DW_ADAM) {
+        RTX_CHECK((d.N_real & 3) == 0 && d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of a multiple of 4 floats (got %d)", d.N_real);
+        RTX_CHECK(d.adam.p && d.adam.m && d.adam.v, RTX_EINVAL, "dw: Adam state is NULL");
+        RTX_CHECK((((uintptr_t)d.adam.p | (uintptr_t)d.adam.m | (uintptr_t)d.adam.v | (uintptr_t)d.adam.gkeep) & 15) == 0, RTX_EINVAL,
+                  "dw: Adam buffers must be 16-byte aligned");
+        return dw_launch_cfg<RTX_DW_ADAM>(d, cfg, stream);
+    }
+    RTX_CHECK((d.N_real & 3) != 0 || ((((uintptr_t)d.gW) & 15) == 0 && (((uintptr_t)d.g16) & 7) == 0), RTX_EINVAL, "dw: gradient buffers must be 16-byte aligned");
+    return dw_launch_cfg<RTX_DW_GRAD>(d, cfg, stream);
+}

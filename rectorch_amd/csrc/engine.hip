@@ -4,14 +4,16 @@
 //
 // Data layout in HBM (T = bf16 or f32 by cfg.numerics; P(d) = roundup(d+1,128), Bp = roundup(B,128)):
 //   layer l (in_l -> out_l), l = 0 .. NL-1 (encoder layers then decoder layers)
-//     Wsh[l]   T [P(out)][P(in)]    compute copy of W_l, K(=in)-contiguous      (forward B operand)
-//     WshT[l]  T [P(in)][P(out)]    transposed copy, K(=out)-contiguous          (backward-data B operand, l>0)
-//     A[l]     T [Bp][P(in)]        input activation of layer l                  (forward A operand)
-//     AT[l]    T [P(in)][Bp]        same, transposed, row `in` = ones            (weight-grad B operand)
+//     Wsh[l]   T [P(out)][P(in)]    compute copy of W_l, row-major like the master: the forward B operand (K = in
+//                                   contiguous) AND, read K-major, the backward-data B operand
+//     A[l]     T [Bp][P(in)]        input activation of layer l; column `in` = ones for b < B: the forward A operand and,
+//                                   read K-major, the weight-gradient B operand (the ones column yields the bias gradient)
 //     O32[l]   f32 [Bp][P(out)]     post-activation output (tanh layers)         (backward derivative)
-//     D[l]     T [Bp][P(out)]       d loss / d pre-activation                    (backward-data A operand)
-//     DT[l]    T [P(out)][Bp]       same, transposed                             (weight-grad A operand)
+//     D[l]     T [Bp][P(out)]       d loss / d pre-activation: backward-data A operand and, read K-major, the
+//                                   weight-gradient A operand
 //   Y  f32 [Bp][P(I)] logits;  Cacc f32 split-K slabs / small GEMM outputs.
+//   No transposed copy of anything exists: the kernels that contract over the batch or over the output features read
+//   the row-major matrices K-major (ds_read_b64_tr_b16 for bf16, plain 4-byte reads for f32).
 //   All pads are zero (memset at creation; producers rewrite the batch padding every call), so no GEMM
 //   needs a bounds check in its main loop.
 #include "../../include/rectorch_hip.h"
@@ -33,12 +35,9 @@ struct Layer {
     int in = 0, out = 0, inp = 0, outp = 0;
     bool tanh_act = false;
     void* Wsh = nullptr;
-    void* WshT = nullptr;
     void* A = nullptr;
-    void* AT = nullptr;
     float* O32 = nullptr;
     void* D = nullptr;
-    void* DT = nullptr;
 };
 
 struct TimingSite {
@@ -75,15 +74,10 @@ struct rtx_engine {
     std::vector<float*> params, grads, m, v;
     bool bound = false, can_train = false, shadows_valid = false;
     TempCsr tmp_in, tmp_tg;
-    // per-layer Adam on a side stream, overlapped with the rest of the backward pass (single-GPU fused step)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    bool no_lse_fuse = true;    // LSE partials in the logits-GEMM epilogue: measured 8 us/step SLOWER (A/B, same box:
-                                // +12 us of shuffles in the GEMM vs -8 us in k_lse_loss); RTX_LSE_FUSE=1 enables it
-    bool fuse_adam = false;     // Adam of the big weight matrices in the epilogue of their dW GEMM (RTX_FUSE_ADAM=1).
-                                // Correct (native test step 3) but not faster yet: 448 vs 446 us/step, A/B on one box --
-                                // 2 x 88 us fused GEMMs + 25 us shadow transpose + 17 us small Adam vs 33 + 31 + 145 us.
-    bool overlap_adam = false;  // measured slower on MI355X (see loss_grads_impl); RTX_OVERLAP_ADAM=1 re-enables
+    // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
+    int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
+    int opt_dw_cfg = RTX_DW_64x128;
+    int opt_lse_fuse = 1;       // bf16: log-sum-exp partials from the logits GEMM's epilogue
     // timing
     bool timing_all = false;
     std::map<std::string, bool> timing_sites;
@@ -177,63 +171,74 @@ struct ScopedTimer {
 #define RTX_CAT(a, b) RTX_CAT2(a, b)
 #define TIMED(name) ScopedTimer RTX_CAT(_timer_, __LINE__)(e, name, st)
 
-// ---- GEMM helper -------------------------------------------------------------------------------------
-static int choose_splits(const rtx_engine* e, int tiles, int k_slices, int tile_shape)
-{
-    // Few output tiles (the skinny [B,n_items]x[n_items,hidden] contractions): split K so that one wave of
-    // workgroups fills the chip (2 per CU for 4-wave tiles, 1 per CU for 8-wave tiles), in multiples of 8 so
-    // every XCD owns whole splits (gemm.hip).
-    const int resident = tile_shape == RTX_TILE_128x128 ? 512 : 256;
-    if (tiles * 2 > resident) return 1;
-    int s = resident / tiles;
-    if (s >= 8) s &= ~7;
-    if (k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
-    const int max_s = k_slices / 2 > 0 ? k_slices / 2 : 1;  // at least two 128-byte K slices per workgroup
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    return s;
-}
-
-// Tile shape for an Mp x Np output.  Measured on MI355X at the ml-20m shapes (tests/native/test_gemm perf): the
-// 8-wave 256x128 / 128x256 tiles are no faster than 128x128 here (logits 31 vs 27 us, dW 30 vs 30, split-K 23.5
-// vs 23.8) -- these GEMMs are bound by their output/partial-sum stores and short K loops, not by L1 -- so the
-// engine uses 128x128 and keeps 2 workgroups per CU.  RTX_FORCE_TILE (0..2) overrides for experiments.
-static int choose_tile(int Mp, int Np, int k_slices)
-{
-    (void)k_slices;
-    static int forced = -2;
-    if (forced == -2) {
-        const char* v = getenv("RTX_FORCE_TILE");
-        forced = v ? atoi(v) : -1;
-    }
-    if (forced == RTX_TILE_256x128 && Mp % 256 == 0) return RTX_TILE_256x128;
-    if (forced == RTX_TILE_128x256 && Np % 256 == 0) return RTX_TILE_128x256;
-    return RTX_TILE_128x128;
-}
-
-static void set_tiles(RtxGemm& g, int Mp, int Np)
-{
+// ---- GEMM helpers -------------------------------------------------------------------------------------
+// A contraction whose output goes to the fp32 scratch Cacc (possibly as split-K slabs):
+//   form NT: C[Mp][Np] = A[Mp][Kp] x B[Np][Kp]^T      (forward)
+//   form NN: C[Mp][Np] = A[Mp][Kp] x B[Kp][Np]        (backward-data: B = the weight copy itself)
+struct GemmPlan {
+    int cfg;        // bf16: RtxDmaCfg; f32: 128x128 tiles
     int bm, bn;
-    rtx_gemm_tile_dims(g.tile_shape, &bm, &bn);
-    g.m_tiles = Mp / bm;
-    g.n_tiles = Np / bn;
+    int m_tiles, n_tiles, k_slices, splits;
+};
+
+static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp)
+{
+    GemmPlan pl = {};
+    pl.k_slices = (int)((size_t)Kp * e->esz / 128);     // 64 bf16 or 32 f32 per slice
+    if (e->bf16) {
+        // the 512-row tile covers every batch row of a B <= 512 step: each weight byte is read by one workgroup.  Small
+        // problems (hidden layers) are latency-bound: 128x128 tiles give 4x the workgroups.
+        const bool big = (Mp % 512 == 0) && ((long)Np * Kp >= (1L << 21));
+        pl.cfg = big ? RTX_DMA_512x128 : RTX_DMA_128x128;
+        rtx_gemm_dma_tile_dims(pl.cfg, &pl.bm, &pl.bn);
+    } else {
+        pl.cfg = RTX_TILE_128x128;
+        pl.bm = pl.bn = 128;
+    }
+    pl.m_tiles = Mp / pl.bm;
+    pl.n_tiles = Np / pl.bn;
+    const int tiles = pl.m_tiles * pl.n_tiles;
+    // split K so that one wave of workgroups fills the chip: 1 per CU for the LDS-DMA kernels (their stages fill the
+    // LDS), 2 per CU for the register-staged f32 kernel; at least two K slices per workgroup
+    const int resident = e->bf16 ? 256 : 512;
+    int s = 1;
+    if (tiles * 2 <= resident) {
+        s = resident / tiles;
+        if (pl.k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
+        const int max_s = pl.k_slices / 2 > 0 ? pl.k_slices / 2 : 1;
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+    }
+    // every split must own at least one slice: per = ceil(k / s) slices each -> ceil(k / per) non-empty splits
+    const int per = (pl.k_slices + s - 1) / s;
+    pl.splits = (pl.k_slices + per - 1) / per;
+    return pl;
 }
 
-// C[Mp][Np] (+slabs) = A[Mp][Kp] * B[Np][Kp]^T into e->Cacc; returns the split count used
-static int gemm_to_cacc(rtx_engine* e, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, int* splits_out,
+static size_t plan_cacc_elems(const rtx_engine* e, int Np, int Kp)
+{
+    size_t mx = 0;
+    for (int Mp = 128; Mp <= e->Bp_alloc; Mp += 128) {
+        const GemmPlan pl = plan_gemm(e, Mp, Np, Kp);
+        mx = std::max(mx, (size_t)pl.splits * Mp * Np);
+    }
+    return mx;
+}
+
+static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, int* splits_out,
                         hipStream_t st)
 {
+    const GemmPlan pl = plan_gemm(e, Mp, Np, Kp);
     RtxGemm g = {};
+    g.form = form;
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
-    g.k_slices = (int)((size_t)Kp * e->esz / 128);
-    g.tile_shape = choose_tile(Mp, Np, g.k_slices);
-    set_tiles(g, Mp, Np);
-    g.splits = choose_splits(e, g.m_tiles * g.n_tiles, g.k_slices, g.tile_shape);
+    g.k_slices = pl.k_slices; g.tile_shape = pl.cfg; g.m_tiles = pl.m_tiles; g.n_tiles = pl.n_tiles; g.splits = pl.splits;
     g.C = e->Cacc; g.ldc = Np; g.slab_stride = (long)Mp * Np;
-    while (g.splits > 1 && (size_t)g.splits * Mp * Np > e->cacc_elems) --g.splits;  // smaller batches: fewer tiles, same scratch
     RTX_CHECK((size_t)g.splits * Mp * Np <= e->cacc_elems, RTX_ESTATE, "internal: Cacc too small (%d x %d x %d)", g.splits, Mp, Np);
     *splits_out = g.splits;
-    return rtx_gemm_launch(g, e->bf16, RTX_EPI_STORE, st);
+    if (e->bf16) return rtx_gemm_dma_launch(g, RTX_EPI_STORE, st);
+    if (form == RTX_FORM_NT) return rtx_gemm_launch(g, RTX_DT_F32, RTX_EPI_STORE, st);
+    return rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, st);
 }
 
 // ---- batch resolution --------------------------------------------------------------------------------
@@ -298,23 +303,19 @@ static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxC
 
 // ---- forward ---------------------------------------------------------------------------------------
 // Runs layers [l0, l1).  If l0 == 0 the gather kernel builds A[0] from `in`.  The last network layer
-// writes logits to `logits` (ld = ldlog).  need_T: also produce the transposed activations (training).
+// writes logits to `logits` (ld = ldlog); with want_lse it also leaves the log-sum-exp partials (training).
 static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg, int B, int training, const rtx_step* step,
-                       int need_T, int l0, int l1, float* logits, long ldlog, float* mu_out, float* lv_out, hipStream_t st)
+                       int want_lse, int l0, int l1, float* logits, long ldlog, float* mu_out, float* lv_out, hipStream_t st)
 {
-    const int Bp = rtx_pad_batch(B), ldt = e->Bp_alloc;
+    const int Bp = rtx_pad_batch(B);
     static const rtx_step zero_step = {};
     if (!step) step = &zero_step;
     if (l0 == 0) {
         Layer& l = e->L[0];
-        if (need_T) {
-            TIMED("memset_xT");
-            RTX_HIP(hipMemset2DAsync(l.AT, (size_t)ldt * e->esz, 0, (size_t)Bp * e->esz, (size_t)l.inp, st));
-        }
         RtxGatherArgs a = {};
         a.in = *in; a.target = *tg;
-        a.B = B; a.Bp = Bp; a.I = e->I; a.Iin = e->Iin; a.ldx = l.inp; a.ldt = ldt;
-        a.X = l.A; a.XT = need_T ? l.AT : nullptr; a.tsum = e->tsum;
+        a.B = B; a.Bp = Bp; a.I = e->I; a.Iin = e->Iin; a.ldx = l.inp;
+        a.X = l.A; a.tsum = e->tsum;
         a.training = training; a.dropout_p = e->cfg.dropout_p;
         a.mask = step->dropout_mask; a.seed = step->seed; a.offset = step->offset;
         TIMED("gather");
@@ -323,41 +324,51 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     for (int li = l0; li < l1; ++li) {
         Layer& l = e->L[li];
         if (li == e->NL - 1) {
+            // logits = A x Wsh^T + b, one launch; K = hidden (short), output [Bp][n_items] f32
             RtxGemm g = {};
+            g.form = RTX_FORM_NT;
             g.A = l.A; g.B = l.Wsh; g.lda = l.inp; g.ldb = l.inp;
             g.k_slices = (int)((size_t)l.inp * e->esz / 128);
-            g.tile_shape = choose_tile(Bp, l.outp, g.k_slices);
-            set_tiles(g, Bp, l.outp);
             g.splits = 1; g.C = logits; g.ldc = ldlog; g.bias = e->params[2 * li + 1];
             g.M_real = B; g.N_real = l.out;
-            if (logits == e->Y && g.tile_shape == RTX_TILE_128x128 && !e->no_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }
             TIMED("gemm_logits");
-            RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_BIAS_ROWS, st));
+            if (e->bf16) {
+                g.tile_shape = (Bp % 512 == 0) ? RTX_DMA_512x128 : RTX_DMA_128x128;
+                int bm, bn;
+                rtx_gemm_dma_tile_dims(g.tile_shape, &bm, &bn);
+                g.m_tiles = Bp / bm; g.n_tiles = l.outp / bn;
+                if (want_lse && e->opt_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }
+                RTX_TRY(rtx_gemm_dma_launch(g, RTX_EPI_BIAS_ROWS, st));
+            } else {
+                g.tile_shape = RTX_TILE_128x128;
+                g.m_tiles = Bp / 128; g.n_tiles = l.outp / 128;
+                RTX_TRY(rtx_gemm_launch(g, RTX_DT_F32, RTX_EPI_BIAS_ROWS, st));
+            }
             break;
         }
         int splits = 1;
         {
             TIMED(li == 0 ? "gemm_fwd_in" : "gemm_fwd_hidden");
-            RTX_TRY(gemm_to_cacc(e, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, &splits, st));
+            RTX_TRY(gemm_to_cacc(e, RTX_FORM_NT, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, &splits, st));
         }
         Layer& nx = e->L[li + 1];
         if (e->vae && li == e->cfg.n_enc - 1) {
             RtxVaeFwdArgs a = {};
             a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.outp; a.ldc = l.outp;
-            a.B = B; a.Bp = Bp; a.ldt = ldt; a.Z = e->Z; a.Zp = e->Zp;
+            a.B = B; a.Bp = Bp; a.Z = e->Z; a.Zp = e->Zp;
             a.bias = e->params[2 * li + 1];
             a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32;
             a.mu_out = mu_out; a.lv_out = lv_out;
-            a.Zr = nx.A; a.ZT = nx.AT;
+            a.Zr = nx.A;
             a.training = training; a.eps_in = step->eps_noise; a.seed = step->seed; a.offset = step->offset;
             TIMED("vae_head_fwd");
             RTX_TRY(rtx_launch_vae_fwd(a, e->bf16, st));
         } else {
             RtxPostArgs a = {};
             a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.outp; a.ldc = l.outp;
-            a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = l.out; a.Np = l.outp;
+            a.B = B; a.Bp = Bp; a.N_real = l.out; a.Np = l.outp;
             a.tanh_act = l.tanh_act; a.bias = e->params[2 * li + 1];
-            a.O32 = l.O32; a.R = nx.A; a.RT = need_T ? nx.AT : nullptr; a.ones_row = 1;
+            a.O32 = l.O32; a.R = nx.A; a.ones_col = 1;
             TIMED("post_fwd");
             RTX_TRY(rtx_launch_post(a, RTX_POST_FWD, e->bf16, st));
         }
@@ -391,18 +402,21 @@ static void fill_adam_tensors(rtx_engine* e, RtxAdamArgs& a, int l0 = 0, int l1 
         w.g = e->can_train ? e->grads[2 * li] : nullptr;
         w.m = e->can_train ? e->m[2 * li] : nullptr;
         w.v = e->can_train ? e->v[2 * li] : nullptr;
-        w.sh = l.Wsh; w.shT = l.WshT; w.rows = l.out; w.cols = l.in; w.ld_sh = l.inp; w.ld_shT = l.outp;
+        w.sh = l.Wsh; w.shT = nullptr; w.rows = l.out; w.cols = l.in; w.ld_sh = l.inp; w.ld_shT = 0;
+        w.sumsq = nullptr;
         RtxAdamTensor& b = a.t[a.n++];
         b.p = e->params[2 * li + 1];
         b.g = e->can_train ? e->grads[2 * li + 1] : nullptr;
         b.m = e->can_train ? e->m[2 * li + 1] : nullptr;
         b.v = e->can_train ? e->v[2 * li + 1] : nullptr;
         b.sh = nullptr; b.shT = nullptr; b.rows = 1; b.cols = l.out; b.ld_sh = 0; b.ld_shT = 0;
+        b.sumsq = nullptr;
     }
 }
 
-// torch.optim.Adam's scalars for update `step` (computed in double like torch does on the host)
-static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& a, int t0 /* first tensor index */)
+// torch.optim.Adam's scalars for update `step` (computed in double like torch does on the host).  The tensors of `a`
+// are tensors [t0, t0 + a.n) of the network unless `ids` names them one by one (DAE: per-tensor norms).
+static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& a, int t0 /* first tensor index */, const int* ids = nullptr)
 {
     a.update = 1;
     const double bc1 = 1.0 - pow((double)step->beta1, (double)step->step);
@@ -411,8 +425,11 @@ static void fill_adam_scalars(rtx_engine* e, const rtx_step* step, RtxAdamArgs& 
     a.bc2_sqrt = (float)sqrt(bc2);
     a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
     a.grad_scale = 1.f;
-    a.lam = 0.f; a.sumsq = nullptr;
-    if (!e->vae && step->lam != 0.f) { a.lam = step->lam; a.sumsq = e->sumsq + t0; }
+    a.lam = 0.f;
+    if (!e->vae && step->lam != 0.f) {
+        a.lam = step->lam;
+        for (int k = 0; k < a.n; ++k) a.t[k].sumsq = e->sumsq + (ids ? ids[k] : t0 + k);
+    }
 }
 
 static int launch_sumsq(rtx_engine* e, hipStream_t st)
@@ -448,7 +465,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 2; }   // 2: rtx_cfg.cond_dim, rtx_ease_*
+int32_t rtx_abi_version(void) { return 3; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -528,10 +545,6 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     e->vae = cfg->variant == RTX_VAE;
     e->esz = e->bf16 ? 2 : 4;
     e->Bp_alloc = rtx_pad_batch(cfg->max_batch);
-    if (const char* v = getenv("RTX_SPLITK")) e->cfg.splitk = atoi(v);   // measurement switch: split-K factor of the two K = n_items GEMMs
-    if (const char* v = getenv("RTX_OVERLAP_ADAM")) e->overlap_adam = atoi(v) != 0;
-    if (const char* v = getenv("RTX_FUSE_ADAM")) e->fuse_adam = atoi(v) != 0;
-    if (const char* v = getenv("RTX_LSE_FUSE")) e->no_lse_fuse = atoi(v) == 0;
     const size_t Bp = e->Bp_alloc, es = e->esz;
     size_t cacc = 0;
 #define ALLOC(ptr, bytes)                                  \
@@ -542,24 +555,12 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     for (int li = 0; li < e->NL; ++li) {
         Layer& l = e->L[li];
         ALLOC(l.Wsh, (size_t)l.outp * l.inp * es);
-        if (li > 0) ALLOC(l.WshT, (size_t)l.inp * l.outp * es);
         ALLOC(l.A, Bp * l.inp * es);
-        ALLOC(l.AT, (size_t)l.inp * Bp * es);
         if (li < e->NL - 1) ALLOC(l.O32, Bp * l.outp * sizeof(float));
         ALLOC(l.D, Bp * l.outp * es);
-        ALLOC(l.DT, (size_t)l.outp * Bp * es);
-        // scratch for the forward output and the backward-data output of this layer (with split-K slabs)
-        const int m_tiles = (int)(Bp / 128);
-        if (li < e->NL - 1) {
-            const int ks = (int)((size_t)l.inp * es / 128);
-            const size_t s = choose_splits(e, m_tiles * (l.outp / 128), ks, RTX_TILE_128x128);
-            cacc = std::max(cacc, s * Bp * l.outp);
-        }
-        if (li > 0) {
-            const int ks = (int)((size_t)l.outp * es / 128);
-            const size_t s = choose_splits(e, m_tiles * (l.inp / 128), ks, RTX_TILE_128x128);
-            cacc = std::max(cacc, s * Bp * l.inp);
-        }
+        // scratch for the forward output and the backward-data output of this layer (with split-K slabs), at any batch
+        if (li < e->NL - 1) cacc = std::max(cacc, plan_cacc_elems(e, l.outp, l.inp));
+        if (li > 0) cacc = std::max(cacc, plan_cacc_elems(e, l.inp, l.outp));
     }
     e->cacc_elems = cacc;
     ALLOC(e->Cacc, cacc * sizeof(float));
@@ -587,9 +588,6 @@ int rtx_engine_destroy(rtx_engine* e)
     for (auto& kv : e->sites)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
-    if (e->ev_main) (void)hipEventDestroy(e->ev_main);
-    if (e->ev_side) (void)hipEventDestroy(e->ev_side);
-    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
 }
@@ -701,150 +699,121 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 }
 
 // ---- training --------------------------------------------------------------------------------------
-// forward + loss + backward.  With adam_side, layer l's fused Adam is launched on the engine's side stream as soon
-// as nothing on the main stream still needs that layer's compute copies (after its data-gradient GEMM), so the
-// HBM-bound optimizer pass of the big decoder layer could run under the remaining backward kernels.
-// MEASURED NEGATIVE on MI355X (ml-20m shape, B=500, bf16): 506 us/step with the overlap vs 477 us without, and
-// 495 us with the side stream at the lowest priority -- the 3160 Adam workgroups flood the CUs and the small
-// hidden-layer GEMMs behind them go from 12 to 43 us each.  Kept behind RTX_OVERLAP_ADAM=1 for later rounds.
-static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
+// forward + loss + backward.  With `fuse` (single-GPU bf16 step) the Adam update of every weight matrix whose rows are
+// a multiple of 4 floats runs INSIDE its weight-gradient kernel (dw_adam.hip: the gradient never reaches HBM and the
+// optimizer's HBM traffic overlaps the matrix work); biases and the remaining tensors follow in one small launch.
+// Otherwise the gradients land in the bound buffers (data-parallel exchange, p.grad, float32 parity mode).
+static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && (l.in & 3) == 0 && l.in >= 4; }
 
 static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
-                           rtx_layer_cb cb, void* user, hipStream_t st, bool adam_side, bool fuse)
+                           rtx_layer_cb cb, void* user, hipStream_t st, bool fuse)
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
-    const int B = batch->batch, Bp = rtx_pad_batch(B), ldt = e->Bp_alloc, NL = e->NL;
+    const int B = batch->batch, Bp = rtx_pad_batch(B), NL = e->NL;
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
-    // loss
-    {
-        RtxLossArgs a = {};
-        a.Y = e->Y; a.ldy = e->Ip; a.B = B; a.I = e->I; a.target = tg; a.tsum = e->tsum;
-        a.lse = e->lse; a.row_loss = e->row_loss; a.inv_batch = step->inv_batch;
-        if (!e->no_lse_fuse && choose_tile(Bp, e->Ip, 0) == RTX_TILE_128x128) { a.part = e->lse_part; a.n_strips = e->lse_strips; a.part_ld = e->lse_strips; }
-        if (e->vae) { a.mu32 = e->mu32; a.lv32 = e->lv32; a.Z = e->Z; a.beta = step->beta; }
-        TIMED("lse_loss");
-        RTX_TRY(rtx_launch_lse_loss(a, st));
-    }
     const bool dae_reg = !e->vae && step->lam != 0.f;
     if (dae_reg) {
         TIMED("sumsq");
         RTX_TRY(launch_sumsq(e, st));
     }
+    // loss and d loss / d logits in one pass over Y
+    {
+        RtxDlogitsArgs a = {};
+        a.loss.Y = e->Y; a.loss.ldy = e->Ip; a.loss.B = B; a.loss.I = e->I; a.loss.target = tg; a.loss.tsum = e->tsum;
+        a.loss.lse = e->lse; a.loss.row_loss = e->row_loss; a.loss.inv_batch = step->inv_batch;
+        if (e->bf16 && e->opt_lse_fuse) { a.loss.part = e->lse_part; a.loss.n_strips = e->lse_strips; a.loss.part_ld = e->lse_strips; }
+        if (e->vae) { a.loss.mu32 = e->mu32; a.loss.lv32 = e->lv32; a.loss.Z = e->Z; a.loss.beta = step->beta; }
+        a.Bp = Bp; a.D = e->L[NL - 1].D; a.ldd = e->Ip;
+        TIMED("dlogits_loss");
+        RTX_TRY(rtx_launch_dlogits(a, e->bf16, st));
+    }
     {
         TIMED("reduce_loss");
         RTX_TRY(rtx_launch_reduce_loss(e->row_loss, B, step->lam, dae_reg ? e->sumsq : nullptr, 2 * NL, loss_out, loss_accum, st));
     }
-    // d logits
-    {
-        Layer& l = e->L[NL - 1];
-        RtxPostArgs a = {};
-        a.C = e->Y; a.splits = 1; a.slab_stride = 0; a.ldc = e->Ip;
-        a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = e->I; a.Np = e->Ip;
-        a.R = l.D; a.RT = l.DT; a.lse = e->lse; a.tsum = e->tsum; a.inv_batch = step->inv_batch;
-        {
-            TIMED("dlogits");
-            RTX_TRY(rtx_launch_post(a, RTX_POST_DLOGITS, e->bf16, st));
-        }
-        TIMED("target_fixup");
-        RTX_TRY(rtx_launch_target_fixup(tg, B, step->inv_batch, l.D, e->Ip, l.DT, ldt, e->bf16, st));
-    }
-    RtxAdamArgs rest = {};   // tensors whose Adam is NOT fused into a GEMM epilogue (biases, small layers)
+    RtxAdamArgs rest = {};   // tensors whose Adam is NOT fused into a weight-gradient kernel (biases, odd-width matrices)
+    int rest_ids[RTX_MAX_TENSORS];
     rest.n = 0;
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
-        // (1) data gradient FIRST: it reads this layer's transposed compute copy, which the fused optimizer epilogue
-        //     of (2) overwrites:  dA[Bp][inp] = D[Bp][outp] x WshT[inp][outp]^T
+        // (1) data gradient FIRST: it reads this layer's compute copy, which the fused optimizer epilogue of (2)
+        //     overwrites:  dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major)
         if (li > 0) {
             int splits = 1;
             {
                 TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
-                RTX_TRY(gemm_to_cacc(e, l.D, l.outp, l.WshT, l.outp, Bp, l.inp, l.outp, &splits, st));
+                RTX_TRY(gemm_to_cacc(e, RTX_FORM_NN, l.D, l.outp, l.Wsh, l.inp, Bp, l.inp, l.outp, &splits, st));
             }
             Layer& pv = e->L[li - 1];
             if (e->vae && li == e->cfg.n_enc) {
                 RtxVaeBwdArgs a = {};
                 a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
-                a.B = B; a.Bp = Bp; a.ldt = ldt; a.Z = e->Z; a.Np = pv.outp;
+                a.B = B; a.Bp = Bp; a.Z = e->Z; a.Np = pv.outp;
                 a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32; a.training = 1;
-                a.beta = step->beta; a.inv_batch = step->inv_batch; a.D = pv.D; a.DT = pv.DT;
+                a.beta = step->beta; a.inv_batch = step->inv_batch; a.D = pv.D;
                 TIMED("vae_head_bwd");
                 RTX_TRY(rtx_launch_vae_bwd(a, e->bf16, st));
             } else {
                 RtxPostArgs a = {};
                 a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.inp; a.ldc = l.inp;
-                a.B = B; a.Bp = Bp; a.ldt = ldt; a.N_real = pv.out; a.Np = pv.outp;
-                a.tanh_act = pv.tanh_act; a.O32 = pv.O32; a.R = (li - 1 > 0) ? pv.D : nullptr; a.RT = pv.DT;
+                a.B = B; a.Bp = Bp; a.N_real = pv.out; a.Np = pv.outp;
+                a.tanh_act = pv.tanh_act; a.O32 = pv.O32; a.R = pv.D;
                 TIMED("post_bwd");
                 RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
             }
         }
-        // (2) weight + bias gradient: gW[out][in] = DT[outp][Bp] x AT[inp][Bp]^T ; column `in` = bias gradient
+        // (2) weight + bias gradient: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column `in` of the
+        //     product (the ones column of A) is the bias gradient
+        const bool fused = fuse && layer_fusable(e, l);
         {
-            RtxGemm g = {};
-            g.A = l.DT; g.B = l.AT; g.lda = ldt; g.ldb = ldt;
-            g.k_slices = (int)((size_t)Bp * e->esz / 128);
-            g.tile_shape = choose_tile(l.outp, l.inp, g.k_slices);
-            set_tiles(g, l.outp, l.inp);
-            g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
-            g.M_real = l.out; g.N_real = l.in;
-            const bool fused = fuse && layer_is_big(l);
-            if (fused) {
-                RtxAdamArgs sc = {};
-                fill_adam_scalars(e, step, sc, 2 * li);
-                g.adam.p = e->params[2 * li]; g.adam.m = e->m[2 * li]; g.adam.v = e->v[2 * li];
-                g.adam.gkeep = (step->flags & RTX_STEP_KEEP_GRADS) ? e->grads[2 * li] : nullptr;
-                g.tile_shape = RTX_TILE_128x128;
-                set_tiles(g, l.outp, l.inp);
-                g.adam.sh = l.Wsh; g.adam.shT = nullptr; g.adam.ld_sh = l.inp; g.adam.ld_shT = l.outp;
-                g.adam.step_size = sc.step_size; g.adam.bc2_sqrt = sc.bc2_sqrt; g.adam.beta1 = sc.beta1; g.adam.beta2 = sc.beta2;
-                g.adam.eps = sc.eps; g.adam.weight_decay = sc.weight_decay; g.adam.lam = sc.lam; g.adam.sumsq = sc.sumsq;
-                {
-                    TIMED(li == NL - 1 ? "gemm_dW_adam_out" : (li == 0 ? "gemm_dW_adam_in" : "gemm_dW_adam_hidden"));
-                    RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_ADAM, st));
-                }
-                if (l.WshT) {   // the transposed compute copy (next step's backward-data operand)
-                    TIMED("shadow_transpose");
-                    RTX_TRY(rtx_launch_transpose(l.Wsh, l.inp, l.WshT, l.outp, l.out, l.in, e->bf16, st));
+            const char* site = li == NL - 1 ? (fused ? "dW_adam_out" : "gemm_dW_out") : (li == 0 ? (fused ? "dW_adam_in" : "gemm_dW_in") : (fused ? "dW_adam_hidden" : "gemm_dW_hidden"));
+            TIMED(site);
+            if (e->bf16) {
+                RtxDw d = {};
+                d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
+                d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+                d.M_real = l.out; d.N_real = l.in; d.gbias = e->grads[2 * li + 1];
+                if (fused) {
+                    RtxAdamArgs sc = {};
+                    fill_adam_scalars(e, step, sc, 2 * li);
+                    d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
+                    d.adam.gkeep = (step->flags & RTX_STEP_KEEP_GRADS) ? e->grads[2 * li] : nullptr;
+                    d.adam.sh = l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
+                    d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
+                    d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
+                    d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
+                    RTX_TRY(rtx_dw_launch(d, RTX_DW_ADAM, e->opt_dw_cfg, st));
+                } else {
+                    d.gW = e->grads[2 * li];
+                    RTX_TRY(rtx_dw_launch(d, RTX_DW_GRAD, e->opt_dw_cfg, st));
                 }
             } else {
-                TIMED(li == NL - 1 ? "gemm_dW_out" : (li == 0 ? "gemm_dW_in" : "gemm_dW_hidden"));
-                RTX_TRY(rtx_gemm_launch(g, e->bf16, RTX_EPI_GRAD, st));
+                RtxGemm g = {};
+                g.form = RTX_FORM_TN;
+                g.A = l.D; g.lda = l.outp; g.B = l.A; g.ldb = l.inp;
+                g.k_slices = Bp / 32; g.tile_shape = RTX_TILE_128x128; g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
+                g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
+                g.M_real = l.out; g.N_real = l.in;
+                RTX_TRY(rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, st));
             }
-            if (fuse) {   // what is left for the small multi-tensor Adam launch at the end of the step
-                RtxAdamArgs one = {};
-                fill_adam_tensors(e, one, li, li + 1);
-                if (!fused) rest.t[rest.n++] = one.t[0];
-                rest.t[rest.n++] = one.t[1];
-            }
+        }
+        if (fuse) {   // what is left for the small multi-tensor Adam launch at the end of the step
+            RtxAdamArgs one = {};
+            fill_adam_tensors(e, one, li, li + 1);
+            if (!fused) { rest_ids[rest.n] = 2 * li; rest.t[rest.n++] = one.t[0]; }
+            rest_ids[rest.n] = 2 * li + 1;
+            rest.t[rest.n++] = one.t[1];
         }
         if (cb) cb(li, user);
-        if (adam_side) {
-            // layer li's gradients are complete and its shadows have no reader left in this step
-            RTX_HIP(hipEventRecord(e->ev_main, st));
-            RTX_HIP(hipStreamWaitEvent(e->side, e->ev_main, 0));
-            RtxAdamArgs a = {};
-            fill_adam_tensors(e, a, li, li + 1);
-            fill_adam_scalars(e, step, a, 2 * li);
-            ScopedTimer tm_adam(e, "adam", e->side);
-            RTX_TRY(rtx_launch_adam(a, e->bf16, e->side));
-        }
     }
     if (fuse) {
-        // biases and small layers: one multi-tensor launch.  (DAE: their lam*p/||p|| term needs per-tensor norms, which
-        // k_adam indexes by position; the fused path is only taken for lam == 0 or the VAE -- see train_step.)
-        fill_adam_scalars(e, step, rest, 0);
-        rest.sumsq = nullptr; rest.lam = 0.f;
+        fill_adam_scalars(e, step, rest, 0, rest_ids);
         TIMED("adam_small");
         RTX_TRY(rtx_launch_adam(rest, e->bf16, st));
-        e->shadows_valid = true;
-    }
-    if (adam_side) {   // the next forward (or anything else on the caller's stream) sees the updated weights
-        RTX_HIP(hipEventRecord(e->ev_side, e->side));
-        RTX_HIP(hipStreamWaitEvent(st, e->ev_side, 0));
         e->shadows_valid = true;
     }
     return RTX_OK;
@@ -853,7 +822,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
 int rtx_engine_loss_grads(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                           rtx_layer_cb cb, void* user, void* stream)
 {
-    return loss_grads_impl(e, batch, step, loss_out, loss_accum, cb, user, (hipStream_t)stream, false, false);
+    return loss_grads_impl(e, batch, step, loss_out, loss_accum, cb, user, (hipStream_t)stream, false);
 }
 
 int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
@@ -901,24 +870,42 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "train_step: step count must be >= 1");
-    if (e->overlap_adam) {
-        if (!e->side) {
-            // lowest priority: the optimizer pass only soaks up the slots the backward kernels leave free
-            int prio_least = 0, prio_greatest = 0;
-            RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-            RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least));
-            RTX_HIP(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
-            RTX_HIP(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
-        }
-        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, true, false);
-    }
-    // Fused optimizer: Adam of the big matrices runs in the epilogue of their weight-gradient GEMM (the gradient
-    // never reaches HBM), the rest in one small launch.  Not for the DAE regulariser (per-tensor norms feed every
-    // tensor's update; kept on the two-kernel path) -- Mult-VAE, the headline model, has lam = 0.
-    if (e->fuse_adam && (e->vae || step->lam == 0.f))
-        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false, true);
-    RTX_TRY(loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false, false));
+    if (e->bf16 && e->opt_fuse_adam)
+        return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, true);
+    RTX_TRY(loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false));
     return rtx_engine_apply_adam(e, step, stream);
+}
+
+// measurement knobs: one entry point instead of environment variables scattered over the kernels' launchers
+int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
+{
+    RTX_CHECK(e && key, RTX_EINVAL, "set_option: NULL argument");
+    const std::string k(key);
+    if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
+    else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
+    else if (k == "dw_cfg") {
+        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_32x128_S2, RTX_EINVAL, "set_option: dw_cfg must be 0..2");
+        e->opt_dw_cfg = value;
+    } else if (k == "splitk") {
+        RTX_CHECK(value >= 0, RTX_EINVAL, "set_option: splitk must be >= 0");
+        // the scratch was sized for the automatic choice: only accept factors it can hold
+        const int old = e->cfg.splitk;
+        e->cfg.splitk = value;
+        size_t need = 0;
+        for (int li = 0; li < e->NL; ++li) {
+            if (li < e->NL - 1) need = std::max(need, plan_cacc_elems(e, e->L[li].outp, e->L[li].inp));
+            if (li > 0) need = std::max(need, plan_cacc_elems(e, e->L[li].inp, e->L[li].outp));
+        }
+        if (need > e->cacc_elems) {
+            e->cfg.splitk = old;
+            rtx_set_error("set_option: split factor %d needs %zu scratch floats, the engine holds %zu", value, need, e->cacc_elems);
+            return RTX_EINVAL;
+        }
+    } else {
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, dw_cfg, splitk)", key);
+        return RTX_EINVAL;
+    }
+    return RTX_OK;
 }
 
 int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int32_t n_items, const float* mu, const float* logvar,

@@ -296,93 +296,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
                 }
         }
     }
-    if constexpr (EPI == RTX_EPI_ADAM) {
-        // Fused optimizer: the dW tile never reaches HBM.  It is parked in LDS (the operand stages are dead now), then
-        // the workgroup walks it ROW-MAJOR with 16-byte accesses -- 512-byte contiguous runs of p / exp_avg /
-        // exp_avg_sq per row, the same streaming pattern as k_adam -- applies torch.optim.Adam and writes p, m, v and
-        // the compute copy.  (A first version updated straight from the MFMA register layout: 2 rows x 128 B per
-        // instruction and 8-byte scattered stores into the transposed copy ran at 2.6 TB/s; the transposed copy is
-        // now produced by a separate tile-transpose kernel.)  Per parameter: 12 B read + 12 B written + 2-4 B shadow,
-        // instead of 4 B gradient store + 16 B + 12 B + shadows in the two-kernel path.
-        if constexpr (BM * BN * 4 <= 2 * STAGE) {
-            const RtxAdamEpi& A = p.adam;
-            float* tile = (float*)smem;
-            __syncthreads();   // every wave has finished reading the operand stages
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NB; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int lr = wm * 64 + 4 * g + i * 32 + (e & 3) + 8 * (e >> 2);
-                        tile[lr * BN + wn * (NB * 32) + j * 32 + r] = acc[i][j][e];
-                    }
-            __syncthreads();
-            float reg = 0.f;
-            if (A.sumsq && A.lam != 0.f) {
-                const float nrm = sqrtf(*A.sumsq);
-                reg = nrm > 0.f ? A.lam / nrm : 0.f;
-            }
-            constexpr int TPR = BN / 4;            // threads per tile row (one float4 each)
-            constexpr int RPS = (WM * WN * 64) / TPR;  // rows per sweep
-            const int c4 = (tid % TPR) * 4;
-            const int col = tn * BN + c4;
-            const bool vec = (p.N_real & 3) == 0;
-#pragma unroll 4
-            for (int lr = tid / TPR; lr < BM; lr += RPS) {
-                const int row = tm * BM + lr;
-                if (row >= p.M_real) break;
-                const float4 g4 = *(const float4*)(tile + lr * BN + c4);
-                const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-                // the bias gradient is the column just past the real ones (ones-row trick)
-                if (p.gbias && p.N_real >= col && p.N_real < col + 4) p.gbias[row] = gv[p.N_real - col];
-                if (col >= p.N_real) continue;
-                const int nv = min(4, p.N_real - col);
-                const size_t off = (size_t)row * p.N_real + col;
-                float pv[4], mv[4], vv[4];
-                if (vec) {
-                    const float4 p4 = *(const float4*)(A.p + off), m4 = *(const float4*)(A.m + off), v4 = *(const float4*)(A.v + off);
-                    pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
-                    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
-                    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
-                } else {
-                    for (int k = 0; k < 4; ++k) {
-                        pv[k] = k < nv ? A.p[off + k] : 0.f;
-                        mv[k] = k < nv ? A.m[off + k] : 0.f;
-                        vv[k] = k < nv ? A.v[off + k] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float gg = gv[k] + reg * pv[k];
-                    if (A.weight_decay != 0.f) gg += A.weight_decay * pv[k];
-                    const float mn = mv[k] + (gg - mv[k]) * (1.f - A.beta1);
-                    const float vn = vv[k] * A.beta2 + (1.f - A.beta2) * gg * gg;
-                    const float denom = sqrtf(vn) / A.bc2_sqrt + A.eps;
-                    pv[k] = pv[k] - A.step_size * (mn / denom);
-                    mv[k] = mn;
-                    vv[k] = vn;
-                }
-                if (vec) {
-                    *(float4*)(A.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                    *(float4*)(A.m + off) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-                    *(float4*)(A.v + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    if (A.gkeep) *(float4*)(A.gkeep + off) = g4;
-                } else {
-                    for (int k = 0; k < nv; ++k) {
-                        A.p[off + k] = pv[k]; A.m[off + k] = mv[k]; A.v[off + k] = vv[k];
-                        if (A.gkeep) A.gkeep[off + k] = gv[k];
-                    }
-                }
-                if (A.sh) {
-                    T* sdst = (T*)A.sh + (size_t)row * A.ld_sh + col;
-                    if (nv == 4) store4<T>(sdst, pv[0], pv[1], pv[2], pv[3]);
-                    else for (int k = 0; k < nv; ++k) sdst[k] = Elem<T>::from(pv[k]);
-                }
-            }
-        }
-        return;
-    }
     // one 64-bit base per lane; every element offset is (compile-time constant) * ld + constant -> scalar math
     const long ld = (EPI == RTX_EPI_GRAD) ? (long)p.N_real : p.ldc;
     float* cp = p.C + (EPI == RTX_EPI_STORE ? (size_t)split * p.slab_stride : (size_t)0) + (size_t)row_base * ld + col_base;
@@ -430,7 +343,6 @@ static void launch_shape(const RtxGemm& g, int epilogue, dim3 grid, hipStream_t 
     switch (epilogue) {
     case RTX_EPI_STORE: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_STORE, WM, WN, NB>), grid, block, 0, stream, g); break;
     case RTX_EPI_BIAS_ROWS: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_BIAS_ROWS, WM, WN, NB>), grid, block, 0, stream, g); break;
-    case RTX_EPI_ADAM: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_ADAM, WM, WN, NB>), grid, block, 0, stream, g); break;
     default: hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_GRAD, WM, WN, NB>), grid, block, 0, stream, g); break;
     }
 }
@@ -451,9 +363,8 @@ int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t strea
               "gemm: fp8 operands only with the plain-store epilogue and the 128x128 tile (Gram matrix of binary data)");
     RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm: empty problem");
     RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm: split-K only with EPI_STORE");
-    RTX_CHECK(epilogue >= RTX_EPI_STORE && epilogue <= RTX_EPI_ADAM, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
+    RTX_CHECK(epilogue >= RTX_EPI_STORE && epilogue <= RTX_EPI_GRAD, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
     RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x256, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
-    RTX_CHECK(epilogue != RTX_EPI_ADAM || g.tile_shape == RTX_TILE_128x128, RTX_EINVAL, "gemm: the fused Adam epilogue needs the 128x128 tile (the dW tile is parked in LDS)");
     // 1-D grid laid out for the XCD-aware mapping in the kernel: 8 * ceil(groups / 8) * group_size workgroups
     const int tiles = g.m_tiles * g.n_tiles;
     int groups, gsize;

@@ -1,0 +1,382 @@
+// gemm_dma.hip -- bf16 MFMA GEMM with LDS-DMA operand staging (gfx950), for the step's big contractions.
+//
+//   NT : C[m][n] = sum_k A[m][k] * B[n][k]     both operands K-contiguous          (forward: Act x W^T)
+//   NN : C[m][n] = sum_k A[m][k] * B[k][n]     B stored K-major, N-contiguous      (backward-data: dOut x W)
+//
+// The NN form reads W itself ([out][in] row-major = K-major for the data gradient), so the engine keeps no transposed
+// weight copy: the B fragments come out of LDS through ds_read_b64_tr_b16 (gfx950's transposing LDS read).
+//
+// Structure (same pipeline as the EASE Gram kernel, syrk.hip): a workgroup of WM x WN waves, every wave owning
+// (MI*32) x (NJ*32) of C as MI x NJ MFMA 32x32x16 accumulators.  Operand K-slices of 64 bf16 go global -> LDS by DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of NS stages; one raw s_barrier per
+// slice, counted vmcnt so the next slice's DMA stays in flight across the barrier; fragment reads are inline asm with
+// counted lgkmcnt (a compiler-visible LDS read behind a DMA in flight would get a vmcnt(0) that drains the ring).
+//
+// LDS images (the DMA writes lane-linear, so every swizzle is applied to the per-lane GLOBAL address and to the read):
+//   K-contiguous operand : row R of the tile at R * 128 B, 16-byte chunk c at slot c ^ (R & 7)   -> ds_read_b128
+//   K-major operand (NN B): k-row r at r * (BN*2) B, 64-byte granule c at slot c ^ (r & 3)        -> ds_read_b64_tr_b16
+//     (a transposing read takes 4 consecutive k-rows x 64 B per half-wave; the XOR puts them on 4 different bank groups)
+//
+// The big configuration (4x2 waves x 128x64 per wave = a 512 x 128 tile) covers ALL batch rows of a B = 500 step, so
+// every byte of the HBM-resident weight matrix is read by exactly one workgroup; 2 x 80 KB stages fill the CU's LDS.
+//
+// Epilogues go through LDS (the stages are dead by then): each wave parks 32 x 64 of C at a time in a private region and
+// re-reads it row-wise -- 16-byte stores of 128-byte row pieces instead of 4-byte stores from the MFMA layout, and, for the
+// logits, the online-softmax partial (max, sum exp) of each row over the wave's 64-column strip with NO cross-lane
+// reduction beyond one shuffle (round 1's shuffle version cost +12 us; reference models.py:813 log_softmax).
+#include "rtx_gemm.h"
+
+#include <utility>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 gd_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float gd_f32x16;
+typedef __attribute__((ext_vector_type(4))) float gd_f32x4;   // native vectors: arrays of them stay in registers (HIP's uint2 / float4
+typedef __attribute__((ext_vector_type(4))) unsigned gd_u32x4; // structs in an array were spilled to scratch right behind the asm reads)
+typedef __attribute__((ext_vector_type(2))) unsigned gd_u32x2;
+typedef __attribute__((address_space(3))) unsigned char gd_lds_byte;
+
+template <int... Is, typename F> __device__ __forceinline__ void gd_static_for_impl(std::integer_sequence<int, Is...>, F&& f)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void gd_static_for(F&& f)
+{
+    gd_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int OFF> __device__ __forceinline__ void gd_rd128(gd_u32x4& dst, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void gd_rdtr(gd_u32x2& dst, unsigned addr)
+{
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void gd_wait_lgkm()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs below the wait (they are register-only: "memory" does not order them)
+}
+template <int N> __device__ __forceinline__ void gd_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one k16-step's operand fragments.  The transposing reads deliver 8 bytes each: their halves are only put together at
+// the MFMA, AFTER the lgkmcnt wait (a copy the compiler places right behind the asm read would move stale registers).
+template <int FORM, int MI, int NJ> struct GdFrag {
+    gd_u32x4 a[MI];
+    gd_u32x4 b[NJ];
+    gd_u32x2 blo[NJ], bhi[NJ];
+};
+
+template <int FORM, int EPI, int WM, int WN, int MI, int NJ, int NS>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 1 ? (WM * WN) / 4 : 1) void rtx_gemm_dma(const RtxGemm p)
+{
+    constexpr int NW = WM * WN, BM = WM * MI * 32, BN = WN * NJ * 32, STAGE = (BM + BN) * 128;
+    constexpr int QA = BM / 8 / NW, QB = BN / 8 / NW;    // 1-KB DMA instructions per wave per slice
+    constexpr int SB = BN * 2;                            // NN: bytes of one k-row of the B slice image
+    constexpr int LPS = QA + QB;                          // loads per slice per wave
+    constexpr int NR = MI + (FORM == RTX_FORM_NN ? 2 * NJ : NJ);   // LDS reads per fragment set
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves' DMA blocks");
+    static_assert(FORM == RTX_FORM_NT || SB >= 256, "NN needs at least 128 columns per tile (64-byte granule swizzle)");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, g = lane >> 5;
+
+    // XCD-aware work mapping (workgroup b runs on XCD b % 8, used for speed only -- see gemm.hip)
+    int tm, tn, split;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        if (p.splits > 1) {
+            const int tiles = p.m_tiles * p.n_tiles;
+            split = xcd + 8 * (j / tiles);
+            if (split >= p.splits) return;
+            const int t = j % tiles;
+            tm = t % p.m_tiles;
+            tn = t / p.m_tiles;
+        } else if (p.m_tiles <= p.n_tiles) {
+            split = 0;
+            tn = xcd + 8 * (j / p.m_tiles);
+            tm = j % p.m_tiles;
+            if (tn >= p.n_tiles) return;
+        } else {
+            split = 0;
+            tm = xcd + 8 * (j / p.n_tiles);
+            tn = j % p.n_tiles;
+            if (tm >= p.m_tiles) return;
+        }
+    }
+    const int per = (p.k_slices + p.splits - 1) / p.splits;
+    const int ks0 = split * per;
+    const int nk = min(ks0 + per, p.k_slices) - ks0;
+
+    // ---- DMA source addresses (per lane, fixed for the whole K walk) ------------------------------------------------
+    const size_t rowA = (size_t)p.lda * 2, rowB = (size_t)p.ldb * 2;
+    const int brow = lane >> 3, chunk = (lane & 7) ^ brow;
+    const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * BM + wave * 8 + brow) * rowA + chunk * 16 + (size_t)ks0 * 128;
+    const unsigned char* gB[FORM == RTX_FORM_NN ? QB : 1];
+    if constexpr (FORM == RTX_FORM_NT) {
+        gB[0] = (const unsigned char*)p.B + ((size_t)tn * BN + wave * 8 + brow) * rowB + chunk * 16 + (size_t)ks0 * 128;
+    } else {
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int o = (wave + q * NW) * 1024 + lane * 16;   // physical byte of this lane's 16-byte piece in the slice image
+            const int rr = o / SB, ww = o % SB;
+            const int cc = (ww >> 6) ^ (rr & 3);                 // logical 64-byte granule that lives at this slot
+            gB[q] = (const unsigned char*)p.B + ((size_t)ks0 * 64 + rr) * rowB + (size_t)tn * BN * 2 + (cc << 6) + (ww & 63);
+        }
+    }
+    gd_lds_byte* lbase = (gd_lds_byte*)smem;
+
+    gd_f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto load_slice = [&](int stage, int t) __attribute__((always_inline)) {
+        gd_lds_byte* sb = lbase + stage * STAGE + wave * 1024;
+        const unsigned char* a_ = gA + (size_t)t * 128;
+#pragma unroll
+        for (int q = 0; q < QA; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(a_ + (size_t)q * NW * 8 * rowA),
+                                             (void __attribute__((address_space(3)))*)(sb + q * NW * 1024), 16, 0, 0);
+        if constexpr (FORM == RTX_FORM_NT) {
+            const unsigned char* b_ = gB[0] + (size_t)t * 128;
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+                __builtin_amdgcn_global_load_lds((const void*)(b_ + (size_t)q * NW * 8 * rowB),
+                                                 (void __attribute__((address_space(3)))*)(sb + BM * 128 + q * NW * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+                __builtin_amdgcn_global_load_lds((const void*)(gB[q] + (size_t)t * 64 * rowB),
+                                                 (void __attribute__((address_space(3)))*)(sb + BM * 128 + q * NW * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing -----------------------------------------------------------------------------------------
+    // K-contiguous operands: chunk c = g + 2 kk of row R sits at slot c ^ (R & 7); R & 7 == r & 7 for every fragment row
+    unsigned slk[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) slk[kk] = (unsigned)(((g + 2 * kk) ^ (r & 7)) * 16);
+    const unsigned offA = (unsigned)((wm * MI * 32 + r) * 128);
+    const unsigned offB_nt = (unsigned)((BM + wn * NJ * 32 + r) * 128);
+    // K-major B (transposing reads): the 16 lanes of a group fetch a [4 k][16 n] block, lane p at k-row p >> 2,
+    // 8 bytes at column (p & 3) * 4; group g4 = lane >> 4: n-half g4 & 1, k-group g4 >> 1 (MFMA B operand: lane (n, kgroup))
+    unsigned offB_nn[NJ];
+    {
+        const int p16 = lane & 15, g4 = lane >> 4, s = p16 >> 2;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = wn * NJ + j;   // logical 64-byte granule of this 32-column block
+            offB_nn[j] = (unsigned)(BM * 128 + ((g4 >> 1) * 8 + s) * SB + ((c ^ s) << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
+        }
+    }
+
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const unsigned sbase = (unsigned)(size_t)(lbase + stage * STAGE);
+        GdFrag<FORM, MI, NJ> x, y;
+        auto frag = [&](GdFrag<FORM, MI, NJ>& F, auto kkc) __attribute__((always_inline)) {
+            constexpr int kk = decltype(kkc)::value;
+            if constexpr (FORM == RTX_FORM_NT) {
+                const unsigned ab = sbase + offB_nt + slk[kk];
+                gd_static_for<NJ>([&](auto jc) __attribute__((always_inline)) { gd_rd128<decltype(jc)::value * 4096>(F.b[decltype(jc)::value], ab); });
+            } else {
+                gd_static_for<NJ>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    gd_rdtr<(kk * 16) * SB>(F.blo[j], sbase + offB_nn[j]);
+                    gd_rdtr<(kk * 16 + 4) * SB>(F.bhi[j], sbase + offB_nn[j]);
+                });
+            }
+            const unsigned aa = sbase + offA + slk[kk];
+            gd_static_for<MI>([&](auto ic) __attribute__((always_inline)) { gd_rd128<decltype(ic)::value * 4096>(F.a[decltype(ic)::value], aa); });
+        };
+        auto mma = [&](const GdFrag<FORM, MI, NJ>& F) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                gd_u32x4 bq;
+                if constexpr (FORM == RTX_FORM_NN) { bq[0] = F.blo[j][0]; bq[1] = F.blo[j][1]; bq[2] = F.bhi[j][0]; bq[3] = F.bhi[j][1]; }
+                else bq = F.b[j];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gd_bf16x8, F.a[i]), __builtin_bit_cast(gd_bf16x8, bq),
+                                                                        acc[i][j], 0, 0, 0);
+            }
+        };
+        frag(x, std::integral_constant<int, 0>{});
+        frag(y, std::integral_constant<int, 1>{});
+        gd_wait_lgkm<NR>();
+        mma(x);
+        frag(x, std::integral_constant<int, 2>{});
+        gd_wait_lgkm<NR>();
+        mma(y);
+        frag(y, std::integral_constant<int, 3>{});
+        gd_wait_lgkm<NR>();
+        mma(x);
+        gd_wait_lgkm<0>();
+        mma(y);
+    };
+
+    // ---- main loop: ring of NS stages, slices t .. t+NS-2 in flight at the top of iteration t ------------------------
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) load_slice(s, s);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (NS == 2 || nk - t < 2) gd_wait_vm<0>();   // my loads of slice t have landed
+        else gd_wait_vm<LPS>();                        //   (NS = 3: slice t+1 stays in flight)
+        __builtin_amdgcn_s_barrier();                  // everybody's have; everybody is done reading slice t-1
+        if (t + NS - 1 < nk) {
+            int nst = stage + NS - 1;
+            if (nst >= NS) nst -= NS;
+            load_slice(nst, t + NS - 1);
+        }
+        compute(stage);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    gd_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // all fragment reads are done: the stages become the epilogue's scratch
+
+    // ---- epilogue through LDS ------------------------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    constexpr int WCOLS = NJ * 32, WLD = WCOLS + 4;   // floats; +4 keeps the row-wise b128 reads conflict-free
+    static_assert(NW * 32 * WLD * 4 <= NS * STAGE, "epilogue scratch must fit in the stages");
+    float* wreg = (float*)smem + wave * (32 * WLD);
+    const int erow = lane >> 1, ehalf = lane & 1;      // row-wise pass: two lanes per row, WCOLS / 2 columns each
+    constexpr int HC = WCOLS / 2, NQ = HC / 4;
+    const int col0 = tn * BN + wn * WCOLS;             // first column of this wave
+    float bj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        bj[j] = 0.f;
+        if (EPI == RTX_EPI_BIAS_ROWS && p.bias) {
+            const int col = col0 + j * 32 + r;
+            bj[j] = p.bias[col < p.N_real ? col : 0];
+        }
+    }
+    const long ld = p.ldc;
+    float* cbase = p.C + (EPI == RTX_EPI_STORE ? (size_t)split * p.slab_stride : (size_t)0);
+    const bool vec_ok = ((ld & 3) == 0) && (((uintptr_t)cbase & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wreg[((e & 3) + 8 * (e >> 2) + 4 * g) * WLD + j * 32 + r] = acc[i][j][e] + bj[j];
+        __builtin_amdgcn_wave_barrier();
+        gd_f32x4 v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = *(const gd_f32x4*)(wreg + erow * WLD + ehalf * HC + q * 4);
+        __builtin_amdgcn_wave_barrier();
+        const int row = tm * BM + wm * MI * 32 + i * 32 + erow;
+        const int colh = col0 + ehalf * HC;
+        if constexpr (EPI == RTX_EPI_BIAS_ROWS) {
+            if (p.lse_part) {
+                // online-softmax partial of this row over the wave's strip: the lane's HC values, then one shuffle
+                float m = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c = colh + q * 4;
+                    if (c + 0 < p.N_real) m = fmaxf(m, v[q].x);
+                    if (c + 1 < p.N_real) m = fmaxf(m, v[q].y);
+                    if (c + 2 < p.N_real) m = fmaxf(m, v[q].z);
+                    if (c + 3 < p.N_real) m = fmaxf(m, v[q].w);
+                }
+                const float mo = __shfl_xor(m, 1, 64);
+                const float mm = fmaxf(m, mo);
+                float s = 0.f;
+                if (mm != -INFINITY) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = colh + q * 4;
+                        if (c + 0 < p.N_real) s += __expf(v[q].x - mm);
+                        if (c + 1 < p.N_real) s += __expf(v[q].y - mm);
+                        if (c + 2 < p.N_real) s += __expf(v[q].z - mm);
+                        if (c + 3 < p.N_real) s += __expf(v[q].w - mm);
+                    }
+                }
+                s += __shfl_xor(s, 1, 64);
+                if (ehalf == 0 && row < p.M_real) p.lse_part[(size_t)row * p.lse_ld + (tn * WN + wn)] = make_float2(mm, s);
+            }
+        }
+        const bool row_ok = (EPI == RTX_EPI_STORE) || row < p.M_real;
+        if (row_ok) {
+            float* dst = cbase + (size_t)row * ld + colh;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = colh + q * 4;
+                if (EPI == RTX_EPI_STORE || (vec_ok && c + 3 < p.N_real)) {
+                    *(gd_f32x4*)(dst + q * 4) = v[q];
+                } else {
+                    if (c + 0 < p.N_real) dst[q * 4 + 0] = v[q].x;
+                    if (c + 1 < p.N_real) dst[q * 4 + 1] = v[q].y;
+                    if (c + 2 < p.N_real) dst[q * 4 + 2] = v[q].z;
+                    if (c + 3 < p.N_real) dst[q * 4 + 3] = v[q].w;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+void rtx_gemm_dma_tile_dims(int cfg, int* bm, int* bn)
+{
+    switch (cfg) {
+    case RTX_DMA_512x128: *bm = 512; *bn = 128; break;
+    case RTX_DMA_256x256: *bm = 256; *bn = 256; break;
+    default: *bm = 128; *bn = 128; break;
+    }
+}
+
+template <int FORM, int EPI, int WM, int WN, int MI, int NJ, int NS>
+static int gd_launch(const RtxGemm& g, dim3 grid, hipStream_t stream)
+{
+    constexpr int BM = WM * MI * 32, BN = WN * NJ * 32, LDS = NS * (BM + BN) * 128;
+    static bool configured = false;
+    if (!configured) {
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_gemm_dma<FORM, EPI, WM, WN, MI, NJ, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured = true;
+    }
+    hipLaunchKernelGGL((rtx_gemm_dma<FORM, EPI, WM, WN, MI, NJ, NS>), grid, dim3(WM * WN * 64), LDS, stream, g);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+template <int FORM, int EPI> static int gd_launch_cfg(const RtxGemm& g, dim3 grid, hipStream_t stream)
+{
+    switch (g.tile_shape) {
+    case RTX_DMA_512x128: return gd_launch<FORM, EPI, 4, 2, 4, 2, 2>(g, grid, stream);
+    case RTX_DMA_256x256: return gd_launch<FORM, EPI, 2, 4, 4, 2, 2>(g, grid, stream);
+    default: return gd_launch<FORM, EPI, 2, 2, 2, 2, 3>(g, grid, stream);
+    }
+}
+
+// bf16 operands only.  g.tile_shape is an RtxDmaCfg; g.form RTX_FORM_NT / RTX_FORM_NN; epilogue RTX_EPI_STORE / RTX_EPI_BIAS_ROWS.
+int rtx_gemm_dma_launch(const RtxGemm& g, int epilogue, hipStream_t stream)
+{
+    RTX_CHECK(g.form == RTX_FORM_NT || g.form == RTX_FORM_NN, RTX_EINVAL, "gemm_dma: form %d not supported", g.form);
+    RTX_CHECK(epilogue == RTX_EPI_STORE || epilogue == RTX_EPI_BIAS_ROWS, RTX_EINVAL, "gemm_dma: bad epilogue %d", epilogue);
+    RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm_dma: empty problem");
+    RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm_dma: split-K only with EPI_STORE");
+    RTX_CHECK(g.tile_shape >= RTX_DMA_128x128 && g.tile_shape <= RTX_DMA_256x256, RTX_EINVAL, "gemm_dma: bad tile configuration %d", g.tile_shape);
+    RTX_CHECK((g.splits - 1) * ((g.k_slices + g.splits - 1) / g.splits) < g.k_slices, RTX_EINVAL, "gemm_dma: %d splits leave an empty split of %d slices",
+              g.splits, g.k_slices);
+    const int tiles = g.m_tiles * g.n_tiles;
+    int groups, gsize;
+    if (g.splits > 1) { groups = g.splits; gsize = tiles; }
+    else if (g.m_tiles <= g.n_tiles) { groups = g.n_tiles; gsize = g.m_tiles; }
+    else { groups = g.m_tiles; gsize = g.n_tiles; }
+    const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * gsize));
+    if (g.form == RTX_FORM_NT) {
+        if (epilogue == RTX_EPI_STORE) return gd_launch_cfg<RTX_FORM_NT, RTX_EPI_STORE>(g, grid, stream);
+        return gd_launch_cfg<RTX_FORM_NT, RTX_EPI_BIAS_ROWS>(g, grid, stream);
+    }
+    if (epilogue == RTX_EPI_STORE) return gd_launch_cfg<RTX_FORM_NN, RTX_EPI_STORE>(g, grid, stream);
+    return gd_launch_cfg<RTX_FORM_NN, RTX_EPI_BIAS_ROWS>(g, grid, stream);
+}

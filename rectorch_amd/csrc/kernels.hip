@@ -42,7 +42,8 @@ __device__ __forceinline__ int64_t csr_row(const RtxCsrView& v, int b) { return 
 // ------------------------------------------------------------------------------------------------
 // K1: gather.  One workgroup per (padded) batch row.  The row's stored entries are read coalesced
 // from the CSR arrays, normalised (F.normalize), dropped out, scattered into an LDS image of a chunk of
-// the dense row, and the chunk is streamed to HBM with 16-byte stores.
+// the dense row, and the chunk is streamed to HBM with 16-byte stores.  Column Iin of a real row is set
+// to one: read K-major by the weight-gradient kernel it turns into the bias-gradient column.
 // ------------------------------------------------------------------------------------------------
 #define RTX_GATHER_CHUNK 4096  // elements per LDS chunk (16 KB fp32 / 8 KB bf16)
 
@@ -53,7 +54,6 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     T* X = (T*)a.X + (size_t)b * a.ldx;
-    T* XT = (T*)a.XT;
     if (b >= a.B) {  // padding row of the batch: zeros (it multiplies nothing that is kept)
         for (int i = tid * 4; i < a.ldx; i += 256 * 4) store4<T>(X + i, 0.f, 0.f, 0.f, 0.f);
         if (tid == 0) a.tsum[b] = 0.f;
@@ -97,11 +97,10 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
                     const bool keep = a.mask ? (a.mask[e] != 0) : rtx_dropout_keep(a.seed, a.offset, e, a.dropout_p);
                     v = keep ? v * scale : 0.f;
                 }
-                const T t = Elem<T>::from(v);
-                row[i - c0] = t;
-                if (XT) XT[(size_t)i * a.ldt + b] = t;
+                row[i - c0] = Elem<T>::from(v);
             }
         }
+        if (tid == 0 && a.Iin >= c0 && a.Iin < c0 + cn) row[a.Iin - c0] = Elem<T>::from(1.f);   // ones column -> bias gradient
         __syncthreads();
         if (sizeof(T) == 2) {
             for (int i = tid * 8; i < cn; i += 256 * 8) *(uint4*)(X + c0 + i) = *(const uint4*)(row + i);
@@ -110,7 +109,6 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
         }
         __syncthreads();
     }
-    if (XT && tid == 0) XT[(size_t)a.Iin * a.ldt + b] = Elem<T>::from(1.f);  // ones row -> bias gradient
 }
 
 int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream)
@@ -155,103 +153,57 @@ int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipSt
 }
 
 // ------------------------------------------------------------------------------------------------
-// post kernels: TB x 64 tiles (TB batch rows, 64 features) of an fp32 [Bp][*] matrix -> T row-major and
-// T transposed, through LDS so both orientations are written in contiguous pieces.  TB = 64 for the
-// [B, n_items] logits gradient (full 128-B runs in the transposed image), TB = 16 for the small hidden
-// activations (4x more workgroups: these kernels are latency-, not bandwidth-bound).
+// post kernels: fp32 GEMM output (split-K slabs) -> bias + tanh (forward) / x (1 - o^2) (backward), written
+// row-major in the compute type.  16 x 64 tiles, one float4 per thread and slab; latency-bound, so small
+// tiles = many workgroups.  (Round 1 also wrote every result transposed through LDS; the K-major operand
+// reads of the weight-gradient kernel made those copies unnecessary.)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TB>
-__device__ __forceinline__ void tile_write_transposed(const float (*tile)[65], T* __restrict__ RT, int ldt, int b0, int n0, int tid,
-                                                      int ones_n, int B)
-{
-    constexpr int EPT = TB / 4;  // consecutive batch entries per thread
-    const int nl = tid >> 2, bq = (tid & 3) * EPT;
-    T* dst = RT + (size_t)(n0 + nl) * ldt + b0 + bq;
-    float v[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) v[e] = tile[bq + e][nl];
-    if (n0 + nl == ones_n) {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) v[e] = (b0 + bq + e < B) ? 1.f : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < EPT; e += 4) store4<T>(dst + e, v[e], v[e + 1], v[e + 2], v[e + 3]);
-}
-
-template <typename T, int MODE, int TB>
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_post(const RtxPostArgs a)
 {
-    __shared__ float tile[TB][65];
-    constexpr int NP = TB / 16;  // passes: 16 rows x 64 columns (float4 per thread) each
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * TB;
-    const int nl = (tid & 15) * 4, n = n0 + nl;
-    const float* __restrict__ C = a.C;
-    float4 c[NP];
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) c[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // split-K slabs: keep NP * 4 independent 16-byte loads in flight per thread
+    const int n = blockIdx.x * 64 + (tid & 15) * 4, b = blockIdx.y * 16 + (tid >> 4);
+    const float* __restrict__ C = a.C + (size_t)b * a.ldc + n;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int s = 0; s < a.splits; ++s) {
-#pragma unroll
-        for (int pass = 0; pass < NP; ++pass) {
-            const int b = b0 + pass * 16 + (tid >> 4);
-            const float4 t = *(const float4*)(C + (size_t)s * a.slab_stride + (size_t)b * a.ldc + n);
-            c[pass].x += t.x; c[pass].y += t.y; c[pass].z += t.z; c[pass].w += t.w;
-        }
+        const float4 t = *(const float4*)(C + (size_t)s * a.slab_stride);
+        c.x += t.x; c.y += t.y; c.z += t.z; c.w += t.w;
+    }
+    float v[4] = {c.x, c.y, c.z, c.w};
+    if (MODE == RTX_POST_BWD && a.tanh_act) {
+        const float4 o = *(const float4*)(a.O32 + (size_t)b * a.Np + n);
+        v[0] *= (1.f - o.x * o.x); v[1] *= (1.f - o.y * o.y);
+        v[2] *= (1.f - o.z * o.z); v[3] *= (1.f - o.w * o.w);
     }
 #pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const int bl = pass * 16 + (tid >> 4);
-        const int b = b0 + bl;
-        float v[4] = {c[pass].x, c[pass].y, c[pass].z, c[pass].w};
-        if (MODE == RTX_POST_BWD && a.tanh_act) {
-            const float4 o = *(const float4*)(a.O32 + (size_t)b * a.Np + n);
-            v[0] *= (1.f - o.x * o.x); v[1] *= (1.f - o.y * o.y);
-            v[2] *= (1.f - o.z * o.z); v[3] *= (1.f - o.w * o.w);
+    for (int e = 0; e < 4; ++e) {
+        const bool valid = (b < a.B) && (n + e < a.N_real);
+        float x = v[e];
+        if (MODE == RTX_POST_FWD && valid) {
+            x += a.bias[n + e];
+            if (a.tanh_act) x = tanhf(x);
         }
-        float lse = 0.f, sc = 0.f;
-        if (MODE == RTX_POST_DLOGITS && b < a.B) {
-            lse = a.lse[b];
-            sc = a.tsum[b] * a.inv_batch;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool valid = (b < a.B) && (n + e < a.N_real);
-            float x = v[e];
-            if (MODE == RTX_POST_FWD) {
-                if (valid) {
-                    x += a.bias[n + e];
-                    if (a.tanh_act) x = tanhf(x);
-                }
-            } else if (MODE == RTX_POST_DLOGITS) {
-                x = valid ? sc * __expf(x - lse) : 0.f;
-            }
-            v[e] = valid ? x : 0.f;
-            tile[bl][nl + e] = v[e];
-        }
-        if (MODE == RTX_POST_FWD && a.O32) *(float4*)(a.O32 + (size_t)b * a.Np + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.R) store4<T>((T*)a.R + (size_t)b * a.Np + n, v[0], v[1], v[2], v[3]);
+        v[e] = valid ? x : 0.f;
     }
-    if (a.RT) {
-        __syncthreads();
-        tile_write_transposed<T, TB>(tile, (T*)a.RT, a.ldt, b0, n0, tid, (MODE == RTX_POST_FWD && a.ones_row) ? a.N_real : -1, a.B);
+    if (MODE == RTX_POST_FWD && a.O32) *(float4*)(a.O32 + (size_t)b * a.Np + n) = make_float4(v[0], v[1], v[2], v[3]);
+    if (a.R) {
+        if (MODE == RTX_POST_FWD && a.ones_col && b < a.B && a.N_real >= n && a.N_real < n + 4) v[a.N_real - n] = 1.f;
+        store4<T>((T*)a.R + (size_t)b * a.Np + n, v[0], v[1], v[2], v[3]);
     }
 }
 
 int rtx_launch_post(const RtxPostArgs& a, int mode, int is_bf16, hipStream_t stream)
 {
-    RTX_CHECK(a.Np % 64 == 0 && a.Bp % 64 == 0 && a.ldc % 4 == 0, RTX_EINVAL, "post: bad padding");
-    const dim3 block(256);
-#define RTX_P(T, M, TB) hipLaunchKernelGGL((k_post<T, M, TB>), dim3(a.Np / 64, a.Bp / TB), block, 0, stream, a)
+    RTX_CHECK(a.Np % 64 == 0 && a.Bp % 16 == 0 && a.ldc % 4 == 0, RTX_EINVAL, "post: bad padding");
+    const dim3 block(256), grid(a.Np / 64, a.Bp / 16);
+#define RTX_P(T, M) hipLaunchKernelGGL((k_post<T, M>), grid, block, 0, stream, a)
     if (is_bf16) {
-        if (mode == RTX_POST_FWD) RTX_P(bf16_t, RTX_POST_FWD, 16);
-        else if (mode == RTX_POST_BWD) RTX_P(bf16_t, RTX_POST_BWD, 16);
-        else RTX_P(bf16_t, RTX_POST_DLOGITS, 64);
+        if (mode == RTX_POST_FWD) RTX_P(bf16_t, RTX_POST_FWD);
+        else RTX_P(bf16_t, RTX_POST_BWD);
     } else {
-        if (mode == RTX_POST_FWD) RTX_P(float, RTX_POST_FWD, 16);
-        else if (mode == RTX_POST_BWD) RTX_P(float, RTX_POST_BWD, 16);
-        else RTX_P(float, RTX_POST_DLOGITS, 64);
+        if (mode == RTX_POST_FWD) RTX_P(float, RTX_POST_FWD);
+        else RTX_P(float, RTX_POST_BWD);
     }
 #undef RTX_P
     RTX_HIP(hipGetLastError());
@@ -266,11 +218,9 @@ int rtx_launch_post(const RtxPostArgs& a, int mode, int is_bf16, hipStream_t str
 template <typename T>
 __global__ __launch_bounds__(256) void k_vae_fwd(const RtxVaeFwdArgs a)
 {
-    __shared__ float tile[16][65];
     const int tid = threadIdx.x;
-    const int j0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const int j = blockIdx.x * 64 + (tid & 63), b0 = blockIdx.y * 16;
     const float* __restrict__ C = a.C;
-    const int jl = tid & 63, j = j0 + jl;
     float m[4], lv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -286,7 +236,7 @@ __global__ __launch_bounds__(256) void k_vae_fwd(const RtxVaeFwdArgs a)
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int bl = k * 4 + (tid >> 6), b = b0 + bl;
+        const int b = b0 + k * 4 + (tid >> 6);
         float z = 0.f;
         if (b < a.B && j < a.Z) {
             const float mm = m[k] + a.bias[j], l = lv[k] + a.bias[a.Z + j];
@@ -301,11 +251,9 @@ __global__ __launch_bounds__(256) void k_vae_fwd(const RtxVaeFwdArgs a)
             if (a.mu_out) a.mu_out[o] = mm;
             if (a.lv_out) a.lv_out[o] = l;
         }
-        tile[bl][jl] = z;
+        if (b < a.B && j == a.Z) z = 1.f;   // ones column -> bias gradient of the first decoder layer
         ((T*)a.Zr)[(size_t)b * a.Zp + j] = Elem<T>::from(z);
     }
-    __syncthreads();
-    tile_write_transposed<T, 16>(tile, (T*)a.ZT, a.ldt, b0, j0, tid, a.Z, a.B);
 }
 
 int rtx_launch_vae_fwd(const RtxVaeFwdArgs& a, int is_bf16, hipStream_t stream)
@@ -322,11 +270,9 @@ int rtx_launch_vae_fwd(const RtxVaeFwdArgs& a, int is_bf16, hipStream_t stream)
 template <typename T>
 __global__ __launch_bounds__(256) void k_vae_bwd(const RtxVaeBwdArgs a)
 {
-    __shared__ float tile[16][65];
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const int n = blockIdx.x * 64 + (tid & 63), b0 = blockIdx.y * 16;
     const float* __restrict__ C = a.C;
-    const int nl = tid & 63, n = n0 + nl;
     const int j = (n < a.Z) ? n : n - a.Z;
     float dz[4], mu[4], lv[4], ep[4];
 #pragma unroll
@@ -341,7 +287,7 @@ __global__ __launch_bounds__(256) void k_vae_bwd(const RtxVaeBwdArgs a)
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int bl = k * 4 + (tid >> 6), b = b0 + bl;
+        const int b = b0 + k * 4 + (tid >> 6);
         float d = 0.f;
         if (b < a.B && n < 2 * a.Z) {
             if (n < a.Z) {
@@ -351,11 +297,8 @@ __global__ __launch_bounds__(256) void k_vae_bwd(const RtxVaeBwdArgs a)
                 if (a.training) d += dz[k] * ep[k] * 0.5f * expf(0.5f * lv[k]);
             }
         }
-        tile[bl][nl] = d;
         ((T*)a.D)[(size_t)b * a.Np + n] = Elem<T>::from(d);
     }
-    __syncthreads();
-    tile_write_transposed<T, 16>(tile, (T*)a.DT, a.ldt, b0, n0, tid, -1, a.B);
 }
 
 int rtx_launch_vae_bwd(const RtxVaeBwdArgs& a, int is_bf16, hipStream_t stream)
@@ -416,64 +359,6 @@ __device__ float block_lse(const float* y, int I, float* red)
     return M + logf(S);
 }
 
-__global__ __launch_bounds__(256) void k_lse_loss(const RtxLossArgs a)
-{
-    __shared__ float red[8];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* y = a.Y + (size_t)b * a.ldy;
-    float lse;
-    if (a.part) {
-        // combine the strip partials the logits GEMM left behind (n_strips * 8 bytes instead of 4 * n_items)
-        float m = -INFINITY, s = 0.f;
-        for (int k = tid; k < a.n_strips; k += 256) {
-            const float2 pr = a.part[(size_t)b * a.part_ld + k];
-            online_merge(m, s, pr.x, pr.y);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-            online_merge(m, s, m2, s2);
-        }
-        __syncthreads();
-        if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = s; }
-        __syncthreads();
-        float M = red[0], S = red[4];
-        online_merge(M, S, red[1], red[5]);
-        online_merge(M, S, red[2], red[6]);
-        online_merge(M, S, red[3], red[7]);
-        lse = M + logf(S);
-        __syncthreads();
-    } else {
-        lse = block_lse(y, a.I, red);
-    }
-    const int64_t u = csr_row(a.target, b);
-    float dot = 0.f;
-    for (int64_t k = a.target.indptr[u] + tid; k < a.target.indptr[u + 1]; k += 256)
-        dot += (a.target.values ? a.target.values[k] : 1.f) * y[a.target.indices[k]];
-    dot = block_sum(dot, red);
-    float kl = 0.f;
-    if (a.mu32) {
-        for (int j = tid; j < a.Z; j += 256) {
-            const float m = a.mu32[(size_t)b * a.Z + j], lv = a.lv32[(size_t)b * a.Z + j];
-            kl += 1.f + lv - m * m - expf(lv);
-        }
-        kl = block_sum(kl, red);
-    }
-    if (tid == 0) {
-        a.lse[b] = lse;
-        a.row_loss[b] = (a.tsum[b] * lse - dot) * a.inv_batch + a.beta * (-0.5f * kl) * a.inv_batch;
-    }
-}
-
-int rtx_launch_lse_loss(const RtxLossArgs& a, hipStream_t stream)
-{
-    if (a.B <= 0) return RTX_OK;
-    RTX_CHECK(a.ldy % 4 == 0, RTX_EINVAL, "lse: ldy must be a multiple of 4");
-    hipLaunchKernelGGL(k_lse_loss, dim3(a.B), dim3(256), 0, stream, a);
-    RTX_HIP(hipGetLastError());
-    return RTX_OK;
-}
-
 __global__ __launch_bounds__(256) void k_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int nt,
                                                      float* loss_out, float* loss_accum)
 {
@@ -498,29 +383,104 @@ int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float*
     return RTX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Loss and its gradient w.r.t. the logits, one pass over Y (one workgroup per user):
+//   lse_b       = logsumexp(Y_b)            from the strip partials of the logits GEMM (or a first pass over the row)
+//   D[b][i]     = (s_b * exp(Y_bi - lse_b) - t_bi) * inv_batch         (reference models.py:813-815 through autograd)
+//   row_loss_b  = (s_b * lse_b - <t_b, Y_b>) * inv_batch (+ beta * KL_b * inv_batch)
+// The target row is sparse: its stored entries are scattered into an LDS image of a 4096-column chunk (as k_gather
+// does for the input), so the pass over Y is purely streaming: 16-byte loads of Y, 8 / 16-byte stores of D.
+// Replaces round 1's k_lse_loss + dlogits post kernel (which also wrote D transposed) + k_target_fixup.
+// ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_target_fixup(const RtxCsrView t, float inv_batch, T* D, int ldd, T* DT, int ldt)
+__global__ __launch_bounds__(256) void k_dlogits(const RtxDlogitsArgs a)
 {
-    const int b = blockIdx.x;
-    const int64_t u = csr_row(t, b);
-    for (int64_t k = t.indptr[u] + threadIdx.x; k < t.indptr[u + 1]; k += 256) {
-        const int i = t.indices[k];
-        const float val = t.values ? t.values[k] : 1.f;
-        const size_t o = (size_t)b * ldd + i;
-        const T nv = Elem<T>::from(Elem<T>::to(D[o]) - val * inv_batch);
-        D[o] = nv;
-        DT[(size_t)i * ldt + b] = nv;
+    __shared__ __attribute__((aligned(16))) float timg[RTX_GATHER_CHUNK];
+    __shared__ float red[8];
+    const RtxLossArgs& L = a.loss;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    T* Drow = (T*)a.D + (size_t)b * a.ldd;
+    if (b >= L.B) {
+        for (int i = tid * 4; i < a.ldd; i += 256 * 4) store4<T>(Drow + i, 0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float* y = L.Y + (size_t)b * L.ldy;
+    float lse;
+    if (L.part) {
+        float m = -INFINITY, s = 0.f;
+        for (int k = tid; k < L.n_strips; k += 256) {
+            const float2 pr = L.part[(size_t)b * L.part_ld + k];
+            online_merge(m, s, pr.x, pr.y);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            online_merge(m, s, m2, s2);
+        }
+        if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = s; }
+        __syncthreads();
+        float M = red[0], S = red[4];
+        online_merge(M, S, red[1], red[5]);
+        online_merge(M, S, red[2], red[6]);
+        online_merge(M, S, red[3], red[7]);
+        lse = M + logf(S);
+        __syncthreads();
+    } else {
+        lse = block_lse(y, L.I, red);
+    }
+    const float sc = L.tsum[b] * L.inv_batch;
+    const int64_t u = csr_row(L.target, b);
+    const int64_t tb = L.target.indptr[u], te = L.target.indptr[u + 1];
+    float dot = 0.f;
+    for (int c0 = 0; c0 < a.ldd; c0 += RTX_GATHER_CHUNK) {
+        const int cn = min(RTX_GATHER_CHUNK, a.ldd - c0);
+        for (int i = tid * 4; i < cn; i += 256 * 4) *(float4*)(timg + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        for (int64_t k = tb + tid; k < te; k += 256) {
+            const int i = L.target.indices[k];
+            if (i >= c0 && i < c0 + cn && i < L.I) timg[i - c0] = L.target.values ? L.target.values[k] : 1.f;
+        }
+        __syncthreads();
+        for (int i = tid * 4; i < cn; i += 256 * 4) {
+            const int col = c0 + i;
+            float4 yy = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < L.ldy) yy = *(const float4*)(y + col);   // ldy is a multiple of 4: a group is inside the row or past it
+            const float4 tt = *(const float4*)(timg + i);
+            const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
+            float d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = col + e < L.I;
+                d[e] = valid ? sc * __expf(yv[e] - lse) - tv[e] * L.inv_batch : 0.f;
+                if (valid) dot += tv[e] * yv[e];
+            }
+            store4<T>(Drow + col, d[0], d[1], d[2], d[3]);
+        }
+        __syncthreads();
+    }
+    dot = block_sum(dot, red);
+    float kl = 0.f;
+    if (L.mu32) {
+        for (int j = tid; j < L.Z; j += 256) {
+            const float m = L.mu32[(size_t)b * L.Z + j], lv = L.lv32[(size_t)b * L.Z + j];
+            kl += 1.f + lv - m * m - expf(lv);
+        }
+        kl = block_sum(kl, red);
+    }
+    if (tid == 0) {
+        L.lse[b] = lse;
+        L.row_loss[b] = (L.tsum[b] * lse - dot) * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
     }
 }
 
-int rtx_launch_target_fixup(const RtxCsrView& target, int B, float inv_batch, void* D, int ldd, void* DT, int ldt,
-                            int is_bf16, hipStream_t stream)
+int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream)
 {
-    if (B <= 0) return RTX_OK;
+    if (a.Bp <= 0) return RTX_OK;
+    RTX_CHECK(a.loss.ldy % 4 == 0 && a.ldd % 8 == 0 && a.ldd >= a.loss.I, RTX_EINVAL, "dlogits: bad leading dimensions");
     if (is_bf16)
-        hipLaunchKernelGGL(k_target_fixup<bf16_t>, dim3(B), dim3(256), 0, stream, target, inv_batch, (bf16_t*)D, ldd, (bf16_t*)DT, ldt);
+        hipLaunchKernelGGL(k_dlogits<bf16_t>, dim3(a.Bp), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(k_target_fixup<float>, dim3(B), dim3(256), 0, stream, target, inv_batch, (float*)D, ldd, (float*)DT, ldt);
+        hipLaunchKernelGGL(k_dlogits<float>, dim3(a.Bp), dim3(256), 0, stream, a);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -697,8 +657,8 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
     const RtxAdamTensor& t = a.t[ti];
     const int local = tile_id - t.tile_start;
     float reg = 0.f;
-    if (a.lam != 0.f && a.sumsq) {
-        const float nrm = sqrtf(a.sumsq[ti]);
+    if (a.lam != 0.f && t.sumsq) {
+        const float nrm = sqrtf(*t.sumsq);
         reg = nrm > 0.f ? a.lam / nrm : 0.f;
     }
     if (t.flat) {
@@ -876,39 +836,6 @@ int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
         hipLaunchKernelGGL(k_adam<bf16_t>, dim3(grid), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(k_adam<float>, dim3(grid), dim3(256), 0, stream, a);
-    RTX_HIP(hipGetLastError());
-    return RTX_OK;
-}
-
-// compute-copy transpose: out[c][r] = in[r][c] for r < R, c < C (64x64 tiles through LDS, both sides coalesced).
-// Used after the fused dW+Adam GEMM, whose epilogue refreshes only the K(=in)-contiguous copy.
-template <typename T>
-__global__ __launch_bounds__(256) void k_transpose(const T* __restrict__ in, int ld_in, T* __restrict__ out, int ld_out, int R, int C)
-{
-    __shared__ T tile[64][66];
-    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int idx = k * 256 + tid, rr = idx >> 6, cc = idx & 63;
-        const bool ok = (r0 + rr < R) && (c0 + cc < C);
-        tile[rr][cc] = ok ? in[(size_t)(r0 + rr) * ld_in + c0 + cc] : (T)0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int idx = k * 256 + tid, cc = idx >> 6, rr = idx & 63;
-        if ((r0 + rr < R) && (c0 + cc < C)) out[(size_t)(c0 + cc) * ld_out + r0 + rr] = tile[rr][cc];
-    }
-}
-
-int rtx_launch_transpose(const void* in, int ld_in, void* out, int ld_out, int R, int C, int is_bf16, hipStream_t stream)
-{
-    if (R <= 0 || C <= 0) return RTX_OK;
-    const dim3 grid((C + 63) / 64, (R + 63) / 64), block(256);
-    if (is_bf16)
-        hipLaunchKernelGGL(k_transpose<bf16_t>, grid, block, 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, R, C);
-    else
-        hipLaunchKernelGGL(k_transpose<float>, grid, block, 0, stream, (const float*)in, ld_in, (float*)out, ld_out, R, C);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

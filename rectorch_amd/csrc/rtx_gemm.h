@@ -22,11 +22,9 @@ enum RtxEpilogue {
     RTX_EPI_STORE = 0,   // C (fp32) [M_pad][ldc] (+ split * slab_stride): raw accumulators, unguarded
     RTX_EPI_BIAS_ROWS = 1,  // C[m][n] = acc + bias[n] for m < M_real, n < N_real (ldc arbitrary): logits
     RTX_EPI_GRAD = 2,    // gW[m * N_real + n] = acc (m < M_real, n < N_real); gb[m] = acc at n == N_real
-    RTX_EPI_ADAM = 3,    // the gradient never leaves the registers: torch.optim.Adam update of W (p, exp_avg, exp_avg_sq)
-                         // + refresh of its compute copies, fused into the weight-gradient GEMM (single-GPU step)
 };
 
-// Adam state of the tensor a RTX_EPI_ADAM launch updates (all [M_real][N_real] row-major float32)
+// Adam state of the tensor a fused weight-gradient launch (RTX_DW_ADAM, dw_adam.hip) updates (all [M_real][N_real] row-major float32)
 struct RtxAdamEpi {
     float* p;
     float* m;
@@ -47,9 +45,17 @@ enum RtxTileShape {     // workgroup tile of C; 128x128 runs 4 waves, the others
 };
 void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
 
+// operand forms.  NT: A[m][k], B[n][k] (both K-contiguous).  NN: B is [k][n] (K-major: the weight matrix itself in the data
+// gradient).  TN: A is [k][m] and B is [k][n] (the weight gradient straight from the row-major activations / deltas).
+enum RtxForm { RTX_FORM_NT = 0, RTX_FORM_NN = 1, RTX_FORM_TN = 2 };
+// tile configurations of the LDS-DMA GEMM (gemm_dma.hip): 4-wave 128x128, 8-wave 512x128 (all rows of a B = 500 step), 8-wave 256x256
+enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2 };
+void rtx_gemm_dma_tile_dims(int cfg, int* bm, int* bn);
+
 struct RtxGemm {
-    const void* A;       // [M_pad][lda] elements of T
-    const void* B;       // [N_pad][ldb]
+    const void* A;       // [M_pad][lda] elements of T   (TN: [K_pad][lda])
+    const void* B;       // [N_pad][ldb]                 (NN / TN: [K_pad][ldb])
+    int form;            // RtxForm (0 = NT)
     long lda, ldb;       // leading dimensions in elements
     int tile_shape;      // RtxTileShape; M_pad / N_pad must be multiples of the tile
     int m_tiles, n_tiles;
@@ -62,7 +68,6 @@ struct RtxGemm {
     const float* bias;   // RTX_EPI_BIAS_ROWS
     float* gbias;        // RTX_EPI_GRAD (nullable)
     int M_real, N_real;
-    RtxAdamEpi adam;     // RTX_EPI_ADAM
     float2* lse_part;    // RTX_EPI_BIAS_ROWS (nullable): per row, per 64-column strip (running max, sum exp) of the
     int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
 };
@@ -71,6 +76,30 @@ struct RtxGemm {
 enum RtxDtype { RTX_DT_F32 = 0, RTX_DT_BF16 = 1, RTX_DT_FP8 = 2 };
 
 int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t stream);
+// bf16, LDS-DMA staging, NT / NN, RTX_EPI_STORE (split-K slabs) / RTX_EPI_BIAS_ROWS (+ log-sum-exp partials); g.tile_shape = RtxDmaCfg
+int rtx_gemm_dma_launch(const RtxGemm& g, int epilogue, hipStream_t stream);
+
+// float32 operands with a K-major matrix (gemm_f32.hip): g.form RTX_FORM_NN / RTX_FORM_TN, 128x128 tiles, g.k_slices = K_pad / 32;
+// RTX_EPI_STORE (split-K slabs) / RTX_EPI_GRAD
+int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream);
+
+// ---- weight gradient in TN form, optionally fused with the Adam update (dw_adam.hip; bf16 operands) ------------------
+enum RtxDwEpilogue { RTX_DW_GRAD = 0, RTX_DW_ADAM = 1 };
+enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2 };
+struct RtxDw {
+    const void* A;       // delta      bf16 [K_pad][lda]: k = batch row, m = output feature (contiguous)
+    const void* B;       // activation bf16 [K_pad][ldb]: n = input feature (contiguous); column N_real holds ones
+    long lda, ldb;
+    int m_tiles, n_tiles;   // M_pad / tile rows, N_pad / 128
+    int k_slices;           // K_pad / 64 (>= 2)
+    int M_real, N_real;
+    float* gW;           // RTX_DW_GRAD: float32 [M_real][N_real] (nullable)
+    bf16_t* g16;         // RTX_DW_GRAD: bf16 image of the same (nullable): staged for a bf16 gradient exchange
+    float* gbias;        // [M_real] = column N_real of the product (nullable)
+    RtxAdamEpi adam;     // RTX_DW_ADAM
+};
+int rtx_dw_tile_rows(int cfg);
+int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 
 // Gram matrix of the EASE solver (syrk.hip): C[m][n] = sum_k A[m][k] A[n][k] for the 128-column tiles on or below the
 // diagonal; A has 256 * rows256 zero-padded rows of k_slices * 128 bytes (fp8 e4m3 or bf16; element (row, slice ks) at

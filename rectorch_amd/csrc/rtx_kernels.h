@@ -21,17 +21,16 @@ struct rtx_csr {
     int32_t n_cols = 0;
 };
 
-// ---- K1: sparse user rows -> dense normalised (+dropout) input, both orientations ------------------
-//   X  [Bp][ldx]  row-major   (forward A operand; rows >= B are written as zeros)
-//   XT [P(I)][ldt] transposed (weight-gradient B operand; caller memsets it, the kernel scatters the
-//                  non-zeros and sets row I to ones for b < B -> bias gradient column)
+// ---- K1: sparse user rows -> dense normalised (+dropout) input ---------------------------------------
+//   X  [Bp][ldx]  row-major: forward A operand and (read K-major) weight-gradient B operand; rows >= B are
+//                 written as zeros; column Iin holds ONES for b < B, so the weight-gradient product emits the
+//                 bias gradient as one extra output column (the forward weight copy has a zero column there)
 //   tsum[b] = sum of the TARGET row's values (s_b of the multinomial likelihood)
 struct RtxGatherArgs {
     RtxCsrView in, target;
-    int B, Bp, I, ldx, ldt;
+    int B, Bp, I, ldx;
     int Iin;              // input columns (= I, or I + cond_dim: trailing condition columns stay raw)
     void* X;
-    void* XT;
     float* tsum;
     int training;
     float dropout_p;
@@ -43,26 +42,20 @@ int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream);
 // DataSampler densify: rows -> float32 [B][I] (ld = I), optional second matrix
 int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipStream_t stream);
 
-// ---- post kernels: fp32 GEMM output (possibly split-K slabs) -> activations in the layouts the next
-//      GEMMs want.  Tiles of 64x64 go through LDS so both orientations are written coalesced. ---------
-enum { RTX_POST_FWD = 0, RTX_POST_BWD = 1, RTX_POST_DLOGITS = 2 };
+// ---- post kernels: fp32 GEMM output (possibly split-K slabs) -> the next GEMM's operand (row-major) -----
+enum { RTX_POST_FWD = 0, RTX_POST_BWD = 1 };
 struct RtxPostArgs {
     const float* C;     // [splits][Bp][ldc]
     int splits;
     long slab_stride;
     int ldc;
     int B, Bp;          // valid / padded batch rows processed by this call
-    int ldt;            // leading dimension (allocated padded batch) of the transposed output
     int N_real, Np;     // valid / padded feature columns
     int tanh_act;
     const float* bias;  // FWD
     float* O32;         // FWD: post-activation fp32 [Bp][Np] (nullable); BWD: input (the saved activation)
     void* R;            // row-major output  T [Bp][Np]   (nullable)
-    void* RT;           // transposed output T [Np][Bp]   (nullable)
-    int ones_row;       // FWD: write ones (b < B) into RT row N_real
-    const float* lse;   // DLOGITS
-    const float* tsum;  // DLOGITS
-    float inv_batch;    // DLOGITS
+    int ones_col;       // FWD: R[b][N_real] = 1 for b < B (bias-gradient column of the next layer's weight gradient)
 };
 int rtx_launch_post(const RtxPostArgs& a, int mode, int is_bf16, hipStream_t stream);
 
@@ -72,15 +65,14 @@ struct RtxVaeFwdArgs {
     int splits;
     long slab_stride;
     int ldc;
-    int B, Bp, ldt, Z, Zp;
+    int B, Bp, Z, Zp;
     const float* bias;   // [2Z]
     float* mu32;         // [Bp][Z] engine copies for the backward
     float* lv32;
     float* eps32;
     float* mu_out;       // [B][Z] user outputs (nullable)
     float* lv_out;
-    void* Zr;            // T [Bp][Zp]
-    void* ZT;            // T [Zp][Bp], row Z = ones
+    void* Zr;            // T [Bp][Zp], column Z = ones (b < B)
     int training;
     const float* eps_in; // [B][Z] injected (nullable -> Philox)
     uint64_t seed, offset;
@@ -92,14 +84,13 @@ struct RtxVaeBwdArgs {
     int splits;
     long slab_stride;
     int ldc;
-    int B, Bp, ldt, Z, Np;  // Np = P(2Z)
+    int B, Bp, Z, Np;  // Np = P(2Z)
     const float* mu32;
     const float* lv32;
     const float* eps32;
     int training;
     float beta, inv_batch;
     void* D;   // T [Bp][Np]
-    void* DT;  // T [Np][Bp]
 };
 int rtx_launch_vae_bwd(const RtxVaeBwdArgs& a, int is_bf16, hipStream_t stream);
 
@@ -120,13 +111,19 @@ struct RtxLossArgs {
     int Z;
     float beta;
 };
-int rtx_launch_lse_loss(const RtxLossArgs& a, hipStream_t stream);
 // loss_out[0] = sum(row_loss[0..B)) + lam * sum_t sqrt(sumsq[t]);  loss_accum[0] += the same (nullable)
 int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int n_tensors,
                            float* loss_out, float* loss_accum, hipStream_t stream);
-// D[b][i] -= val/B, DT[i][b] likewise, at the target's stored entries
-int rtx_launch_target_fixup(const RtxCsrView& target, int B, float inv_batch, void* D, int ldd, void* DT, int ldt,
-                            int is_bf16, hipStream_t stream);
+// Loss AND its gradient w.r.t. the logits in one pass over Y (reference models.py:813-815 + autograd of log_softmax):
+//   lse_b from the strip partials the logits GEMM left (or, without them, a first pass over the row),
+//   row_loss_b as rtx_launch_lse_loss,  D[b][i] = (s_b * softmax(Y_b)_i - t_bi) * inv_batch  (T = bf16 / f32, zero padding)
+struct RtxDlogitsArgs {
+    RtxLossArgs loss;   // Y, target, tsum, part..., outputs lse / row_loss, KL inputs
+    int Bp;             // rows [B, Bp) of D are written as zeros
+    void* D;            // T [Bp][ldd]
+    int ldd;            // >= I, multiple of 8; columns [I, ldd) are written as zeros
+};
+int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream);
 // predict(): logits[b][i] = -inf where the input has a stored non-zero
 int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, int n_items, hipStream_t stream);
 // public loss_function on dense tensors: row_loss[b] = s*lse - <x,y>  (+ beta * KL_b)
@@ -148,7 +145,8 @@ struct RtxAdamTensor {
     float* m;
     float* v;
     void* sh;    // T [rows_p][ld_sh]   compute copy, same orientation   (nullable)
-    void* shT;   // T [cols_p][ld_shT]  compute copy, transposed          (nullable)
+    void* shT;   // T [cols_p][ld_shT]  compute copy, transposed          (nullable; the engine keeps none any more)
+    const float* sumsq;  // DAE: this tensor's squared norm (g += lam * p / ||p||), nullable
     int rows, cols, ld_sh, ld_shT;
     int tile_start;  // first tile of this tensor in the launch
     int flat;        // filled by rtx_launch_adam: walked as one contiguous array in chunks of 4096 elements (see k_adam)
@@ -162,16 +160,12 @@ struct RtxAdamArgs {
     float step_size;   // lr / (1 - beta1^t)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
     float beta1, beta2, eps, weight_decay;
-    float lam;         // DAE: g += lam * p / ||p||
-    const float* sumsq;  // [n] squared norms (DAE), nullable
+    float lam;         // DAE: g += lam * p / ||p||  (per-tensor norms in t[k].sumsq)
     float grad_scale;  // multiplies g before use (1.0; data-parallel averaging hooks)
 };
 int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream);
 int rtx_launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
 int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, float* sumsq, hipStream_t stream);
-
-// out[c][r] = in[r][c], r < R, c < C (compute-copy transpose after the fused dW+Adam GEMM)
-int rtx_launch_transpose(const void* in, int ld_in, void* out, int ld_out, int R, int C, int is_bf16, hipStream_t stream);
 
 // evaluate() on the device: exact top-kmax per score row + nDCG@k / Recall@k for each cut-off in ks (host array)
 int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, const RtxCsrView& held, const int* ks, int n_k,

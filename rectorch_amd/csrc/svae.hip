@@ -729,7 +729,7 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
     a.step_size = (float)((double)step->lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
-    a.grad_scale = 1.f; a.lam = 0.f; a.sumsq = nullptr;
+    a.grad_scale = 1.f; a.lam = 0.f;
     return rtx_launch_adam(a, 0, st);
 }
 

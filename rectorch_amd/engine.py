@@ -75,6 +75,23 @@ class RowBatch:
         return int(self.rows.numel())
 
 
+def tag_rows(t, rb):
+    """Mark the dense tensor ``t`` as the image of the resident rows ``rb`` (what the device DataSampler yields).  The tag
+    carries the tensor's version counter: once the caller edits ``t`` in place (``x.clamp_``, ``x[:, cold] = 0`` ...)
+    the tag is stale and the tensor's CONTENTS are used, as the reference would (rectorch/models.py:819-822)."""
+    t._rtx_rows = rb
+    t._rtx_ver = t._version
+    return t
+
+
+def tagged_rows(t):
+    """The RowBatch ``t`` was gathered from, or None when ``t`` is not tagged or was modified since."""
+    rb = getattr(t, "_rtx_rows", None)
+    if rb is not None and getattr(t, "_rtx_ver", None) == t._version:
+        return rb
+    return None
+
+
 def _check_width(t, n_items, what):
     if n_items is not None and (t.dim() != 2 or t.shape[1] != n_items):
         raise _lib.RtxError("%s must be [batch, %d] (n_items of the network), got %s" % (what, n_items, tuple(t.shape)))
@@ -84,7 +101,7 @@ def make_batch(x, target=None, keep=None, n_items=None, n_in=None):
     """Build the C ``rtx_batch`` for ``x`` (a RowBatch, or a dense [B, n_items] device tensor, or a dense
     tensor carrying the RowBatch it was gathered from).  ``keep`` collects tensors that must outlive the call."""
     b = Batch()
-    rb = x if isinstance(x, RowBatch) else getattr(x, "_rtx_rows", None)
+    rb = x if isinstance(x, RowBatch) else tagged_rows(x)
     if rb is not None:
         b.csr = rb.tr.handle
         b.row_ids = rb.rows.data_ptr()
@@ -99,10 +116,14 @@ def make_batch(x, target=None, keep=None, n_items=None, n_in=None):
         b.x_dense = x.data_ptr()
         b.batch = x.shape[0]
     if target is not None:
-        trb = getattr(target, "_rtx_rows", None)
-        if trb is not None and rb is not None and trb.rows is rb.rows and trb.te is not None:
+        trb = None if isinstance(target, RowBatch) else tagged_rows(target)
+        if isinstance(target, RowBatch) and rb is not None and target.rows is rb.rows:
+            b.target_csr = target.tr.handle      # the (input rows, target rows) pair of a sparse sampler
+        elif trb is not None and rb is not None and trb.rows is rb.rows and trb.te is not None:
             b.target_csr = trb.te.handle
         else:
+            if isinstance(target, RowBatch):
+                target = target.tr.gather_dense(target.rows)
             _check_width(target, n_items, "the target batch")
             target = target.to(torch.float32).contiguous()
             if keep is not None:
@@ -234,6 +255,10 @@ class Engine:
                                           stream_ptr()))
 
     # ---- instrumentation --------------------------------------------------------------------------
+    def set_option(self, key, value):
+        """measurement knobs of the engine ("fuse_adam", "lse_fuse", "dw_cfg", "splitk"; include/rectorch_hip.h)"""
+        check(lib().rtx_engine_set_option(self.handle, key.encode(), int(value)))
+
     def set_timing(self, site=None, enable=True):
         check(lib().rtx_engine_set_timing(self.handle, None if site is None else site.encode(), int(enable)))
 

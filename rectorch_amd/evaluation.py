@@ -47,6 +47,9 @@ class ValidFunc():
 
 
 def _to_numpy(t):
+    from .engine import RowBatch
+    if isinstance(t, RowBatch):            # rows of a device-resident CSR (sparse samplers): densify on the device
+        return t.tr.gather_dense(t.rows).cpu().numpy()
     t = t.view(t.shape[0], -1)
     return t.cpu().numpy()
 
@@ -66,10 +69,13 @@ class _PerUserResults:
 
 def _predict_numpy(model, data_tr):
     """scores of one batch as a host array; the resident-rows shortcut of the device sampler survives the reshape"""
+    from .engine import RowBatch, tag_rows, tagged_rows
+    if isinstance(data_tr, RowBatch):
+        return model.predict(data_tr)[0].cpu().numpy()
     data_tensor = data_tr.view(data_tr.shape[0], -1)
-    rows = getattr(data_tr, "_rtx_rows", None)
+    rows = tagged_rows(data_tr)
     if rows is not None:
-        data_tensor._rtx_rows = rows
+        tag_rows(data_tensor, rows)
     return model.predict(data_tensor)[0].cpu().numpy()
 
 

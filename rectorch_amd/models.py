@@ -19,7 +19,7 @@ import torch
 import torch.optim as optim
 
 from . import _lib
-from .engine import CsrMatrix, EaseSolver, RowBatch, SvaeTarget, multinomial_loss
+from .engine import CsrMatrix, EaseSolver, RowBatch, SvaeTarget, multinomial_loss, tagged_rows
 from .evaluation import ValidFunc, evaluate
 from .samplers import DataSampler
 
@@ -307,7 +307,7 @@ class AETrainer(TorchNNTrainer):
         x_in = self.network._as_input(x)
         n = len(x_in) if isinstance(x_in, RowBatch) else x_in.shape[0]
         eng = self.network.rtx_engine(self.predict_numerics, n)
-        if not isinstance(x_in, RowBatch) and getattr(x_in, "_rtx_rows", None) is None:
+        if not isinstance(x_in, RowBatch) and tagged_rows(x_in) is None:
             # dense input: through the PyTorch-ROCm custom op (torch.ops.rectorch_hip.*, rectorch_amd/ops.py)
             from . import ops  # noqa: F401  (registers the ops)
             if self._variant == "vae":

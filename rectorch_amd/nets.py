@@ -125,8 +125,8 @@ class AE_net(nn.Module):
         self._rtx_shadow_versions[numerics] = ver
 
     def _as_input(self, x):
-        from .engine import RowBatch
-        if isinstance(x, RowBatch) or getattr(x, "_rtx_rows", None) is not None:
+        from .engine import RowBatch, tagged_rows
+        if isinstance(x, RowBatch) or tagged_rows(x) is not None:
             return x
         dev = self._device()
         return x.reshape(x.shape[0], -1).to(dev, torch.float32).contiguous()

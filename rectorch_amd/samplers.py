@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from scipy.sparse import csr_matrix, hstack
 
-from .engine import CsrMatrix, RowBatch, SvaeTarget
+from .engine import CsrMatrix, RowBatch, SvaeTarget, tag_rows
 
 __all__ = ['Sampler', 'DataSampler', 'ConditionedDataSampler', 'BalancedConditionedDataSampler',
            'EmptyConditionedDataSampler', 'SVAE_Sampler']
@@ -108,12 +108,11 @@ class DataSampler(Sampler):
             yield from self._iter_host()
             return
         for rb in self.iter_rows():
-            data_tr = self._csr_tr.gather_dense(rb.rows)
-            data_tr._rtx_rows = rb          # lets the trainer skip the dense detour when it gets this tensor back
+            # tagged: the trainer skips the dense detour when it gets this tensor back UNMODIFIED
+            data_tr = tag_rows(self._csr_tr.gather_dense(rb.rows), rb)
             data_te = None
             if self._csr_te is not None:
-                data_te = self._csr_te.gather_dense(rb.rows)
-                data_te._rtx_rows = rb
+                data_te = tag_rows(self._csr_te.gather_dense(rb.rows), rb)
             yield data_tr, data_te
 
     def _iter_host(self):
@@ -130,6 +129,15 @@ class DataSampler(Sampler):
             yield data_tr, data_te
 
 
+def _sparse_pair(data_tr, data_te):
+    """``(input rows, target rows)`` of one batch as two device-resident :class:`RowBatch` objects over the same row
+    ids -- what the ``sparse=True`` samplers yield in place of the dense ``(data, target)`` tensors.  It is a PAIR like
+    every other sampler's item: ``train_epoch`` / ``evaluate`` / ``one_plus_random`` unpack it unchanged."""
+    tr, te = CsrMatrix(data_tr), CsrMatrix(data_te)
+    rows = torch.arange(data_tr.shape[0], dtype=torch.int32, device="cuda")
+    return RowBatch(tr, te, rows), RowBatch(te, None, rows)
+
+
 class ConditionedDataSampler(Sampler):
     r"""Data sampler with conditioned filtering for :class:`rectorch_amd.models.CMultiVAE` (reference
     samplers.py:108-234).
@@ -140,8 +148,9 @@ class ConditionedDataSampler(Sampler):
     items having any condition when unconditioned); examples whose filtered target is empty are dropped.
 
     This is host-side bookkeeping, as in the reference; the batches it yields are what the MI355X engine consumes.
-    With ``sparse=True`` (not in the reference) the pair is yielded as a :class:`rectorch_amd.engine.RowBatch` of two
-    small per-batch CSR matrices uploaded to HBM, so nothing dense of width ``n_items`` crosses PCIe.
+    With ``sparse=True`` (not in the reference) the pair is yielded as two :class:`rectorch_amd.engine.RowBatch`
+    objects (input rows, target rows) over small per-batch CSR matrices uploaded to HBM, so nothing dense of width
+    ``n_items`` crosses PCIe.
 
     Parameters
     ----------
@@ -221,8 +230,7 @@ class ConditionedDataSampler(Sampler):
 
     def _emit(self, data_tr, data_te):
         if self.sparse:
-            tr, te = CsrMatrix(data_tr), CsrMatrix(data_te)
-            return RowBatch(tr, te, torch.arange(data_tr.shape[0], dtype=torch.int32, device="cuda"))
+            return _sparse_pair(data_tr, data_te)
         return torch.FloatTensor(data_tr.toarray()), torch.FloatTensor(data_te.toarray())
 
     def __iter__(self):
@@ -326,8 +334,7 @@ class EmptyConditionedDataSampler(Sampler):
                 self.sparse_data_te = self.sparse_data_tr
             data_te = self.sparse_data_te[rows]
             if self.sparse:
-                yield RowBatch(CsrMatrix(data_tr), CsrMatrix(data_te),
-                               torch.arange(len(rows), dtype=torch.int32, device="cuda"))
+                yield _sparse_pair(data_tr, data_te)
             else:
                 yield torch.FloatTensor(data_tr.toarray()), torch.FloatTensor(data_te.toarray())
 

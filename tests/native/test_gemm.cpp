@@ -4,6 +4,8 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
 #include <vector>
 
 void rtx_set_error(const char* fmt, ...);
@@ -133,6 +135,373 @@ static void perf_case(const char* name, int M, int N, int K, int splits, int epi
     hipFree(A); hipFree(B); hipFree(C);
 }
 
+
+// ---- ds_read_b64_tr_b16 semantics probe: with linear per-lane addresses (lane * 8 bytes) lane l, element j must receive
+//      lds[(l & 15) + j * 16 + (l >> 4) * 64] (16-bit elements) -- what gemm_dma.hip / dw_adam.hip are built on ------------------
+__global__ void k_tr_probe(unsigned short* out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short lds[256];
+    for (int i = threadIdx.x; i < 256; i += 64) lds[i] = (unsigned short)i;
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    u32x2 v;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)lds + threadIdx.x * 8;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    out[threadIdx.x * 4 + 0] = (unsigned short)(v[0] & 0xffff);
+    out[threadIdx.x * 4 + 1] = (unsigned short)(v[0] >> 16);
+    out[threadIdx.x * 4 + 2] = (unsigned short)(v[1] & 0xffff);
+    out[threadIdx.x * 4 + 3] = (unsigned short)(v[1] >> 16);
+}
+
+static int tr_probe()
+{
+    unsigned short* d;
+    CK(hipMalloc(&d, 256 * 2));
+    hipLaunchKernelGGL(k_tr_probe, dim3(1), dim3(64), 0, 0, d);
+    CK(hipDeviceSynchronize());
+    unsigned short h[256];
+    CK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 4; ++j) bad += h[l * 4 + j] != (unsigned short)((l & 15) + j * 16 + (l >> 4) * 64);
+    printf("[tr-probe] ds_read_b64_tr_b16: %s\n", bad ? "UNEXPECTED MAPPING" : "ok");
+    if (bad) {
+        for (int l = 0; l < 64; ++l) printf("   lane %2d: %3d %3d %3d %3d\n", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3]);
+    }
+    hipFree(d);
+    return bad != 0;
+}
+
+// ---- LDS-DMA GEMM (gemm_dma.hip): NT / NN, store (split-K) and bias (+ log-sum-exp partials) epilogues -------------------------
+static int run_dma_case(const char* name, int form, int cfg, int M, int N, int K, int splits, int epi, int M_real, int N_real, int odd_ld)
+{
+    std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+    std::vector<double> dA((size_t)M * K), dB((size_t)N * K);   // dB[n][k] whatever the storage form
+    for (size_t i = 0; i < hA.size(); ++i) { hA[i] = f32_to_bf16(frand()); dA[i] = bf16_to_f32(hA[i]); }
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const bf16_t v = f32_to_bf16(frand() * 0.5f + 0.1f);
+            dB[(size_t)n * K + k] = bf16_to_f32(v);
+            if (form == RTX_FORM_NT) hB[(size_t)n * K + k] = v; else hB[(size_t)k * N + n] = v;
+        }
+    std::vector<float> hbias(N);
+    for (int i = 0; i < N; ++i) hbias[i] = frand();
+    const long ldc = (epi == RTX_EPI_STORE) ? N : (odd_ld ? N_real : N);
+    const size_t csz = (epi == RTX_EPI_STORE) ? (size_t)splits * M * N : (size_t)M_real * ldc;
+    bf16_t *A, *B;
+    float *C, *bias;
+    float2* part;
+    const int strips = N / 64;
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2));
+    CK(hipMalloc(&C, csz * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&part, (size_t)M * strips * 8));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(bias, hbias.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0xff, csz * 4));
+    CK(hipMemset(part, 0xff, (size_t)M * strips * 8));
+    RtxGemm g = {};
+    g.form = form; g.A = A; g.B = B; g.lda = K; g.ldb = (form == RTX_FORM_NT) ? K : N;
+    int bm, bn;
+    rtx_gemm_dma_tile_dims(cfg, &bm, &bn);
+    g.tile_shape = cfg; g.m_tiles = M / bm; g.n_tiles = N / bn; g.k_slices = K / 64; g.splits = splits;
+    g.C = C; g.ldc = ldc; g.slab_stride = (long)M * N; g.bias = bias; g.M_real = M_real; g.N_real = N_real;
+    if (epi == RTX_EPI_BIAS_ROWS) { g.lse_part = part; g.lse_ld = strips; }
+    int rc = rtx_gemm_dma_launch(g, epi, 0);
+    if (rc) { printf("[dma %s] launch failed rc=%d: %s\n", name, rc, rtx_last_error_str()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<float> hC(csz);
+    std::vector<float2> hp((size_t)M * strips);
+    CK(hipMemcpy(hC.data(), C, csz * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost));
+    double max_err = 0, max_lse = 0;
+    long bad = 0;
+    int printed = 0;
+    const int Mc = (epi == RTX_EPI_STORE) ? M : M_real, Nc = (epi == RTX_EPI_STORE) ? N : N_real;
+    std::vector<double> refrow(N);
+    for (int m = 0; m < Mc; ++m) {
+        for (int n = 0; n < Nc; ++n) {
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += dA[(size_t)m * K + k] * dB[(size_t)n * K + k];
+            double got;
+            if (epi == RTX_EPI_STORE) {
+                got = 0;
+                for (int s2 = 0; s2 < splits; ++s2) got += hC[(size_t)s2 * M * N + (size_t)m * N + n];
+            } else {
+                ref += hbias[n];
+                got = hC[(size_t)m * ldc + n];
+            }
+            refrow[n] = ref;
+            const double err = fabs(got - ref);
+            if (!(err <= 1e-4 * sqrt((double)K))) {
+                ++bad;
+                if (printed++ < 5) printf("   mismatch (%d,%d): got %.6f ref %.6f\n", m, n, got, ref);
+            }
+            max_err = std::max(max_err, err);
+        }
+        if (epi == RTX_EPI_BIAS_ROWS) {   // row log-sum-exp from the strip partials
+            double mx = -1e300;
+            for (int n = 0; n < Nc; ++n) mx = std::max(mx, refrow[n]);
+            double se = 0;
+            for (int n = 0; n < Nc; ++n) se += exp(refrow[n] - mx);
+            const double ref_lse = mx + log(se);
+            double gm = -1e300;
+            for (int q = 0; q < strips; ++q) if (hp[(size_t)m * strips + q].y > 0.f) gm = std::max(gm, (double)hp[(size_t)m * strips + q].x);
+            double gs = 0;
+            for (int q = 0; q < strips; ++q) if (hp[(size_t)m * strips + q].y > 0.f) gs += hp[(size_t)m * strips + q].y * exp(hp[(size_t)m * strips + q].x - gm);
+            const double e2 = fabs(gm + log(gs) - ref_lse);
+            max_lse = std::max(max_lse, e2);
+            if (!(e2 <= 1e-4 * sqrt((double)K))) { ++bad; if (printed++ < 5) printf("   lse mismatch row %d: got %.6f ref %.6f\n", m, gm + log(gs), ref_lse); }
+        }
+    }
+    // BIAS: nothing may be written outside the valid block
+    if (epi == RTX_EPI_BIAS_ROWS && !odd_ld) {
+        for (int m = 0; m < M_real; ++m)
+            for (int n = N_real; n < N; ++n) {
+                uint32_t u; memcpy(&u, &hC[(size_t)m * ldc + n], 4);
+                if (u != 0xffffffffu) { ++bad; if (printed++ < 5) printf("   pad written at (%d,%d)\n", m, n); }
+            }
+    }
+    printf("[dma %s] %s cfg%d M=%d N=%d K=%d splits=%d epi=%d  max_err=%.3e lse_err=%.3e bad=%ld -> %s\n", name, form == RTX_FORM_NT ? "NT" : "NN", cfg,
+           M, N, K, splits, epi, max_err, max_lse, bad, bad ? "FAIL" : "ok");
+    hipFree(A); hipFree(B); hipFree(C); hipFree(bias); hipFree(part);
+    return bad != 0;
+}
+
+static void perf_dma(const char* name, int form, int cfg, int M, int N, int K, int splits, int epi)
+{
+    bf16_t *A, *B;
+    float *C, *bias;
+    float2* part;
+    std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto& v : hA) v = f32_to_bf16(frand());
+    for (auto& v : hB) v = f32_to_bf16(frand());
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2));
+    CK(hipMalloc(&C, (size_t)splits * M * N * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&part, (size_t)M * (N / 64) * 8));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, N * 4));
+    RtxGemm g = {};
+    g.form = form; g.A = A; g.B = B; g.lda = K; g.ldb = (form == RTX_FORM_NT) ? K : N;
+    int bm, bn;
+    rtx_gemm_dma_tile_dims(cfg, &bm, &bn);
+    g.tile_shape = cfg; g.m_tiles = M / bm; g.n_tiles = N / bn; g.k_slices = K / 64; g.splits = splits;
+    g.C = C; g.ldc = N; g.slab_stride = (long)M * N; g.bias = bias; g.M_real = M - 12; g.N_real = N - 116;
+    if (epi == RTX_EPI_BIAS_ROWS) { g.lse_part = part; g.lse_ld = N / 64; }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) rtx_gemm_dma_launch(g, epi, 0);
+    CK(hipEventRecord(e0, 0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) rtx_gemm_dma_launch(g, epi, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1000.0 / it;
+    printf("[perf dma %s] %s cfg%d M=%d N=%d K=%d splits=%d epi=%d: %.1f us  %.1f TFLOP/s\n", name, form == RTX_FORM_NT ? "NT" : "NN", cfg, M, N, K, splits, epi,
+           us, 2.0 * M * N * K / us * 1e-6);
+    hipFree(A); hipFree(B); hipFree(C); hipFree(bias); hipFree(part);
+}
+
+// ---- weight gradient in TN form, fused with Adam (dw_adam.hip) -------------------------------------------------------------------
+static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_real, int K_real, float lam, float wd, int keep)
+{
+    const int Mp = rtx_pad(M_real), Np = rtx_pad(N_real), Kp = rtx_pad_batch(K_real);
+    std::vector<bf16_t> hD((size_t)Kp * Mp, 0), hX((size_t)Kp * Np, 0);
+    for (int k = 0; k < K_real; ++k) {
+        for (int m = 0; m < Mp; ++m) hD[(size_t)k * Mp + m] = f32_to_bf16(m < M_real ? frand() * 0.05f : frand());   // pad columns: garbage (must not leak)
+        for (int n = 0; n < N_real; ++n) hX[(size_t)k * Np + n] = f32_to_bf16(frand());
+        hX[(size_t)k * Np + N_real] = f32_to_bf16(1.f);
+    }
+    const size_t P = (size_t)M_real * N_real;
+    std::vector<float> hp(P), hm(P), hv(P);
+    for (size_t i = 0; i < P; ++i) { hp[i] = frand(); hm[i] = frand() * 0.01f; hv[i] = fabsf(frand()) * 1e-4f; }
+    bf16_t *D, *X, *sh, *g16;
+    float *p, *m, *v, *gk, *gb, *sumsq;
+    CK(hipMalloc(&D, hD.size() * 2)); CK(hipMalloc(&X, hX.size() * 2));
+    CK(hipMalloc(&p, P * 4)); CK(hipMalloc(&m, P * 4)); CK(hipMalloc(&v, P * 4)); CK(hipMalloc(&gk, P * 4)); CK(hipMalloc(&g16, P * 2));
+    CK(hipMalloc(&gb, Mp * 4)); CK(hipMalloc(&sh, (size_t)Mp * Np * 2)); CK(hipMalloc(&sumsq, 4));
+    CK(hipMemcpy(D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(p, hp.data(), P * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(m, hm.data(), P * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(v, hv.data(), P * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(gk, 0xff, P * 4)); CK(hipMemset(g16, 0xff, P * 2)); CK(hipMemset(gb, 0xff, Mp * 4)); CK(hipMemset(sh, 0, (size_t)Mp * Np * 2));
+    double ss = 0;
+    for (float w : hp) ss += (double)w * w;
+    const float hss = (float)ss;
+    CK(hipMemcpy(sumsq, &hss, 4, hipMemcpyHostToDevice));
+    RtxDw d = {};
+    d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
+    d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+    d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
+    const float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const int step = 3;
+    const float step_size = (float)(lr / (1.0 - pow((double)b1, step))), bc2 = (float)sqrt(1.0 - pow((double)b2, step));
+    if (epi == RTX_DW_ADAM) {
+        d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.gkeep = keep ? gk : nullptr; d.adam.sh = sh; d.adam.ld_sh = Np;
+        d.adam.step_size = step_size; d.adam.bc2_sqrt = bc2; d.adam.beta1 = b1; d.adam.beta2 = b2; d.adam.eps = eps; d.adam.weight_decay = wd;
+        d.adam.lam = lam; d.adam.sumsq = lam != 0.f ? sumsq : nullptr;
+    } else {
+        d.gW = gk; d.g16 = keep ? g16 : nullptr;
+    }
+    int rc = rtx_dw_launch(d, epi, cfg, 0);
+    if (rc) { printf("[dw %s] launch failed rc=%d: %s\n", name, rc, rtx_last_error_str()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<float> gp(P), gm(P), gv(P), gg(P), ggb(Mp);
+    std::vector<bf16_t> gsh((size_t)Mp * Np), gg16(P);
+    CK(hipMemcpy(gp.data(), p, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gm.data(), m, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gv.data(), v, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gg.data(), gk, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ggb.data(), gb, Mp * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gsh.data(), sh, gsh.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gg16.data(), g16, P * 2, hipMemcpyDeviceToHost));
+    long bad = 0;
+    int printed = 0;
+    double e_g = 0, e_p = 0, e_m = 0, e_v = 0;
+    const float reg = lam != 0.f ? lam / sqrtf(hss) : 0.f;
+    for (int r = 0; r < M_real; ++r) {
+        for (int c = 0; c <= N_real; ++c) {
+            double ref = 0;
+            for (int k = 0; k < K_real; ++k) ref += (double)bf16_to_f32(hD[(size_t)k * Mp + r]) * bf16_to_f32(hX[(size_t)k * Np + c]);
+            if (c == N_real) {
+                const double e = fabs(ggb[r] - ref);
+                if (!(e <= 1e-4 * sqrt((double)K_real))) { ++bad; if (printed++ < 5) printf("   bias grad row %d: got %.6f ref %.6f\n", r, ggb[r], ref); }
+                continue;
+            }
+            const size_t o = (size_t)r * N_real + c;
+            const bool have_g = (epi == RTX_DW_GRAD) || keep;
+            if (have_g) {
+                const double e = fabs(gg[o] - ref);
+                e_g = std::max(e_g, e);
+                if (!(e <= 1e-4 * sqrt((double)K_real))) { ++bad; if (printed++ < 5) printf("   grad (%d,%d): got %.6f ref %.6f\n", r, c, gg[o], ref); }
+            }
+            if (epi == RTX_DW_GRAD) {
+                if (keep && gg16[o] != f32_to_bf16(gg[o])) { ++bad; if (printed++ < 5) printf("   bf16 grad image (%d,%d) differs\n", r, c); }
+                continue;
+            }
+            // Adam with the DEVICE's f32 gradient when it is available (isolates the optimizer arithmetic), else the reference
+            float g0 = have_g ? gg[o] : (float)ref;
+            float g1 = g0 + reg * hp[o];
+            if (wd != 0.f) g1 += wd * hp[o];
+            const float m1 = hm[o] + (g1 - hm[o]) * (1.f - b1);
+            const float v1 = hv[o] * b2 + (1.f - b2) * g1 * g1;
+            const float denom = sqrtf(v1) / bc2 + eps;
+            const float p1 = hp[o] - step_size * (m1 / denom);
+            const double tol = have_g ? 2e-6 : 2e-3;
+            e_p = std::max(e_p, (double)fabs(gp[o] - p1)); e_m = std::max(e_m, (double)fabs(gm[o] - m1)); e_v = std::max(e_v, (double)fabs(gv[o] - v1));
+            if (!(fabs(gp[o] - p1) <= tol && fabs(gm[o] - m1) <= tol && fabs(gv[o] - v1) <= tol)) {
+                ++bad;
+                if (printed++ < 5) printf("   adam (%d,%d): p %.7f/%.7f m %.7f/%.7f v %.3e/%.3e\n", r, c, gp[o], p1, gm[o], m1, gv[o], v1);
+            }
+            if (gsh[(size_t)r * Np + c] != f32_to_bf16(gp[o])) { ++bad; if (printed++ < 5) printf("   compute copy (%d,%d) is not bf16(p)\n", r, c); }
+        }
+    }
+    if (epi == RTX_DW_ADAM)   // the padding of the compute copy stays zero
+        for (int r = 0; r < Mp; ++r)
+            for (int c = 0; c < Np; ++c)
+                if ((r >= M_real || c >= N_real) && gsh[(size_t)r * Np + c] != 0) { ++bad; if (printed++ < 5) printf("   compute-copy pad (%d,%d) written\n", r, c); }
+    printf("[dw %s] cfg%d epi=%d %dx%d K=%d lam=%.2f wd=%.3f keep=%d  err g=%.2e p=%.2e m=%.2e v=%.2e bad=%ld -> %s\n", name, cfg, epi, M_real, N_real, K_real,
+           lam, wd, keep, e_g, e_p, e_m, e_v, bad, bad ? "FAIL" : "ok");
+    hipFree(D); hipFree(X); hipFree(p); hipFree(m); hipFree(v); hipFree(gk); hipFree(g16); hipFree(gb); hipFree(sh); hipFree(sumsq);
+    return bad != 0;
+}
+
+static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, int K_real)
+{
+    const int Mp = rtx_pad(M_real), Np = rtx_pad(N_real), Kp = rtx_pad_batch(K_real);
+    std::vector<bf16_t> hD((size_t)Kp * Mp), hX((size_t)Kp * Np);
+    for (auto& x : hD) x = f32_to_bf16(frand() * 0.01f);
+    for (auto& x : hX) x = f32_to_bf16(frand());
+    const size_t P = (size_t)M_real * N_real;
+    bf16_t *D, *X, *sh;
+    float *p, *m, *v, *gb, *gW;
+    CK(hipMalloc(&D, hD.size() * 2)); CK(hipMalloc(&X, hX.size() * 2));
+    CK(hipMalloc(&p, P * 4)); CK(hipMalloc(&m, P * 4)); CK(hipMalloc(&v, P * 4)); CK(hipMalloc(&gW, P * 4));
+    CK(hipMalloc(&gb, Mp * 4)); CK(hipMalloc(&sh, (size_t)Mp * Np * 2));
+    CK(hipMemcpy(D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(p, 0, P * 4)); CK(hipMemset(m, 0, P * 4)); CK(hipMemset(v, 0, P * 4));
+    RtxDw d = {};
+    d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
+    d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+    d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
+    d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.sh = sh; d.adam.ld_sh = Np;
+    d.adam.step_size = 1e-3f; d.adam.bc2_sqrt = 0.05f; d.adam.beta1 = 0.9f; d.adam.beta2 = 0.999f; d.adam.eps = 1e-8f;
+    d.gW = gW;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) rtx_dw_launch(d, epi, cfg, 0);
+    CK(hipEventRecord(e0, 0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) rtx_dw_launch(d, epi, cfg, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1000.0 / it;
+    const double bytes = (epi == RTX_DW_ADAM ? 26.0 : 4.0) * P + 2.0 * Kp * (Mp + Np);
+    printf("[perf dw %s] cfg%d epi=%d %dx%d K=%d: %.1f us  %.2f TB/s (p,m,v r+w + compute copy + operands)  %.1f TFLOP/s\n", name, cfg, epi, M_real, N_real,
+           K_real, us, bytes / us * 1e-6, 2.0 * P * Kp / us * 1e-6);
+    hipFree(D); hipFree(X); hipFree(p); hipFree(m); hipFree(v); hipFree(gW); hipFree(gb); hipFree(sh);
+}
+
+// ---- float32 GEMM with a K-major operand (gemm_f32.hip) ------------------------------------------------------------------------------
+static int run_f32_case(const char* name, int form, int M, int N, int K, int splits, int epi, int M_real, int N_real)
+{
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    std::vector<double> dA((size_t)M * K), dB((size_t)N * K);   // d*[row][k]
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) {
+            const float v = frand();
+            dA[(size_t)m * K + k] = v;
+            if (form == RTX_FORM_TN) hA[(size_t)k * M + m] = v; else hA[(size_t)m * K + k] = v;
+        }
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float v = frand() * 0.5f + 0.1f;
+            dB[(size_t)n * K + k] = v;
+            hB[(size_t)k * N + n] = v;
+        }
+    const size_t csz = (epi == RTX_EPI_STORE) ? (size_t)splits * M * N : (size_t)M_real * N_real;
+    float *A, *B, *C, *gb;
+    CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&B, hB.size() * 4)); CK(hipMalloc(&C, csz * 4)); CK(hipMalloc(&gb, M * 4));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0xff, csz * 4)); CK(hipMemset(gb, 0xff, M * 4));
+    RtxGemm g = {};
+    g.form = form; g.A = A; g.B = B; g.lda = (form == RTX_FORM_TN) ? M : K; g.ldb = N;
+    g.m_tiles = M / 128; g.n_tiles = N / 128; g.k_slices = K / 32; g.splits = splits;
+    g.C = C; g.ldc = N; g.slab_stride = (long)M * N; g.gbias = gb; g.M_real = M_real; g.N_real = N_real;
+    int rc = rtx_gemm_f32_km_launch(g, epi, 0);
+    if (rc) { printf("[f32 %s] launch failed rc=%d: %s\n", name, rc, rtx_last_error_str()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<float> hC(csz), hgb(M);
+    CK(hipMemcpy(hC.data(), C, csz * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hgb.data(), gb, M * 4, hipMemcpyDeviceToHost));
+    double max_err = 0;
+    long bad = 0;
+    int printed = 0;
+    const int Mc = (epi == RTX_EPI_STORE) ? M : M_real, Nc = (epi == RTX_EPI_STORE) ? N : N_real + 1;
+    for (int m = 0; m < Mc; ++m)
+        for (int n = 0; n < Nc; ++n) {
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += dA[(size_t)m * K + k] * dB[(size_t)n * K + k];
+            double got;
+            if (epi == RTX_EPI_STORE) {
+                got = 0;
+                for (int s2 = 0; s2 < splits; ++s2) got += hC[(size_t)s2 * M * N + (size_t)m * N + n];
+            } else {
+                got = (n < N_real) ? hC[(size_t)m * N_real + n] : hgb[m];
+            }
+            const double err = fabs(got - ref);
+            if (!(err <= 2e-6 * sqrt((double)K) * 4)) { ++bad; if (printed++ < 5) printf("   mismatch (%d,%d): got %.7f ref %.7f\n", m, n, got, ref); }
+            max_err = std::max(max_err, err);
+        }
+    printf("[f32 %s] %s M=%d N=%d K=%d splits=%d epi=%d  max_err=%.3e bad=%ld -> %s\n", name, form == RTX_FORM_TN ? "TN" : "NN", M, N, K, splits, epi, max_err, bad,
+           bad ? "FAIL" : "ok");
+    hipFree(A); hipFree(B); hipFree(C); hipFree(gb);
+    return bad != 0;
+}
+
 int main(int argc, char** argv)
 {
     int fails = 0;
@@ -153,7 +522,53 @@ int main(int argc, char** argv)
         fails += run_case<float>("bias", 512, 768, 320, 1, RTX_EPI_BIAS_ROWS, 410, 701, shape);
         fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
     }
+    fails += tr_probe();
+    for (int cfg = 0; cfg < 3; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages)
+        for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
+            fails += run_dma_case("store", form, cfg, 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, 0);
+            fails += run_dma_case("splitk3", form, cfg, 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, 0);
+            fails += run_dma_case("splitk11", form, cfg, 512, 512, 1408, 11, RTX_EPI_STORE, 512, 512, 0);
+            fails += run_dma_case("k1", form, cfg, 512, 256, 64, 1, RTX_EPI_STORE, 512, 256, 0);
+            fails += run_dma_case("bias", form, cfg, 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, 0);
+            fails += run_dma_case("bias-oddld", form, cfg, 512, 768, 128, 1, RTX_EPI_BIAS_ROWS, 500, 703, 1);
+        }
+        fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
+    }
+    for (int cfg = 0; cfg < 3; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages)
+        fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
+        fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
+        fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
+        fails += run_dw_case("adam-tall", cfg, RTX_DW_ADAM, 1000, 24, 128, 0.f, 0.f, 1);
+        fails += run_dw_case("grad", cfg, RTX_DW_GRAD, 300, 200, 250, 0.f, 0.f, 1);
+        fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
+        fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
+    }
+    for (int form : {RTX_FORM_NN, RTX_FORM_TN}) {
+        fails += run_f32_case("store", form, 256, 384, 352, 1, RTX_EPI_STORE, 256, 384);
+        fails += run_f32_case("splitk3", form, 256, 384, 352, 3, RTX_EPI_STORE, 256, 384);
+        fails += run_f32_case("k1", form, 128, 128, 32, 1, RTX_EPI_STORE, 128, 128);
+        fails += run_f32_case("grad", form, 384, 256, 256, 1, RTX_EPI_GRAD, 300, 200);
+    }
     if (argc > 1) {
+        // the step's big contractions on the LDS-DMA kernels: logits, fwd-1 / dH3 (split-K), fused dW + Adam
+        perf_dma("logits", RTX_FORM_NT, RTX_DMA_512x128, 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS);
+        perf_dma("logits", RTX_FORM_NT, RTX_DMA_128x128, 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS);
+        perf_dma("logits-store", RTX_FORM_NT, RTX_DMA_512x128, 512, 20224, 640, 1, RTX_EPI_STORE);
+        for (int sp : {23, 32, 46}) perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_512x128, 512, 640, 20224, sp, RTX_EPI_STORE);
+        for (int sp : {23, 32, 46}) perf_dma("dH3", RTX_FORM_NN, RTX_DMA_512x128, 512, 640, 20224, sp, RTX_EPI_STORE);
+        perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_128x128, 512, 640, 20224, 12, RTX_EPI_STORE);
+        perf_dma("hidden", RTX_FORM_NT, RTX_DMA_128x128, 512, 512, 640, 5, RTX_EPI_STORE);
+        perf_dma("hidden", RTX_FORM_NT, RTX_DMA_128x128, 512, 512, 640, 1, RTX_EPI_STORE);
+        perf_dma("hidden", RTX_FORM_NN, RTX_DMA_128x128, 512, 640, 512, 4, RTX_EPI_STORE);
+        perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+        perf_dma("sq4k", RTX_FORM_NN, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+        perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_512x128, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+        for (int cfg = 0; cfg < 3; ++cfg) {
+            perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500);
+            perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500);
+            perf_dw("dW4 grad", cfg, RTX_DW_GRAD, 20108, 600, 500);
+        }
+        perf_dw("dW-hidden+adam", 0, RTX_DW_ADAM, 400, 600, 500);
         // ml-20m step shapes: fwd-1 / dH3 (skinny, split-K), logits, dW4 / dW1
         perf_case<bf16_t>("fwd1", 512, 640, 20224, 24, RTX_EPI_STORE, 0);
         for (int s : {8, 16, 24, 32}) perf_case<bf16_t>("fwd1", 512, 640, 20224, s, RTX_EPI_STORE, 1);

@@ -7,6 +7,7 @@ gradients 2e-4, parameters after Adam 2e-6 absolute.  bf16 mode: operands rounde
 f32 accumulation -> logits ~1e-2 relative; gated by nDCG@100 / Recall@50 parity instead.
 """
 import os
+import random
 import subprocess
 import tempfile
 
@@ -758,13 +759,74 @@ def test_cmvae_sparse_sampler_batches_equal_dense_batches():
         sampler = ConditionedDataSampler(iid2cids, C_, tr, None, batch_size=16, shuffle=False, sparse=sparse)
         out = []
         for item in sampler:
-            if sparse:
-                out.append(model._fused_step(item, None, want_loss=True))
-            else:
-                out.append(model.train_batch(*item))
+            data, gt = item                    # every sampler yields a PAIR, the sparse form included
+            out.append(model.train_batch(data, gt))
         losses[sparse] = out
     assert len(losses[True]) == len(losses[False]) > 3
     np.testing.assert_allclose(losses[True], losses[False], rtol=1e-6)
+
+
+def test_cmvae_sparse_samplers_through_the_public_consumers():
+    """train() / evaluate() / one_plus_random() unpack ``(data, target)`` from the sparse=True samplers like from the
+    dense ones and give the same numbers (reference consumers: models.py:401-422, evaluation.py:100-103, 157-161)"""
+    from rectorch_amd.samplers import ConditionedDataSampler, EmptyConditionedDataSampler
+    from rectorch_amd.evaluation import evaluate, one_plus_random
+    from rectorch_amd.utils.hashinit import hash_state_dict
+    rng = np.random.RandomState(5)
+    U, I, C_, H, L = 48, 96, 3, 24, 8
+    tr = csr_matrix((rng.rand(U, I) < 0.15).astype(np.float32))
+    tr = csr_matrix(tr + csr_matrix((np.ones(U), (np.arange(U), np.arange(U) % I)), shape=(U, I)))
+    tr.data[:] = 1.0
+    te = csr_matrix((rng.rand(U, I) < 0.1).astype(np.float32))
+    te = csr_matrix(te + csr_matrix((np.ones(U), (np.arange(U), (np.arange(U) * 5 + 1) % I)), shape=(U, I)))
+    te.data[:] = 1.0
+    iid2cids = {i: sorted({int(i % C_), int((i * 7) % C_)}) for i in range(I)}
+    sd = hash_state_dict([I + C_, H, L], [L, H, I], "vae", 5, 1.0)
+    res = {}
+    for sparse in (False, True):
+        torch.manual_seed(7)
+        net, model = make_cvae(C_, [I, H, L], [L, H, I], 0.0, sd, beta=0.1, numerics="fp32")
+        train_s = ConditionedDataSampler(iid2cids, C_, tr, None, batch_size=16, shuffle=False, sparse=sparse)
+        valid_s = EmptyConditionedDataSampler(C_, tr, te, batch_size=16, shuffle=False, sparse=sparse)
+        model.train(train_s, valid_s, "ndcg@10", num_epochs=2, best_path=os.path.join(tempfile.gettempdir(), "cmvae_sparse_%d.pth" % sparse),
+                    verbose=1)
+        ev = evaluate(model, valid_s, ["ndcg@10", "recall@5"])
+        random.seed(3)
+        opr = one_plus_random(model, valid_s, ["hit@3"], r=20)
+        res[sparse] = (ev, opr, [p.detach().cpu().numpy().copy() for p in net.parameters()])
+    for k in res[False][0]:
+        assert res[True][0][k].shape == (U,)
+        np.testing.assert_allclose(res[True][0][k], res[False][0][k], rtol=1e-6, atol=1e-7)
+    for k in res[False][1]:
+        np.testing.assert_allclose(res[True][1][k], res[False][1][k], rtol=1e-6, atol=1e-7)
+    for a, b in zip(res[True][2], res[False][2]):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_resident_sampler_tensor_edited_in_place_is_honoured():
+    """a tensor yielded by the device DataSampler carries its CSR rows as a shortcut; once the caller edits the tensor in
+    place the shortcut is stale and the CONTENTS must be used (reference models.py:619-624 uses x itself)"""
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.utils.hashinit import hash_state_dict
+    rng = np.random.RandomState(11)
+    U, I, H, L = 20, 130, 24, 8
+    X = csr_matrix((rng.rand(U, I) < 0.2).astype(np.float32))
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 3, 1.0)
+    net, model = make_vae([I, H, L], [L, H, I], 0.0, sd, beta=0.1)
+    smp = DataSampler(X, None, batch_size=U, shuffle=False)
+    x, _ = next(iter(smp))
+    p0 = model.predict(x)[0].cpu().numpy()
+    dense = torch.from_numpy(X.toarray()).cuda()
+    np.testing.assert_array_equal(np.isneginf(p0), X.toarray() != 0)
+    x[:, :40] = 0                                   # in-place edit: cold-start the first 40 items
+    dense[:, :40] = 0
+    p1 = model.predict(x)[0].cpu().numpy()
+    p2 = model.predict(dense)[0].cpu().numpy()
+    np.testing.assert_array_equal(np.isneginf(p1), dense.cpu().numpy() != 0)
+    fin = np.isfinite(p2)
+    np.testing.assert_allclose(p1[fin], p2[fin], rtol=1e-6, atol=1e-7)
+    assert not np.allclose(p0[:, 60:][np.isfinite(p0[:, 60:]) & np.isfinite(p1[:, 60:])],
+                           p1[:, 60:][np.isfinite(p0[:, 60:]) & np.isfinite(p1[:, 60:])])
 
 
 def test_dp_path_world1_rccl():
