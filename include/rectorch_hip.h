@@ -82,6 +82,9 @@ typedef struct {
  * kernel (dw_adam.hip), so those gradients are never written to HBM; set this bit to ALSO store them in the bound
  * gradient buffers (p.grad in the Python mirror).  float32 numerics and rtx_engine_loss_grads always store them. */
 #define RTX_STEP_KEEP_GRADS 1
+/* Mult-DAE under data parallelism: the regulariser lam * sum ||W||_2 is the same on every rank, so only ONE rank may add
+ * it to the loss it reports before the ranks' losses are summed; the others set this bit (the update itself is unchanged) */
+#define RTX_STEP_NO_REG_IN_LOSS 2
 
 /* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
  * have been enqueued; layers complete in reverse order (last decoder layer first).  A data-parallel
@@ -140,6 +143,15 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream);
  * of the float32 gradient buffers (bf16 gradient exchange halves the bytes on xGMI and the Adam read). */
 int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t layer_lo, int32_t layer_hi,
                                  const uint16_t* const* grads_bf16, void* stream);
+/* Sharded optimizer for data parallelism (reduce-scatter -> Adam on the local rows -> all-gather of the compute copy):
+ * the update of rows [row_lo, row_hi) of layer `layer`'s weight matrix (row_hi may reach into the row padding) and,
+ * with with_bias, of its whole (replicated) bias.  w_grad_bf16 / b_grad_bf16 (nullable): bf16 images of the reduced
+ * gradients of the weight matrix (element 0 = row 0) and of the bias, read instead of the bound float32 buffers. */
+int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t layer, int32_t row_lo, int32_t row_hi,
+                               int32_t with_bias, const uint16_t* w_grad_bf16, const uint16_t* b_grad_bf16, void* stream);
+/* the compute copy of layer `layer`'s weight matrix in HBM: [padded_rows][ld] elements of elem_bytes bytes (bf16 or
+ * float32), padded_rows a multiple of 128; valid until the next rtx_engine_train_step (which may swap buffers) */
+int rtx_engine_shadow_region(rtx_engine* e, int32_t layer, void** base, int32_t* padded_rows, int32_t* ld, int32_t* elem_bytes);
 /* float32 -> bfloat16 (round to nearest even) of n contiguous elements: stages a gradient bucket for a bf16 all-reduce */
 int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* both of the above: one full train_batch */
@@ -215,9 +227,11 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
                         const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream);
 
 /* measurement knobs of one engine (the defaults are the shipped configuration): key "fuse_adam" (0/1, bf16 step:
- * Adam inside the weight-gradient kernels), "lse_fuse" (0/1: log-sum-exp partials from the logits GEMM epilogue),
- * "dw_cfg" (0..2: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs,
- * 0 = automatic).  Replaces round 1's RTX_* environment switches. */
+ * Adam inside the weight-gradient kernels), "two_stream" (0/1: those kernels on a second stream beside the
+ * data-gradient chain), "lse_fuse" (0/1: log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the
+ * big NT contractions on the register-staged GEMM instead of the LDS-DMA one), "dw_cfg" (0..2: tile configuration of
+ * the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic).  Replaces round 1's
+ * RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */

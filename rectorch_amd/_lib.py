@@ -16,6 +16,7 @@ MAX_LAYERS = 8
 RTX_VAE, RTX_DAE = 0, 1
 RTX_FP32, RTX_BF16 = 0, 1
 RTX_STEP_KEEP_GRADS = 1
+RTX_STEP_NO_REG_IN_LOSS = 2
 NUMERICS = {"fp32": RTX_FP32, "bf16": RTX_BF16}
 
 
@@ -73,6 +74,8 @@ SIGNATURES = {
     "rtx_engine_loss_grads": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, LAYER_CB, _P, _P]),
     "rtx_engine_apply_adam": (C.c_int, [_P, C.POINTER(Step), _P]),
     "rtx_engine_apply_adam_layers": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, _P, _P]),
+    "rtx_engine_apply_adam_rows": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rtx_engine_shadow_region": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),

@@ -207,7 +207,29 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
         const dw_f32x4 g4 = *(const dw_f32x4*)(tile + lr * 128 + col4);
         if (row >= p.M_real) continue;
         // the bias gradient is the column just past the real ones (ones-column of the activations)
-        if (p.gbias && p.N_real >= col && p.N_real < col + 4) p.gbias[row] = g4[p.N_real - col];
+        if (p.N_real >= col && p.N_real < col + 4) {
+            const float gb = g4[p.N_real - col];
+            if (p.gbias) p.gbias[row] = gb;
+            if constexpr (EPI == RTX_DW_ADAM) {
+                if (p.bias_p) {   // the layer's bias takes its Adam step here too: no separate small-tensor launch
+                    const RtxAdamEpi& A = p.adam;
+                    const float bp0 = p.bias_p[row], bm0 = p.bias_m[row], bv0 = p.bias_v[row];
+                    float breg = 0.f;
+                    if (p.bias_sumsq && A.lam != 0.f) {
+                        const float nrm = sqrtf(*p.bias_sumsq);
+                        breg = nrm > 0.f ? A.lam / nrm : 0.f;
+                    }
+                    float gg = gb + breg * bp0;
+                    if (A.weight_decay != 0.f) gg += A.weight_decay * bp0;
+                    const float m1 = bm0 + (gg - bm0) * (1.f - A.beta1);
+                    const float v1 = bv0 * A.beta2 + (1.f - A.beta2) * gg * gg;
+                    const float denom = sqrtf(v1) / A.bc2_sqrt + A.eps;
+                    p.bias_p[row] = bp0 - A.step_size * (m1 / denom);
+                    p.bias_m[row] = m1;
+                    p.bias_v[row] = v1;
+                }
+            }
+        }
         if (col >= p.N_real) continue;
         const size_t off = (size_t)row * p.N_real + col;
         if constexpr (EPI == RTX_DW_ADAM) {

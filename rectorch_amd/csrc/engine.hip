@@ -34,7 +34,9 @@ const char* rtx_last_error_str();
 struct Layer {
     int in = 0, out = 0, inp = 0, outp = 0;
     bool tanh_act = false;
-    void* Wsh = nullptr;
+    void* Wsh = nullptr;      // the compute copy every reader of this step uses
+    void* Wsh_alt = nullptr;  // the fused optimizer writes the NEXT step's copy here (they swap after the step), so the
+                              // weight-gradient kernels may run beside the data-gradient chain that still reads Wsh
     void* A = nullptr;
     float* O32 = nullptr;
     void* D = nullptr;
@@ -74,10 +76,16 @@ struct rtx_engine {
     std::vector<float*> params, grads, m, v;
     bool bound = false, can_train = false, shadows_valid = false;
     TempCsr tmp_in, tmp_tg;
+    // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
+    hipStream_t side = nullptr;
+    hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
+    hipEvent_t ev_done = nullptr;
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
     int opt_lse_fuse = 1;       // bf16: log-sum-exp partials from the logits GEMM's epilogue
+    int opt_two_stream = 0;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain
+    int opt_nt_regstage = 0;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip)
     // timing
     bool timing_all = false;
     std::map<std::string, bool> timing_sites;
@@ -176,20 +184,25 @@ struct ScopedTimer {
 //   form NT: C[Mp][Np] = A[Mp][Kp] x B[Np][Kp]^T      (forward)
 //   form NN: C[Mp][Np] = A[Mp][Kp] x B[Kp][Np]        (backward-data: B = the weight copy itself)
 struct GemmPlan {
-    int cfg;        // bf16: RtxDmaCfg; f32: 128x128 tiles
+    int cfg;        // LDS-DMA kernel: RtxDmaCfg; register-staged kernels (f32, optionally bf16 NT): 128x128 tiles
+    int regstage;
     int bm, bn;
     int m_tiles, n_tiles, k_slices, splits;
 };
 
-static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp)
+static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form = RTX_FORM_NT)
 {
     GemmPlan pl = {};
     pl.k_slices = (int)((size_t)Kp * e->esz / 128);     // 64 bf16 or 32 f32 per slice
-    if (e->bf16) {
+    pl.regstage = !e->bf16 || (form == RTX_FORM_NT && e->opt_nt_regstage && (long)Np * Kp >= (1L << 21));
+    if (!pl.regstage) {
         // the 512-row tile covers every batch row of a B <= 512 step: each weight byte is read by one workgroup.  Small
         // problems (hidden layers) are latency-bound: 128x128 tiles give 4x the workgroups.
         const bool big = (Mp % 512 == 0) && ((long)Np * Kp >= (1L << 21));
         pl.cfg = big ? RTX_DMA_512x128 : RTX_DMA_128x128;
+        // data-gradient chain beside the weight-gradient kernels (two streams): a 64-KB-LDS configuration, so that its
+        // workgroups fit on a CU next to one of theirs (the 512-row tile takes the whole LDS of a CU)
+        if (form == RTX_FORM_NN && e->opt_fuse_adam && e->opt_two_stream) pl.cfg = RTX_DMA_128x128_S2;
         rtx_gemm_dma_tile_dims(pl.cfg, &pl.bm, &pl.bn);
     } else {
         pl.cfg = RTX_TILE_128x128;
@@ -200,10 +213,11 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp)
     const int tiles = pl.m_tiles * pl.n_tiles;
     // split K so that one wave of workgroups fills the chip: 1 per CU for the LDS-DMA kernels (their stages fill the
     // LDS), 2 per CU for the register-staged f32 kernel; at least two K slices per workgroup
-    const int resident = e->bf16 ? 256 : 512;
+    const int resident = (pl.regstage || pl.cfg == RTX_DMA_128x128_S2) ? 512 : 256;
     int s = 1;
     if (tiles * 2 <= resident) {
         s = resident / tiles;
+        if (pl.regstage && s >= 8) s &= ~7;   // register-staged kernel: every XCD owns whole splits
         if (pl.k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
         const int max_s = pl.k_slices / 2 > 0 ? pl.k_slices / 2 : 1;
         if (s > max_s) s = max_s;
@@ -215,20 +229,28 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp)
     return pl;
 }
 
-static size_t plan_cacc_elems(const rtx_engine* e, int Np, int Kp)
+static size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
 {
     size_t mx = 0;
-    for (int Mp = 128; Mp <= e->Bp_alloc; Mp += 128) {
-        const GemmPlan pl = plan_gemm(e, Mp, Np, Kp);
-        mx = std::max(mx, (size_t)pl.splits * Mp * Np);
+    const int keep = e->opt_nt_regstage, keep2 = e->opt_two_stream;
+    for (int rs = 0; rs < 4; ++rs) {     // whichever kernels the knobs select later
+        e->opt_nt_regstage = rs & 1;
+        e->opt_two_stream = rs >> 1;
+        for (int form : {RTX_FORM_NT, RTX_FORM_NN})
+            for (int Mp = 128; Mp <= e->Bp_alloc; Mp += 128) {
+                const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, form);
+                mx = std::max(mx, (size_t)pl.splits * Mp * Np);
+            }
     }
+    e->opt_nt_regstage = keep;
+    e->opt_two_stream = keep2;
     return mx;
 }
 
 static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, int* splits_out,
                         hipStream_t st)
 {
-    const GemmPlan pl = plan_gemm(e, Mp, Np, Kp);
+    const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, form);
     RtxGemm g = {};
     g.form = form;
     g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
@@ -236,8 +258,8 @@ static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const 
     g.C = e->Cacc; g.ldc = Np; g.slab_stride = (long)Mp * Np;
     RTX_CHECK((size_t)g.splits * Mp * Np <= e->cacc_elems, RTX_ESTATE, "internal: Cacc too small (%d x %d x %d)", g.splits, Mp, Np);
     *splits_out = g.splits;
-    if (e->bf16) return rtx_gemm_dma_launch(g, RTX_EPI_STORE, st);
-    if (form == RTX_FORM_NT) return rtx_gemm_launch(g, RTX_DT_F32, RTX_EPI_STORE, st);
+    if (!pl.regstage) return rtx_gemm_dma_launch(g, RTX_EPI_STORE, st);
+    if (form == RTX_FORM_NT) return rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_STORE, st);
     return rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, st);
 }
 
@@ -332,17 +354,17 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             g.splits = 1; g.C = logits; g.ldc = ldlog; g.bias = e->params[2 * li + 1];
             g.M_real = B; g.N_real = l.out;
             TIMED("gemm_logits");
-            if (e->bf16) {
+            if (e->bf16 && !e->opt_nt_regstage) {
                 g.tile_shape = (Bp % 512 == 0) ? RTX_DMA_512x128 : RTX_DMA_128x128;
                 int bm, bn;
                 rtx_gemm_dma_tile_dims(g.tile_shape, &bm, &bn);
                 g.m_tiles = Bp / bm; g.n_tiles = l.outp / bn;
-                if (want_lse && e->opt_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }
+                if (want_lse && e->opt_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }   // (see lse_fused)
                 RTX_TRY(rtx_gemm_dma_launch(g, RTX_EPI_BIAS_ROWS, st));
             } else {
                 g.tile_shape = RTX_TILE_128x128;
                 g.m_tiles = Bp / 128; g.n_tiles = l.outp / 128;
-                RTX_TRY(rtx_gemm_launch(g, RTX_DT_F32, RTX_EPI_BIAS_ROWS, st));
+                RTX_TRY(rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_BIAS_ROWS, st));
             }
             break;
         }
@@ -555,6 +577,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     for (int li = 0; li < e->NL; ++li) {
         Layer& l = e->L[li];
         ALLOC(l.Wsh, (size_t)l.outp * l.inp * es);
+        if (e->bf16) ALLOC(l.Wsh_alt, (size_t)l.outp * l.inp * es);
         ALLOC(l.A, Bp * l.inp * es);
         if (li < e->NL - 1) ALLOC(l.O32, Bp * l.outp * sizeof(float));
         ALLOC(l.D, Bp * l.outp * es);
@@ -572,7 +595,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
     ALLOC(e->lse_part, Bp * e->lse_strips * sizeof(float2));
     ALLOC(e->tsum, Bp * sizeof(float));
     ALLOC(e->lse, Bp * sizeof(float));
-    ALLOC(e->row_loss, Bp * sizeof(float));
+    ALLOC(e->row_loss, Bp * rtx_dlogits_chunks(e->Ip) * sizeof(float));
     ALLOC(e->sumsq, sizeof(float) * 2 * RTX_MAX_LAYERS * 2);
     ALLOC(e->scratch_loss, sizeof(float) * 4);
 #undef ALLOC
@@ -588,6 +611,10 @@ int rtx_engine_destroy(rtx_engine* e)
     for (auto& kv : e->sites)
         for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->ev_d)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+    if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
 }
@@ -725,23 +752,81 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RtxDlogitsArgs a = {};
         a.loss.Y = e->Y; a.loss.ldy = e->Ip; a.loss.B = B; a.loss.I = e->I; a.loss.target = tg; a.loss.tsum = e->tsum;
         a.loss.lse = e->lse; a.loss.row_loss = e->row_loss; a.loss.inv_batch = step->inv_batch;
-        if (e->bf16 && e->opt_lse_fuse) { a.loss.part = e->lse_part; a.loss.n_strips = e->lse_strips; a.loss.part_ld = e->lse_strips; }
+        if (e->bf16 && e->opt_lse_fuse && !e->opt_nt_regstage) { a.loss.part = e->lse_part; a.loss.n_strips = e->lse_strips; a.loss.part_ld = e->lse_strips; }
         if (e->vae) { a.loss.mu32 = e->mu32; a.loss.lv32 = e->lv32; a.loss.Z = e->Z; a.loss.beta = step->beta; }
         a.Bp = Bp; a.D = e->L[NL - 1].D; a.ldd = e->Ip;
         TIMED("dlogits_loss");
         RTX_TRY(rtx_launch_dlogits(a, e->bf16, st));
     }
-    {
-        TIMED("reduce_loss");
-        RTX_TRY(rtx_launch_reduce_loss(e->row_loss, B, step->lam, dae_reg ? e->sumsq : nullptr, 2 * NL, loss_out, loss_accum, st));
-    }
-    RtxAdamArgs rest = {};   // tensors whose Adam is NOT fused into a weight-gradient kernel (biases, odd-width matrices)
+    RtxAdamArgs rest = {};   // tensors whose Adam is NOT fused into a weight-gradient kernel (odd-width matrices + their biases)
     int rest_ids[RTX_MAX_TENSORS];
     rest.n = 0;
+    // Fused step: the weight-gradient + Adam kernels are HBM / load-path streaming kernels that depend only on D[l] and
+    // A[l]; the data-gradient chain (dX GEMM -> activation derivative, layer by layer) is a chain of short latency-bound
+    // launches.  They run on two streams: `ws` takes layer l's weight kernel as soon as D[l] exists, the caller's stream
+    // goes on down the chain.  The fused optimizer writes the NEXT step's compute copy (Wsh_alt), so the chain can still
+    // read this step's.
+    const bool two = fuse && e->opt_two_stream;
+    hipStream_t ws = st;
+    if (two) {
+        if (!e->side) {
+            RTX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+            for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
+            RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        }
+        ws = e->side;
+        RTX_HIP(hipEventRecord(e->ev_d[NL - 1], st));   // D[NL-1] (and the loss inputs) are complete
+    }
+    {
+        TIMED("reduce_loss");
+        const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);
+        RTX_TRY(rtx_launch_reduce_loss(e->row_loss, B * rtx_dlogits_chunks(e->Ip), step->lam, reg_in_loss ? e->sumsq : nullptr, 2 * NL, loss_out, loss_accum, st));
+    }
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
-        // (1) data gradient FIRST: it reads this layer's compute copy, which the fused optimizer epilogue of (2)
-        //     overwrites:  dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major)
+        // (1) weight + bias gradient: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column `in` of the
+        //     product (the ones column of A) is the bias gradient
+        const bool fused = fuse && layer_fusable(e, l);
+        auto weight_grad = [&]() -> int {
+            const char* site = li == NL - 1 ? (fused ? "dW_adam_out" : "gemm_dW_out") : (li == 0 ? (fused ? "dW_adam_in" : "gemm_dW_in") : (fused ? "dW_adam_hidden" : "gemm_dW_hidden"));
+            ScopedTimer tm(e, site, ws);
+            if (e->bf16) {
+                RtxDw d = {};
+                d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
+                d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+                d.M_real = l.out; d.N_real = l.in;
+                if (fused) {
+                    RtxAdamArgs sc = {};
+                    fill_adam_scalars(e, step, sc, 2 * li);
+                    const bool keep = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
+                    d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
+                    d.adam.gkeep = keep ? e->grads[2 * li] : nullptr;
+                    d.gbias = keep ? e->grads[2 * li + 1] : nullptr;
+                    d.adam.sh = two ? l.Wsh_alt : l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
+                    d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
+                    d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
+                    d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
+                    d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
+                    d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
+                    return rtx_dw_launch(d, RTX_DW_ADAM, e->opt_dw_cfg, ws);
+                }
+                d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
+                return rtx_dw_launch(d, RTX_DW_GRAD, e->opt_dw_cfg, ws);
+            }
+            RtxGemm g = {};
+            g.form = RTX_FORM_TN;
+            g.A = l.D; g.lda = l.outp; g.B = l.A; g.ldb = l.inp;
+            g.k_slices = Bp / 32; g.tile_shape = RTX_TILE_128x128; g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
+            g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
+            g.M_real = l.out; g.N_real = l.in;
+            return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
+        };
+        if (two) {   // the long kernel first: it only needs D[li]
+            RTX_HIP(hipStreamWaitEvent(ws, e->ev_d[li], 0));
+            RTX_TRY(weight_grad());
+        }
+        // (2) data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come
+        //     before (1), whose fused optimizer epilogue overwrites this layer's compute copy.
         if (li > 0) {
             int splits = 1;
             {
@@ -765,55 +850,31 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
                 TIMED("post_bwd");
                 RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
             }
+            if (two) RTX_HIP(hipEventRecord(e->ev_d[li - 1], st));
         }
-        // (2) weight + bias gradient: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column `in` of the
-        //     product (the ones column of A) is the bias gradient
-        const bool fused = fuse && layer_fusable(e, l);
-        {
-            const char* site = li == NL - 1 ? (fused ? "dW_adam_out" : "gemm_dW_out") : (li == 0 ? (fused ? "dW_adam_in" : "gemm_dW_in") : (fused ? "dW_adam_hidden" : "gemm_dW_hidden"));
-            TIMED(site);
-            if (e->bf16) {
-                RtxDw d = {};
-                d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-                d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
-                d.M_real = l.out; d.N_real = l.in; d.gbias = e->grads[2 * li + 1];
-                if (fused) {
-                    RtxAdamArgs sc = {};
-                    fill_adam_scalars(e, step, sc, 2 * li);
-                    d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
-                    d.adam.gkeep = (step->flags & RTX_STEP_KEEP_GRADS) ? e->grads[2 * li] : nullptr;
-                    d.adam.sh = l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
-                    d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
-                    d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
-                    d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
-                    RTX_TRY(rtx_dw_launch(d, RTX_DW_ADAM, e->opt_dw_cfg, st));
-                } else {
-                    d.gW = e->grads[2 * li];
-                    RTX_TRY(rtx_dw_launch(d, RTX_DW_GRAD, e->opt_dw_cfg, st));
-                }
-            } else {
-                RtxGemm g = {};
-                g.form = RTX_FORM_TN;
-                g.A = l.D; g.lda = l.outp; g.B = l.A; g.ldb = l.inp;
-                g.k_slices = Bp / 32; g.tile_shape = RTX_TILE_128x128; g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
-                g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
-                g.M_real = l.out; g.N_real = l.in;
-                RTX_TRY(rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, st));
-            }
-        }
-        if (fuse) {   // what is left for the small multi-tensor Adam launch at the end of the step
+        if (!two) RTX_TRY(weight_grad());
+        if (fuse && !fused) {   // what is left for the small multi-tensor Adam launch at the end of the step
             RtxAdamArgs one = {};
             fill_adam_tensors(e, one, li, li + 1);
-            if (!fused) { rest_ids[rest.n] = 2 * li; rest.t[rest.n++] = one.t[0]; }
-            rest_ids[rest.n] = 2 * li + 1;
-            rest.t[rest.n++] = one.t[1];
+            rest_ids[rest.n] = 2 * li; rest.t[rest.n++] = one.t[0];
+            rest_ids[rest.n] = 2 * li + 1; rest.t[rest.n++] = one.t[1];
         }
         if (cb) cb(li, user);
     }
     if (fuse) {
-        fill_adam_scalars(e, step, rest, 0, rest_ids);
-        TIMED("adam_small");
-        RTX_TRY(rtx_launch_adam(rest, e->bf16, st));
+        if (rest.n > 0) {
+            // (on the side stream these in-place updates come after every reader of this step: ws has waited for ev_d[0])
+            fill_adam_scalars(e, step, rest, 0, rest_ids);
+            ScopedTimer tm(e, "adam_small", ws);
+            RTX_TRY(rtx_launch_adam(rest, e->bf16, ws));
+        }
+        if (two) {
+            for (int li = 0; li < NL; ++li)
+                if (layer_fusable(e, e->L[li])) std::swap(e->L[li].Wsh, e->L[li].Wsh_alt);
+            // everything the step did is ordered on the caller's stream when the call returns
+            RTX_HIP(hipEventRecord(e->ev_done, ws));
+            RTX_HIP(hipStreamWaitEvent(st, e->ev_done, 0));
+        }
         e->shadows_valid = true;
     }
     return RTX_OK;
@@ -859,6 +920,60 @@ int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t la
     return RTX_OK;
 }
 
+// Sharded optimizer (data parallel, ZeRO-1 style): this rank owns rows [row_lo, row_hi) of layer `layer`'s weight matrix.
+// After the reduce-scatter of the gradient it updates only those rows (p, exp_avg, exp_avg_sq and the rows of the compute
+// copy) -- the optimizer's 28 B/param of HBM traffic shrink by the number of ranks -- and, with with_bias, the (replicated,
+// all-reduced) bias in full.  The caller then all-gathers the compute copy (rtx_engine_shadow_region).
+int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t layer, int32_t row_lo, int32_t row_hi, int32_t with_bias,
+                               const uint16_t* w_grad_bf16, const uint16_t* b_grad_bf16, void* stream)
+{
+    RTX_TRY(check_ready(e, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "apply_adam_rows: step count must be >= 1");
+    RTX_CHECK(layer >= 0 && layer < e->NL, RTX_EINVAL, "apply_adam_rows: layer %d out of range", layer);
+    const Layer& l = e->L[layer];
+    RTX_CHECK(row_lo >= 0 && row_lo <= row_hi && row_hi <= l.outp, RTX_EINVAL, "apply_adam_rows: bad row range [%d, %d) of %d", row_lo, row_hi, l.outp);
+    hipStream_t st = (hipStream_t)stream;
+    RtxAdamArgs full = {}, a = {};
+    fill_adam_tensors(e, full, layer, layer + 1);
+    int ids[2];
+    const int hi = std::min(row_hi, l.out);     // padding rows hold no parameters
+    if (row_lo < hi) {
+        RtxAdamTensor w = full.t[0];
+        const size_t off = (size_t)row_lo * l.in;
+        w.p += off; w.g += off; w.m += off; w.v += off;
+        if (w_grad_bf16) w.g16 = w_grad_bf16 + off;
+        w.sh = (char*)l.Wsh + (size_t)row_lo * l.inp * e->esz;
+        w.rows = hi - row_lo;
+        ids[a.n] = 2 * layer;
+        a.t[a.n++] = w;
+    }
+    if (with_bias) {
+        RtxAdamTensor b = full.t[1];
+        if (b_grad_bf16) b.g16 = b_grad_bf16;
+        ids[a.n] = 2 * layer + 1;
+        a.t[a.n++] = b;
+    }
+    if (a.n == 0) return RTX_OK;
+    fill_adam_scalars(e, step, a, 0, ids);
+    TIMED("adam");
+    RTX_TRY(rtx_launch_adam(a, e->bf16, st));
+    e->shadows_valid = true;    // (whole again once the caller has all-gathered the compute copies of this step)
+    return RTX_OK;
+}
+
+// the compute copy of layer `layer`'s weight matrix: [padded_rows][ld] elements of `elem_bytes` bytes, padded_rows a multiple
+// of 128 -- the buffer a sharded-optimizer caller all-gathers in place (equal row blocks per rank)
+int rtx_engine_shadow_region(rtx_engine* e, int32_t layer, void** base, int32_t* padded_rows, int32_t* ld, int32_t* elem_bytes)
+{
+    RTX_CHECK(e && layer >= 0 && layer < e->NL, RTX_EINVAL, "shadow_region: bad arguments");
+    const Layer& l = e->L[layer];
+    if (base) *base = l.Wsh;
+    if (padded_rows) *padded_rows = l.outp;
+    if (ld) *ld = l.inp;
+    if (elem_bytes) *elem_bytes = (int32_t)e->esz;
+    return RTX_OK;
+}
+
 int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream)
 {
     RTX_CHECK(src && dst && n >= 0, RTX_EINVAL, "cast_f32_bf16: bad arguments");
@@ -883,6 +998,8 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     const std::string k(key);
     if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
+    else if (k == "two_stream") e->opt_two_stream = value != 0;
+    else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_32x128_S2, RTX_EINVAL, "set_option: dw_cfg must be 0..2");
         e->opt_dw_cfg = value;
@@ -902,7 +1019,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, nt_regstage, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;

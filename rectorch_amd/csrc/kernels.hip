@@ -384,27 +384,37 @@ int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// Loss and its gradient w.r.t. the logits, one pass over Y (one workgroup per user):
-//   lse_b       = logsumexp(Y_b)            from the strip partials of the logits GEMM (or a first pass over the row)
+// Loss and its gradient w.r.t. the logits, one pass over Y.  One workgroup per (user, 4096-column chunk):
+//   lse_b       = logsumexp(Y_b)            from the strip partials of the logits GEMM (or from k_row_lse)
 //   D[b][i]     = (s_b * exp(Y_bi - lse_b) - t_bi) * inv_batch         (reference models.py:813-815 through autograd)
-//   row_loss_b  = (s_b * lse_b - <t_b, Y_b>) * inv_batch (+ beta * KL_b * inv_batch)
-// The target row is sparse: its stored entries are scattered into an LDS image of a 4096-column chunk (as k_gather
-// does for the input), so the pass over Y is purely streaming: 16-byte loads of Y, 8 / 16-byte stores of D.
-// Replaces round 1's k_lse_loss + dlogits post kernel (which also wrote D transposed) + k_target_fixup.
+//   row_part[b][c] = -<t_b, Y_b>_chunk * inv_batch   (+ s_b * lse_b * inv_batch + beta * KL_b * inv_batch in chunk 0)
+// The target row is sparse: its stored entries are scattered into an LDS image of the chunk (as k_gather does for the
+// input), so the pass over Y is purely streaming: 16-byte loads of Y, 8 / 16-byte stores of D.  The loss is the
+// fixed-order sum of row_part (k_reduce_loss).  Replaces round 1's k_lse_loss + dlogits post kernel (which also wrote D
+// transposed) + k_target_fixup.
 // ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_lse(const float* Y, int ldy, int I, float* lse)
+{
+    __shared__ float red[8];
+    const float v = block_lse(Y + (size_t)blockIdx.x * ldy, I, red);
+    if (threadIdx.x == 0) lse[blockIdx.x] = v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_dlogits(const RtxDlogitsArgs a)
 {
     __shared__ __attribute__((aligned(16))) float timg[RTX_GATHER_CHUNK];
     __shared__ float red[8];
     const RtxLossArgs& L = a.loss;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    T* Drow = (T*)a.D + (size_t)b * a.ldd;
+    const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int c0 = chunk * RTX_GATHER_CHUNK;
+    const int cn = min(RTX_GATHER_CHUNK, a.ldd - c0);
+    T* Drow = (T*)a.D + (size_t)b * a.ldd + c0;
     if (b >= L.B) {
-        for (int i = tid * 4; i < a.ldd; i += 256 * 4) store4<T>(Drow + i, 0.f, 0.f, 0.f, 0.f);
+        for (int i = tid * 4; i < cn; i += 256 * 4) store4<T>(Drow + i, 0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const float* y = L.Y + (size_t)b * L.ldy;
+    const float* y = L.Y + (size_t)b * L.ldy + c0;
     float lse;
     if (L.part) {
         float m = -INFINITY, s = 0.f;
@@ -424,43 +434,39 @@ __global__ __launch_bounds__(256) void k_dlogits(const RtxDlogitsArgs a)
         online_merge(M, S, red[2], red[6]);
         online_merge(M, S, red[3], red[7]);
         lse = M + logf(S);
-        __syncthreads();
     } else {
-        lse = block_lse(y, L.I, red);
+        lse = L.lse[b];     // k_row_lse ran first
     }
     const float sc = L.tsum[b] * L.inv_batch;
     const int64_t u = csr_row(L.target, b);
     const int64_t tb = L.target.indptr[u], te = L.target.indptr[u + 1];
+    for (int i = tid * 4; i < cn; i += 256 * 4) *(float4*)(timg + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int64_t k = tb + tid; k < te; k += 256) {
+        const int i = L.target.indices[k];
+        if (i >= c0 && i < c0 + cn && i < L.I) timg[i - c0] = L.target.values ? L.target.values[k] : 1.f;
+    }
+    __syncthreads();
     float dot = 0.f;
-    for (int c0 = 0; c0 < a.ldd; c0 += RTX_GATHER_CHUNK) {
-        const int cn = min(RTX_GATHER_CHUNK, a.ldd - c0);
-        for (int i = tid * 4; i < cn; i += 256 * 4) *(float4*)(timg + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        for (int64_t k = tb + tid; k < te; k += 256) {
-            const int i = L.target.indices[k];
-            if (i >= c0 && i < c0 + cn && i < L.I) timg[i - c0] = L.target.values ? L.target.values[k] : 1.f;
-        }
-        __syncthreads();
-        for (int i = tid * 4; i < cn; i += 256 * 4) {
-            const int col = c0 + i;
-            float4 yy = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < L.ldy) yy = *(const float4*)(y + col);   // ldy is a multiple of 4: a group is inside the row or past it
-            const float4 tt = *(const float4*)(timg + i);
-            const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
-            float d[4];
+#pragma unroll 4
+    for (int i = tid * 4; i < cn; i += 256 * 4) {
+        const int col = c0 + i;
+        float4 yy = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < L.ldy) yy = *(const float4*)(y + i);   // ldy is a multiple of 4: a group is inside the row or past it
+        const float4 tt = *(const float4*)(timg + i);
+        const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w};
+        float d[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool valid = col + e < L.I;
-                d[e] = valid ? sc * __expf(yv[e] - lse) - tv[e] * L.inv_batch : 0.f;
-                if (valid) dot += tv[e] * yv[e];
-            }
-            store4<T>(Drow + col, d[0], d[1], d[2], d[3]);
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = col + e < L.I;
+            d[e] = valid ? sc * __expf(yv[e] - lse) - tv[e] * L.inv_batch : 0.f;
+            if (valid) dot += tv[e] * yv[e];
         }
-        __syncthreads();
+        store4<T>(Drow + i, d[0], d[1], d[2], d[3]);
     }
     dot = block_sum(dot, red);
     float kl = 0.f;
-    if (L.mu32) {
+    if (chunk == 0 && L.mu32) {
         for (int j = tid; j < L.Z; j += 256) {
             const float m = L.mu32[(size_t)b * L.Z + j], lv = L.lv32[(size_t)b * L.Z + j];
             kl += 1.f + lv - m * m - expf(lv);
@@ -468,19 +474,32 @@ __global__ __launch_bounds__(256) void k_dlogits(const RtxDlogitsArgs a)
         kl = block_sum(kl, red);
     }
     if (tid == 0) {
-        L.lse[b] = lse;
-        L.row_loss[b] = (L.tsum[b] * lse - dot) * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
+        float part = -dot * L.inv_batch;
+        if (chunk == 0) {
+            if (L.part) L.lse[b] = lse;
+            part += L.tsum[b] * lse * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
+        }
+        L.row_loss[(size_t)b * gridDim.y + chunk] = part;
     }
 }
 
+int rtx_dlogits_chunks(int ldd) { return (ldd + RTX_GATHER_CHUNK - 1) / RTX_GATHER_CHUNK; }
+
+// a.loss.row_loss receives B * rtx_dlogits_chunks(a.ldd) partial sums (row-major [B][chunks]): sum them with
+// rtx_launch_reduce_loss(row_loss, B * chunks, ...)
 int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream)
 {
     if (a.Bp <= 0) return RTX_OK;
     RTX_CHECK(a.loss.ldy % 4 == 0 && a.ldd % 8 == 0 && a.ldd >= a.loss.I, RTX_EINVAL, "dlogits: bad leading dimensions");
+    if (!a.loss.part && a.loss.B > 0) {
+        hipLaunchKernelGGL(k_row_lse, dim3(a.loss.B), dim3(256), 0, stream, a.loss.Y, a.loss.ldy, a.loss.I, a.loss.lse);
+        RTX_HIP(hipGetLastError());
+    }
+    const dim3 grid(a.Bp, rtx_dlogits_chunks(a.ldd));
     if (is_bf16)
-        hipLaunchKernelGGL(k_dlogits<bf16_t>, dim3(a.Bp), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_dlogits<bf16_t>, grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(k_dlogits<float>, dim3(a.Bp), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_dlogits<float>, grid, dim3(256), 0, stream, a);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

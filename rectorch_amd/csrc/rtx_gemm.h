@@ -49,7 +49,7 @@ void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
 // gradient).  TN: A is [k][m] and B is [k][n] (the weight gradient straight from the row-major activations / deltas).
 enum RtxForm { RTX_FORM_NT = 0, RTX_FORM_NN = 1, RTX_FORM_TN = 2 };
 // tile configurations of the LDS-DMA GEMM (gemm_dma.hip): 4-wave 128x128, 8-wave 512x128 (all rows of a B = 500 step), 8-wave 256x256
-enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2 };
+enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2, RTX_DMA_128x128_S2 = 3 };   // _S2: two stages (64 KB of LDS: co-resident with other kernels)
 void rtx_gemm_dma_tile_dims(int cfg, int* bm, int* bn);
 
 struct RtxGemm {
@@ -97,6 +97,10 @@ struct RtxDw {
     bf16_t* g16;         // RTX_DW_GRAD: bf16 image of the same (nullable): staged for a bf16 gradient exchange
     float* gbias;        // [M_real] = column N_real of the product (nullable)
     RtxAdamEpi adam;     // RTX_DW_ADAM
+    float* bias_p;       // RTX_DW_ADAM (nullable): the layer's bias [M_real] and its Adam moments, updated in the same launch
+    float* bias_m;       //   with the scalars of `adam`
+    float* bias_v;
+    const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
 };
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);

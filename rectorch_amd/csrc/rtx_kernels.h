@@ -116,7 +116,7 @@ int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float*
                            float* loss_out, float* loss_accum, hipStream_t stream);
 // Loss AND its gradient w.r.t. the logits in one pass over Y (reference models.py:813-815 + autograd of log_softmax):
 //   lse_b from the strip partials the logits GEMM left (or, without them, a first pass over the row),
-//   row_loss_b as rtx_launch_lse_loss,  D[b][i] = (s_b * softmax(Y_b)_i - t_bi) * inv_batch  (T = bf16 / f32, zero padding)
+//   row-loss partials (their fixed-order sum is the loss),  D[b][i] = (s_b * softmax(Y_b)_i - t_bi) * inv_batch  (T = bf16 / f32, zero padding)
 struct RtxDlogitsArgs {
     RtxLossArgs loss;   // Y, target, tsum, part..., outputs lse / row_loss, KL inputs
     int Bp;             // rows [B, Bp) of D are written as zeros
@@ -124,6 +124,8 @@ struct RtxDlogitsArgs {
     int ldd;            // >= I, multiple of 8; columns [I, ldd) are written as zeros
 };
 int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream);
+// one workgroup per (user, 4096-column chunk): loss.row_loss receives [B][rtx_dlogits_chunks(ldd)] partial sums
+int rtx_dlogits_chunks(int ldd);
 // predict(): logits[b][i] = -inf where the input has a stored non-zero
 int rtx_launch_neg_inf(const RtxCsrView& in, int B, float* logits, long ld, int n_items, hipStream_t stream);
 // public loss_function on dense tensors: row_loss[b] = s*lse - <x,y>  (+ beta * KL_b)

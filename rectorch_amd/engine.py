@@ -248,6 +248,29 @@ class Engine:
             arr = (C.c_void_p * self.n_tensors)(*[C.c_void_p(int(a)) for a in grads_bf16])
         check(lib().rtx_engine_apply_adam_layers(self.handle, C.byref(step), int(layer_lo), int(layer_hi), arr, stream_ptr()))
 
+    def apply_adam_rows(self, step, layer, row_lo, row_hi, with_bias=True, w_grad_bf16=None, b_grad_bf16=None):
+        """sharded optimizer: Adam on rows [row_lo, row_hi) of layer ``layer``'s weight matrix (+ its replicated bias) on the
+        CURRENT stream; ``*_grad_bf16``: device addresses of the bf16 images of the reduced gradients, or None."""
+        check(lib().rtx_engine_apply_adam_rows(self.handle, C.byref(step), int(layer), int(row_lo), int(row_hi), int(bool(with_bias)),
+                                               None if w_grad_bf16 is None else C.c_void_p(int(w_grad_bf16)),
+                                               None if b_grad_bf16 is None else C.c_void_p(int(b_grad_bf16)), stream_ptr()))
+
+    def shadow_tensor(self, layer):
+        """the compute copy of layer ``layer``'s weight matrix as a torch tensor ALIASING the engine's buffer
+        ([padded_rows, ld], bfloat16 or float32): what a sharded-optimizer step all-gathers in place."""
+        base, rows, ld, eb = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().rtx_engine_shadow_region(self.handle, int(layer), C.byref(base), C.byref(rows), C.byref(ld), C.byref(eb)))
+
+        class _Alias:     # __cuda_array_interface__ is honoured by PyTorch-ROCm as well
+            pass
+        al = _Alias()
+        n = rows.value * ld.value
+        al.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i2" if eb.value == 2 else "<f4", "data": (base.value, False), "version": 2}
+        t = torch.as_tensor(al, device="cuda")
+        if eb.value == 2:
+            t = t.view(torch.bfloat16)
+        return t.view(rows.value, ld.value)
+
     def train_step(self, x, target, step, loss_out, loss_accum=None):
         keep = []
         b = make_batch(x, target, keep=keep, n_items=self.n_items, n_in=self.n_in)

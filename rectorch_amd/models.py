@@ -54,6 +54,7 @@ class _RtxState:
         self.adam_step = 0
         self.loss_buf = None      # [0] = last loss, [1] = running sum since the last read-back
         self.reducer = None       # data parallel: rectorch_amd.parallel.GradAllReducer
+        self.masters_sharded = False   # sharded optimizer: the float32 master rows of other ranks are stale until gathered
         self.inject = None        # parity tests: (dropout keep-mask, eps) captured from the reference's RNG
 
     def __repr__(self):
@@ -222,10 +223,13 @@ class AETrainer(TorchNNTrainer):
         params = self.network._param_list()
         if st.grads is None or st.flat_grads.device != params[0].device:
             # one flat gradient buffer (one RCCL all-reduce region per layer); p.grad are views into it
+            # a weight matrix's region holds its rows padded to a multiple of 128 (zeros), so that a data-parallel
+            # reduce-scatter can cut it into equal, row-aligned blocks for any power-of-two number of ranks
             offs, total = [], 0
             for p in params:
                 offs.append(total)
-                total += (p.numel() + 63) // 64 * 64
+                n = p.numel() if p.dim() == 1 else ((p.shape[0] + 1 + 127) // 128 * 128) * p.shape[1]
+                total += (n + 63) // 64 * 64
             st.flat_grads = torch.zeros(total, dtype=torch.float32, device=params[0].device)
             st.grads = [st.flat_grads[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
             st.layer_ranges = [(offs[2 * l], offs[2 * l + 1] + params[2 * l + 1].numel()) for l in range(len(params) // 2)]
@@ -268,7 +272,9 @@ class AETrainer(TorchNNTrainer):
                          inv_batch=1.0 / (B if red is None else red.global_batch(B)),
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
                          eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
-                         flags=_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0)
+                         flags=(_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0) |
+                               # data parallel: the (rank-independent) DAE regulariser enters the summed loss once
+                               (_lib.RTX_STEP_NO_REG_IN_LOSS if red is not None and red.rank != 0 else 0))
         loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]
         if red is None:
             eng.train_step(x, target, step, loss_out, loss_acc)
@@ -276,6 +282,14 @@ class AETrainer(TorchNNTrainer):
             if getattr(red, "bucket_adam", False):
                 g16 = red.grads16_ptrs()
                 red.adam = lambda lo, hi: eng.apply_adam_layers(step, lo, hi, g16)
+                if getattr(red, "sharded", False):
+                    # sharded optimizer: this rank updates only its rows of the big matrices, then the compute copies
+                    # are all-gathered in place (rectorch_amd/parallel.py)
+                    red.adam_rows = lambda layer, lo, hi: eng.apply_adam_rows(
+                        step, layer, lo, hi, True,
+                        None if g16 is None else g16[2 * layer], None if g16 is None else g16[2 * layer + 1])
+                    red.shadow = eng.shadow_tensor
+                    st.masters_sharded = True
             else:
                 red.adam = None
             eng.loss_grads(x, target, step, loss_out, loss_acc, layer_cb=red.on_layer)
@@ -303,6 +317,8 @@ class AETrainer(TorchNNTrainer):
     # ----------------------------------------------------------------------------------- prediction
     def _predict_tuple(self, x, remove_train):
         _lib.require_gpu()
+        if self.predict_numerics != self.numerics:
+            self._gather_sharded_state()      # that engine's compute copies come from the float32 masters
         self.network.eval()
         x_in = self.network._as_input(x)
         n = len(x_in) if isinstance(x_in, RowBatch) else x_in.shape[0]
@@ -322,6 +338,24 @@ class AETrainer(TorchNNTrainer):
         return (recon_x, )
 
     # -------------------------------------------------------------------------------- checkpointing
+    def _gather_sharded_state(self):
+        """Data parallel with the sharded optimizer: every rank holds current float32 rows (and Adam moments) only for
+        its own shard of the big matrices.  Collective: call on every rank before reading parameters from the host side
+        (checkpoints, ``state_dict()``, the float32 ``predict`` engine)."""
+        st = self._rtx
+        if st.reducer is None or not st.masters_sharded:
+            return
+        params = self.network._param_list()
+
+        def tensors(layer):
+            p = params[2 * layer]
+            state = self.optimizer.state[p]
+            return [p.data, state['exp_avg'], state['exp_avg_sq']]
+        st.reducer.wait()
+        st.reducer.gather_state(tensors)
+        st.masters_sharded = False
+        self.network._rtx_shadow_versions.clear()     # compute copies of the other numerics modes: refresh from the masters
+
     def _sync_optimizer_state(self):
         """write the step count the fused Adam kernel is at into torch.optim.Adam's state"""
         for p in self.network.parameters():
@@ -331,6 +365,7 @@ class AETrainer(TorchNNTrainer):
 
     def save_model(self, filepath, cur_epoch):
         r"""Save the model to file (reference models.py:475-489): ``epoch``, ``state_dict``, ``optimizer``."""
+        self._gather_sharded_state()
         self._sync_optimizer_state()
         state = {'epoch': cur_epoch,
                  'state_dict': self.network.state_dict(),
@@ -495,6 +530,7 @@ class MultiVAE(VAE):
 
     def save_model(self, filepath, cur_epoch):
         r"""Save the model to file (reference models.py:897-903): adds ``gradient_updates``."""
+        self._gather_sharded_state()
         self._sync_optimizer_state()
         state = {'epoch': cur_epoch,
                  'state_dict': self.network.state_dict(),

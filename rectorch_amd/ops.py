@@ -13,23 +13,31 @@ for callers that want to stay inside the dispatcher (profilers, ``torch.ops`` us
     torch.ops.rectorch_hip.multinomial_loss(recon, x, mu, logvar, beta)               -> Tensor []
     torch.ops.rectorch_hip.train_step_dense(engine_handle, x, target, step_scalars...) -> Tensor [] (loss)
 """
+import weakref
+
 import torch
 
 from . import engine as _engine
 
 _LIB = torch.library.Library("rectorch_hip", "DEF")
-_HANDLES = {}
+# integer handle -> object, WEAKLY: a handle lives as long as its Engine / CsrMatrix does and not a moment longer (an
+# engine replaced by a larger one, or the engines of a discarded model, release their HBM buffers as usual)
+_HANDLES = weakref.WeakValueDictionary()
 
 
 def register_handle(obj):
-    """Keep ``obj`` (an Engine or CsrMatrix) reachable from an integer the dispatcher can carry."""
+    """Make ``obj`` (an Engine or CsrMatrix) reachable from an integer the dispatcher can carry, for as long as the caller
+    keeps ``obj`` alive."""
     h = id(obj)
     _HANDLES[h] = obj
     return h
 
 
 def _get(h):
-    return _HANDLES[int(h)]
+    try:
+        return _HANDLES[int(h)]
+    except KeyError:
+        raise RuntimeError("rectorch_hip op: handle %d does not name a live Engine / CsrMatrix" % int(h)) from None
 
 
 _LIB.define("csr_gather_dense(int csr, Tensor row_ids) -> Tensor")

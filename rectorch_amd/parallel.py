@@ -17,6 +17,13 @@ each already scaled by 1/B_global.  One exchange per step:
   * in bf16 numerics the exchange itself is bf16 (HIP cast kernel -> RCCL bf16 sum -> Adam reads bf16): xGMI bytes,
     not compute, bound the step at this model size.
 
+Sharded optimizer (``attach(..., sharded=True)``, ZeRO-1 style): a big weight matrix's gradient is REDUCE-SCATTERED in
+equal blocks of (padded) rows, each rank runs Adam on its own rows only -- the optimizer's 28 B/param of HBM traffic, the
+dominant HBM term of the step, shrink by the number of ranks -- and the bf16 compute copy of the matrix is all-gathered in
+place (2 B/param on xGMI instead of the all-reduce's second half).  The float32 master rows of the other ranks go stale;
+``GradAllReducer.gather_state()`` brings p / exp_avg / exp_avg_sq together for checkpoints and ``state_dict()``.  Biases
+and small layers stay replicated (all-reduce + identical update).
+
 Small layers are coalesced into one message (``min_bucket_bytes``).  Works with any torch.distributed
 backend: "nccl" (= RCCL on ROCm) for device tensors, "gloo" for the CPU tests of the plan itself.
 """
@@ -52,7 +59,7 @@ class GradAllReducer:
     """
 
     def __init__(self, flat, layer_ranges, group=None, min_bucket_bytes=4 << 20, comm_dtype=torch.float32,
-                 tensor_offsets=None):
+                 tensor_offsets=None, shard_layers=None):
         self.flat = flat
         self.group = group
         self.rank = dist.get_rank(group)
@@ -80,7 +87,41 @@ class GradAllReducer:
                 hi = l - 1
                 size = 0
         self.launched = []
-        self._batch_cache = {}
+        # sharded optimizer: layer -> (rows, cols, padded_rows) of its weight matrix; such a layer is its own bucket
+        self.shard_layers = dict(shard_layers or {})
+        for l, (rows, cols, prow) in self.shard_layers.items():
+            assert prow % self.world == 0, "padded rows %d of layer %d do not split over %d ranks" % (prow, l, self.world)
+            assert self.tensor_offsets is not None
+        if self.shard_layers:
+            self._replan_for_shards(min_bucket_bytes)
+        self.adam_rows = None     # set per step by the trainer: adam_rows(layer, row_lo, row_hi) on the current stream
+        self.shadow = None        # set per step by the trainer: shadow(layer) -> [padded_rows, ld] tensor aliasing the compute copy
+
+    def _replan_for_shards(self, min_bucket_bytes):
+        """a sharded layer always closes a bucket of its own; the others coalesce as before"""
+        self.close_at, self.bucket_layers = {}, {}
+        n = len(self.layer_ranges)
+        hi, size = n - 1, 0
+        for l in range(n - 1, -1, -1):
+            if l in self.shard_layers:
+                if hi > l:       # close the pending small layers above first (they complete earlier)
+                    self.close_at[l + 1] = (self.layer_ranges[l + 1][0], self.layer_ranges[hi][1])
+                    self.bucket_layers[l + 1] = (l + 1, hi + 1)
+                self.close_at[l] = self.layer_ranges[l]
+                self.bucket_layers[l] = (l, l + 1)
+                hi, size = l - 1, 0
+                continue
+            size += (self.layer_ranges[l][1] - self.layer_ranges[l][0]) * self.flat.element_size()
+            if size >= min_bucket_bytes or l == 0:
+                self.close_at[l] = (self.layer_ranges[l][0], self.layer_ranges[hi][1])
+                self.bucket_layers[l] = (l, hi + 1)
+                hi, size = l - 1, 0
+
+    def shard_rows_of(self, layer):
+        """(row_lo, row_hi) of the padded rows of ``layer``'s weight matrix this rank owns"""
+        prow = self.shard_layers[layer][2]
+        per = prow // self.world
+        return self.rank * per, (self.rank + 1) * per
 
     def buckets(self):
         """(closing layer, start, end) in launch order -- for tests and the design notes."""
@@ -109,8 +150,87 @@ class GradAllReducer:
         if not self.on_device or self.adam is None:
             view.copy_(v16)       # consumers that read the float32 buffer (host tests, unfused optimizer, p.grad)
 
+    def _reduce_scatter(self, buf):
+        """in-place reduce-scatter of a buffer of world equal blocks: afterwards block `rank` holds the sum"""
+        n = buf.numel() // self.world
+        mine = buf[self.rank * n:(self.rank + 1) * n]
+        try:
+            dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            # backends without reduce-scatter (gloo in the CPU / shared-GPU tests): same result from an all-reduce
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_gather_inplace(self, full):
+        """in-place all-gather of a buffer of world equal blocks: block r comes from rank r"""
+        n = full.numel() // self.world
+        flat = full.view(-1)
+        mine = flat[self.rank * n:(self.rank + 1) * n]
+        try:
+            dist.all_gather_into_tensor(flat, mine, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
+            for r, t in enumerate(parts):
+                flat[r * n:(r + 1) * n].copy_(t)
+
+    def _exchange_sharded(self, layer):
+        """gradient of a sharded layer: reduce-scatter of the weight region (padded rows: equal blocks), all-reduce of the bias"""
+        rows, cols, prow = self.shard_layers[layer]
+        w0 = self.tensor_offsets[2 * layer]
+        b0 = self.tensor_offsets[2 * layer + 1]
+        wreg, breg = (w0, w0 + prow * cols), (b0, b0 + rows)
+        if self.flat16 is None:
+            self._reduce_scatter(self.flat[wreg[0]:wreg[1]])
+            dist.all_reduce(self.flat[breg[0]:breg[1]], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        for a, b in (wreg, breg):
+            if self.on_device:
+                from .engine import cast_f32_bf16
+                cast_f32_bf16(self.flat[a:b], self.flat16[a:b])
+            else:
+                self.flat16[a:b].copy_(self.flat[a:b])
+        self._reduce_scatter(self.flat16[wreg[0]:wreg[1]])
+        dist.all_reduce(self.flat16[breg[0]:breg[1]], op=dist.ReduceOp.SUM, group=self.group)
+
+    def _on_sharded_layer(self, layer):
+        lo, hi = self.shard_rows_of(layer)
+        if self.on_device:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self._exchange_sharded(layer)
+            self.opt.wait_stream(self.side)
+            with torch.cuda.stream(self.opt):
+                self.adam_rows(layer, lo, hi)
+            self.side.wait_stream(self.opt)
+            with torch.cuda.stream(self.side):
+                self._all_gather_inplace(self.shadow(layer))
+        else:
+            self._exchange_sharded(layer)
+            self.adam_rows(layer, lo, hi)
+            self._all_gather_inplace(self.shadow(layer))
+        self.launched.append(int(layer))
+
+    def gather_state(self, tensors_of_layer):
+        """Sharded optimizer: bring the float32 master rows (and Adam moments) of every sharded weight matrix together on
+        every rank (checkpoints, ``state_dict()``).  ``tensors_of_layer(layer)`` -> the [rows, cols] tensors to complete."""
+        for layer, (rows, cols, prow) in self.shard_layers.items():
+            for t in tensors_of_layer(layer):
+                buf = torch.zeros(prow * cols, dtype=t.dtype, device=t.device)
+                lo, hi = self.shard_rows_of(layer)
+                hi = min(hi, rows)
+                if lo < hi:
+                    buf[lo * cols:hi * cols].copy_(t.view(-1)[lo * cols:hi * cols])
+                self._all_gather_inplace(buf)
+                t.view(-1).copy_(buf[:rows * cols])
+
     def on_layer(self, layer, _user=None):
         """Host callback from rtx_engine_loss_grads: gradients of ``layer`` are enqueued on the compute stream."""
+        if int(layer) in self.shard_layers and self.adam_rows is not None:
+            # (the small layers above it were closed as their own bucket at layer + 1)
+            self._on_sharded_layer(int(layer))
+            return
         rng = self.close_at.get(int(layer))
         if rng is None:
             return
@@ -141,7 +261,9 @@ class GradAllReducer:
         self.launched = []
 
     def global_batch(self, local_batch):
-        """Sum of the ranks' local batch sizes (cached per local size: equal every step but the ragged last)."""
+        """Sum of the ranks' local batch sizes: one blocking all-reduce + host read.  ``attach`` replaces it with a
+        communication-free rule whenever the global batch is known on the host (``fixed_global_batch``, or the trainer's
+        sampler length): use this form only for ragged, data-dependent batch sizes."""
         if self.world == 1:
             return local_batch
         t = torch.tensor([float(local_batch)], device=self.flat.device)
@@ -177,21 +299,32 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None, comm_dtype=None, bucket_adam=True):
+def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None, comm_dtype=None, bucket_adam=True, sharded=False):
     """Turn a :class:`rectorch_amd.models.AETrainer` into a data-parallel replica: broadcasts rank 0's
     parameters, then every ``train_batch`` all-reduces the gradients as described above.  Each rank must feed
     ITS slice of the global batch (see ``shard_rows``).
 
     ``comm_dtype``: None -> bfloat16 when the model trains in bf16 numerics, float32 (exact) in the fp32 parity mode.
-    ``bucket_adam``: apply Adam per bucket right behind its all-reduce (third stream) instead of once after all."""
+    ``bucket_adam``: apply Adam per bucket right behind its all-reduce (third stream) instead of once after all.
+    ``sharded``: reduce-scatter + Adam on the local rows + all-gather of the compute copy for every weight matrix of at
+    least ``min_bucket_bytes`` whose padded rows split evenly over the ranks (module docstring); implies ``bucket_adam``."""
     st, params, m, v = model._ensure_train_state()
     for p in params:
         dist.broadcast(p.data, src=0, group=group)
     model.network._rtx_shadow_versions.clear()      # parameters changed under the engines: refresh the shadows
     if comm_dtype is None:
         comm_dtype = torch.bfloat16 if getattr(model, "numerics", "fp32") == "bf16" else torch.float32
-    red = GradAllReducer(st.flat_grads, st.layer_ranges, group, min_bucket_bytes, comm_dtype, st.tensor_offsets)
-    red.bucket_adam = bool(bucket_adam)
+    shard_layers = {}
+    world = dist.get_world_size(group)
+    if sharded:
+        for l in range(len(params) // 2):
+            w = params[2 * l]
+            prow = (w.shape[0] + 1 + 127) // 128 * 128
+            if w.numel() * 4 >= min_bucket_bytes and prow % world == 0:
+                shard_layers[l] = (int(w.shape[0]), int(w.shape[1]), prow)
+    red = GradAllReducer(st.flat_grads, st.layer_ranges, group, min_bucket_bytes, comm_dtype, st.tensor_offsets, shard_layers)
+    red.bucket_adam = bool(bucket_adam) or bool(shard_layers)
+    red.sharded = bool(shard_layers)
     if fixed_global_batch is not None:
         red.global_batch = lambda local, _g=int(fixed_global_batch): _g
     st.reducer = red

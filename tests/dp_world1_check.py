@@ -23,7 +23,7 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
-def run(g, comm_dtype, bucket_adam, min_bucket):
+def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False):
     enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
     beta, anneal, p, lr = [float(v) for v in g["meta"]]
     net = MultiVAE_net(dec, enc, dropout=p)
@@ -31,13 +31,14 @@ def run(g, comm_dtype, bucket_adam, min_bucket):
     net.to("cuda")
     model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
     if comm_dtype is not None:
-        red = parallel.attach(model, min_bucket_bytes=min_bucket, comm_dtype=comm_dtype, bucket_adam=bucket_adam)
-        assert len(red.buckets()) >= 2
+        red = parallel.attach(model, min_bucket_bytes=min_bucket, comm_dtype=comm_dtype, bucket_adam=bucket_adam, sharded=sharded)
+        assert len(red.buckets()) >= 2 and bool(red.shard_layers) == sharded
     losses = []
     for t in range(g["xs"].shape[0]):
         model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), dev(g["eps_%d" % t]))
         gt = torch.from_numpy(g["gts"][t]) if "gts" in g else None
         losses.append(model.train_batch(torch.from_numpy(g["xs"][t]), gt))
+    model._gather_sharded_state()
     torch.cuda.synchronize()
     return losses, [p_.detach().cpu().numpy().copy() for p_ in net._param_list()]
 
@@ -56,6 +57,11 @@ def main():
         sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % (g["xs"].shape[0] - 1)))
         for k, a, b in zip(keys, params, sd_t):
             assert float(np.max(np.abs(a - b))) < 5e-6, (bucket_adam, k)
+    # sharded optimizer with one rank: in-place RCCL reduce-scatter / all-gather over the whole matrices, same arithmetic
+    losses, params = run(g, torch.float32, True, 256, sharded=True)
+    assert losses == ref_losses, (losses, ref_losses)
+    for k, a, b in zip(keys, params, ref_params):
+        assert np.array_equal(a, b), ("sharded fp32 exchange must be bit-identical to the single-GPU step", k)
     for bucket_adam in (False, True):
         losses, params = run(g, torch.bfloat16, bucket_adam, 256)
         for k, a, b in zip(keys, params, ref_params):

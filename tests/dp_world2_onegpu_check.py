@@ -26,9 +26,14 @@ def dev(a, dtype=torch.float32):
 def main():
     rank, world, _ = parallel.init_from_env(backend="gloo")
     assert world == 2
-    for name, comm, bucket_adam, tol in (("g2b_mvae_train_step_te", torch.float32, True, 5e-6),
-                                         ("g2c_mvae_train_step_deep", torch.float32, False, 5e-6),
-                                         ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5)):
+    for name, comm, bucket_adam, tol, sharded in (("g2b_mvae_train_step_te", torch.float32, True, 5e-6, False),
+                                                  ("g2c_mvae_train_step_deep", torch.float32, False, 5e-6, False),
+                                                  ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5, False),
+                                                  # sharded optimizer: reduce-scatter, Adam on the local rows, all-gather of
+                                                  # the compute copies; the masters are gathered before they are compared
+                                                  ("g2b_mvae_train_step_te", torch.float32, True, 5e-6, True),
+                                                  ("g2c_mvae_train_step_deep", torch.float32, True, 5e-6, True),
+                                                  ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5, True)):
         g = load_golden(name)
         enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
         beta, anneal, p, lr = [float(v) for v in g["meta"]]
@@ -39,7 +44,8 @@ def main():
         net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
         net.to("cuda")
         model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
-        parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam)
+        red = parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam, sharded=sharded)
+        assert bool(red.shard_layers) == sharded
         _, keys = params_in_order(sd_from(g, "sd0__"))
         for t in range(g["xs"].shape[0]):
             B = g["xs"][t].shape[0]
@@ -50,6 +56,9 @@ def main():
             ref = float(g["loss_%d" % t])
             assert abs(loss - ref) < (1e-5 if comm == torch.float32 else 1e-5) * abs(ref), (name, t, loss, ref)
             sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
+            if sharded:
+                assert model._rtx.masters_sharded
+                model._gather_sharded_state()       # collective: every rank completes its float32 rows
             for k, prm, want in zip(keys, net._param_list(), sd_t):
                 dl = np.abs(prm.detach().cpu().numpy() - want)
                 if comm == torch.float32:

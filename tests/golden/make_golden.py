@@ -359,6 +359,7 @@ def g8():
 # ---------------------------------------------------------------- G9
 def g9():
     I, H, L = 12, 6, 3
+    torch.manual_seed(90)                # the reference's own random initialisation, reproducibly
     net = MultiVAE_net([L, H, I], dropout=0.5)
     model = MultiVAE(net, beta=0.2, anneal_steps=5)
     torch.manual_seed(9)
@@ -386,6 +387,22 @@ def g9():
     x = small_x(4, I, 10)
     pred = model.predict(torch.from_numpy(x), remove_train=True)[0].numpy()
     save("g9_checkpoint_predict", x=x, pred=pred, dims=np.array([I, H, L]))
+    # resume semantics (reference models.py:496-516, 905-908): a FRESH reference model loads the checkpoint file and takes
+    # one more training step -- the loaded Adam moments, step count and gradient_updates (-> annealed beta) all enter it
+    net2 = MultiVAE_net([L, H, I], dropout=0.5)
+    model2 = MultiVAE(net2, beta=0.2, anneal_steps=5)
+    ck2 = model2.load_model(os.path.join(HERE, "g9_reference_checkpoint.pth"))
+    xr = small_x(4, I, 11)
+    mask, eps = replay_rng(21, 4, I, L, 0.5)
+    torch.manual_seed(21)
+    loss = model2.train_batch(torch.from_numpy(xr), None)
+    opt2 = model2.optimizer.state_dict()
+    save("g9_resume_step", x=xr, mask=mask, eps=eps, loss=np.float64(loss), epoch=np.int64(ck2["epoch"]),
+         gradient_updates_after=np.float64(model2.gradient_updates),
+         step_after=np.float64(float(opt2["state"][0]["step"])),
+         **flat("sd__", sd_np(net2)),
+         **{"exp_avg_%d" % k: v["exp_avg"].numpy().copy() for k, v in opt2["state"].items()},
+         **{"exp_avg_sq_%d" % k: v["exp_avg_sq"].numpy().copy() for k, v in opt2["state"].items()})
 
 
 def g10():

@@ -172,12 +172,14 @@ static std::vector<float> d2h(const float* d, size_t n)
 }
 
 static int g_fail = 0;
-static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1;   // rtx_engine_set_option values applied to every engine a case creates
+static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 0, g_opt_ntreg = 0;   // rtx_engine_set_option values applied to every engine a case creates
 static void apply_options(rtx_engine* eng)
 {
     rtx_engine_set_option(eng, "fuse_adam", g_opt_fuse);
     rtx_engine_set_option(eng, "dw_cfg", g_opt_dw_cfg);
     rtx_engine_set_option(eng, "lse_fuse", g_opt_lse);
+    rtx_engine_set_option(eng, "two_stream", g_opt_two);
+    rtx_engine_set_option(eng, "nt_regstage", g_opt_ntreg);
 }
 static void check(const char* what, double err, double tol)
 {
@@ -424,7 +426,7 @@ static void philox_case()
 
 static void perf_case(int numerics, int B, int steps, int splitk)
 {
-    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d\n", numerics ? "bf16" : "fp32", B, splitk);
+    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d nt_regstage=%d dw_cfg=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_ntreg, g_opt_dw_cfg);
     Net net = make_net({20108, 600, 200}, {200, 600, 20108}, ORC_VAE, 0.5f, 0.1f);
     const int I = 20108, U = 4096;
     Csr tr;
@@ -522,17 +524,26 @@ int main(int argc, char** argv)
         g_opt_lse = 0;
         parity_case("wide-vae-nolsefuse", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_lse = 1;
+        g_opt_two = 1;
+        parity_case("wide-vae-two-streams", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+        parity_case("mid-dae-two-streams", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
+        g_opt_two = 0;
+        g_opt_ntreg = 1;
+        parity_case("wide-vae-nt-regstage", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+        g_opt_ntreg = 0;
         parity_case("mid-dae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
     }
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
-        for (int cfg = 0; cfg < 3; ++cfg) { g_opt_dw_cfg = cfg; perf_case(RTX_BF16, B, 50, 0); }
-        g_opt_dw_cfg = 0;
-        g_opt_fuse = 0;
-        perf_case(RTX_BF16, B, 50, 0);
-        g_opt_fuse = 1;
-        for (int sk : {16, 32}) perf_case(RTX_BF16, B, 50, sk);
-        perf_case(RTX_FP32, B, 20, 0);
+        perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration
+        g_opt_two = 1; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 0;     // weight-gradient kernels on a side stream
+        g_opt_ntreg = 1; perf_case(RTX_BF16, B, 50, 0);                  // register-staged NT GEMMs (+ LSE pass in the loss kernel)
+        g_opt_two = 1; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 0; g_opt_ntreg = 0;
+        g_opt_dw_cfg = 2; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0;
+        if (argc > 3) {
+            g_opt_fuse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_fuse = 1;
+            perf_case(RTX_FP32, B, 20, 0);
+        }
     }
     printf("%s (%d failing checks)\n", g_fail ? "ENGINE TESTS FAILED" : "ENGINE TESTS PASSED", g_fail);
     return g_fail ? 1 : 0;

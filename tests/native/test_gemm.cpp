@@ -338,7 +338,18 @@ static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_rea
     const float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const int step = 3;
     const float step_size = (float)(lr / (1.0 - pow((double)b1, step))), bc2 = (float)sqrt(1.0 - pow((double)b2, step));
+    std::vector<float> hbp(Mp), hbm(Mp), hbv(Mp);
+    for (int i = 0; i < Mp; ++i) { hbp[i] = frand(); hbm[i] = frand() * 0.01f; hbv[i] = fabsf(frand()) * 1e-4f; }
+    float *bp, *bm, *bv, *bss;
+    CK(hipMalloc(&bp, Mp * 4)); CK(hipMalloc(&bm, Mp * 4)); CK(hipMalloc(&bv, Mp * 4)); CK(hipMalloc(&bss, 4));
+    CK(hipMemcpy(bp, hbp.data(), Mp * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bm, hbm.data(), Mp * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(bv, hbv.data(), Mp * 4, hipMemcpyHostToDevice));
+    double bssd = 0;
+    for (int i = 0; i < M_real; ++i) bssd += (double)hbp[i] * hbp[i];
+    const float hbss = (float)bssd;
+    CK(hipMemcpy(bss, &hbss, 4, hipMemcpyHostToDevice));
     if (epi == RTX_DW_ADAM) {
+        d.bias_p = bp; d.bias_m = bm; d.bias_v = bv; d.bias_sumsq = lam != 0.f ? bss : nullptr;
         d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.gkeep = keep ? gk : nullptr; d.adam.sh = sh; d.adam.ld_sh = Np;
         d.adam.step_size = step_size; d.adam.bc2_sqrt = bc2; d.adam.beta1 = b1; d.adam.beta2 = b2; d.adam.eps = eps; d.adam.weight_decay = wd;
         d.adam.lam = lam; d.adam.sumsq = lam != 0.f ? sumsq : nullptr;
@@ -354,6 +365,9 @@ static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_rea
     CK(hipMemcpy(gv.data(), v, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gg.data(), gk, P * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(ggb.data(), gb, Mp * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gsh.data(), sh, gsh.size() * 2, hipMemcpyDeviceToHost));
     CK(hipMemcpy(gg16.data(), g16, P * 2, hipMemcpyDeviceToHost));
+    std::vector<float> gbp(Mp), gbm(Mp), gbv(Mp);
+    CK(hipMemcpy(gbp.data(), bp, Mp * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gbm.data(), bm, Mp * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gbv.data(), bv, Mp * 4, hipMemcpyDeviceToHost));
     long bad = 0;
     int printed = 0;
     double e_g = 0, e_p = 0, e_m = 0, e_v = 0;
@@ -365,6 +379,18 @@ static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_rea
             if (c == N_real) {
                 const double e = fabs(ggb[r] - ref);
                 if (!(e <= 1e-4 * sqrt((double)K_real))) { ++bad; if (printed++ < 5) printf("   bias grad row %d: got %.6f ref %.6f\n", r, ggb[r], ref); }
+                if (epi == RTX_DW_ADAM) {   // the bias took its Adam step in the same launch
+                    const float breg = lam != 0.f ? lam / sqrtf(hbss) : 0.f;
+                    float g1 = ggb[r] + breg * hbp[r];
+                    if (wd != 0.f) g1 += wd * hbp[r];
+                    const float m1 = hbm[r] + (g1 - hbm[r]) * (1.f - b1);
+                    const float v1 = hbv[r] * b2 + (1.f - b2) * g1 * g1;
+                    const float p1 = hbp[r] - step_size * (m1 / (sqrtf(v1) / bc2 + eps));
+                    if (!(fabs(gbp[r] - p1) <= 2e-6 && fabs(gbm[r] - m1) <= 2e-6 && fabs(gbv[r] - v1) <= 2e-6)) {
+                        ++bad;
+                        if (printed++ < 5) printf("   bias adam row %d: p %.7f/%.7f m %.7f/%.7f\n", r, gbp[r], p1, gbm[r], m1);
+                    }
+                }
                 continue;
             }
             const size_t o = (size_t)r * N_real + c;
@@ -402,6 +428,7 @@ static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_rea
     printf("[dw %s] cfg%d epi=%d %dx%d K=%d lam=%.2f wd=%.3f keep=%d  err g=%.2e p=%.2e m=%.2e v=%.2e bad=%ld -> %s\n", name, cfg, epi, M_real, N_real, K_real,
            lam, wd, keep, e_g, e_p, e_m, e_v, bad, bad ? "FAIL" : "ok");
     hipFree(D); hipFree(X); hipFree(p); hipFree(m); hipFree(v); hipFree(gk); hipFree(g16); hipFree(gb); hipFree(sh); hipFree(sumsq);
+    hipFree(bp); hipFree(bm); hipFree(bv); hipFree(bss);
     return bad != 0;
 }
 
@@ -523,7 +550,7 @@ int main(int argc, char** argv)
         fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
     }
     fails += tr_probe();
-    for (int cfg = 0; cfg < 3; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages)
+    for (int cfg = 0; cfg < 4; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages), 128x128 (2 stages)
         for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
             fails += run_dma_case("store", form, cfg, 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, 0);
             fails += run_dma_case("splitk3", form, cfg, 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, 0);
@@ -553,6 +580,7 @@ int main(int argc, char** argv)
         // the step's big contractions on the LDS-DMA kernels: logits, fwd-1 / dH3 (split-K), fused dW + Adam
         perf_dma("logits", RTX_FORM_NT, RTX_DMA_512x128, 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS);
         perf_dma("logits", RTX_FORM_NT, RTX_DMA_128x128, 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS);
+        perf_dma("logits", RTX_FORM_NT, RTX_DMA_256x256, 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS);
         perf_dma("logits-store", RTX_FORM_NT, RTX_DMA_512x128, 512, 20224, 640, 1, RTX_EPI_STORE);
         for (int sp : {23, 32, 46}) perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_512x128, 512, 640, 20224, sp, RTX_EPI_STORE);
         for (int sp : {23, 32, 46}) perf_dma("dH3", RTX_FORM_NN, RTX_DMA_512x128, 512, 640, 20224, sp, RTX_EPI_STORE);
@@ -560,6 +588,8 @@ int main(int argc, char** argv)
         perf_dma("hidden", RTX_FORM_NT, RTX_DMA_128x128, 512, 512, 640, 5, RTX_EPI_STORE);
         perf_dma("hidden", RTX_FORM_NT, RTX_DMA_128x128, 512, 512, 640, 1, RTX_EPI_STORE);
         perf_dma("hidden", RTX_FORM_NN, RTX_DMA_128x128, 512, 640, 512, 4, RTX_EPI_STORE);
+        for (int sp : {12, 24}) perf_dma("dH3", RTX_FORM_NN, RTX_DMA_128x128_S2, 512, 640, 20224, sp, RTX_EPI_STORE);
+        perf_dma("dH3", RTX_FORM_NN, RTX_DMA_128x128, 512, 640, 20224, 12, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NN, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_512x128, 4096, 4096, 4096, 1, RTX_EPI_STORE);
