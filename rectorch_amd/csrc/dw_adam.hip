@@ -48,23 +48,30 @@ template <int N> __device__ __forceinline__ void dw_wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-struct DwFrag {
-    dw_u32x2 alo, ahi, blo, bhi;
+template <int NJ> struct DwFrag {
+    dw_u32x2 alo, ahi, blo[NJ], bhi[NJ];
 };
 
-template <int TMW, int NS, int EPI>
-__global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
+// p / exp_avg / exp_avg_sq are touched once per step: non-temporal loads and stores keep them from evicting the operand
+// panels (D, activations) that every tile of a run re-reads from L2
+__device__ __forceinline__ dw_f32x4 dw_ld_nt(const float* p) { return __builtin_nontemporal_load((const dw_f32x4*)p); }
+__device__ __forceinline__ void dw_st_nt(float* p, dw_f32x4 v) { __builtin_nontemporal_store(v, (dw_f32x4*)p); }
+
+// WM x WN waves; a wave owns 32 x (128 / WN) of the tile (NJ = 4 / WN accumulators): tile = (32 WM) x 128
+template <int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn(const RtxDw p)
 {
-    constexpr int NW = TMW * 4, NTH = NW * 64, TM = TMW * 32;
+    constexpr int NW = WM * WN, NTH = NW * 64, TM = WM * 32, NJ = 4 / WN;
     constexpr int SA = TM * 2, SBB = 256;                       // bytes of one k-row of the A / B slice images
-    constexpr int ABYTES = 64 * SA, STAGE = ABYTES + 64 * SBB;  // 4 or 8 KB + 16 KB
-    constexpr int QB = 16 / NW, LPS = 1 + QB;
-    constexpr int RPP = NTH / 32;                               // tile rows per epilogue pass (4 passes)
+    constexpr int ABYTES = 64 * SA, STAGE = ABYTES + 64 * SBB;  // 4 / 8 / 16 KB + 16 KB
+    constexpr int QA = (ABYTES / 1024 + NW - 1) / NW, QB = 16 / NW, LPS = QA + QB;
+    constexpr int RPP = NTH / 32, NP = TM / RPP;                // tile rows per epilogue pass, passes
+    static_assert(WN * NJ == 4 && (ABYTES / 1024) % NW == 0 && 16 % NW == 0, "tile shape: whole DMA instructions per wave");
     static_assert(TM * 128 * 4 <= NS * STAGE, "the parked gradient tile must fit in the stages");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, g = lane >> 5;
 
     // tile order: short dimension fastest, one contiguous run per XCD (workgroup b runs on XCD b % 8: speed only)
@@ -81,29 +88,30 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
     // ---- optimizer state of this tile: issued before anything else, consumed after the K walk -------------------------
     const int col4 = (tid & 31) * 4, rowl = tid >> 5;
     const int col = tn * 128 + col4;
-    dw_f32x4 pv[4], mv[4], vv[4];
+    dw_f32x4 pv[NP], mv[NP], vv[NP];
     if constexpr (EPI == RTX_DW_ADAM) {
         // out-of-range threads load a clamped (valid) address instead of branching around the load: a branch per load
         // makes hipcc wait vmcnt(0) behind each one
         const int colc = min(col, p.N_real - 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NP; ++q) {
             const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
             const size_t off = (size_t)rowc * p.N_real + colc;
-            pv[q] = *(const dw_f32x4*)(p.adam.p + off);
-            mv[q] = *(const dw_f32x4*)(p.adam.m + off);
-            vv[q] = *(const dw_f32x4*)(p.adam.v + off);
+            pv[q] = dw_ld_nt(p.adam.p + off);
+            mv[q] = dw_ld_nt(p.adam.m + off);
+            vv[q] = dw_ld_nt(p.adam.v + off);
         }
     }
 
     // ---- DMA source addresses ---------------------------------------------------------------------------------------------
     const size_t rowA = (size_t)p.lda * 2, rowB = (size_t)p.ldb * 2;
-    const unsigned char* gA;
-    {
-        const int o = wave * 1024 + lane * 16;          // physical byte of this lane's piece in the A slice image
+    const unsigned char* gA[QA];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int o = (wave + q * NW) * 1024 + lane * 16;   // physical byte of this lane's piece in the A slice image
         const int rr = o / SA, ww = o % SA;
-        const int cc = (SA == 128) ? ((ww >> 6) ^ ((rr >> 1) & 1)) : 0;
-        gA = (const unsigned char*)p.A + (size_t)rr * rowA + (size_t)tm * TM * 2 + (cc << 6) + (ww & 63);
+        const int cc = (SA >= 256) ? ((ww >> 6) ^ (rr & 3)) : (SA == 128) ? ((ww >> 6) ^ ((rr >> 1) & 1)) : 0;
+        gA[q] = (const unsigned char*)p.A + (size_t)rr * rowA + (size_t)tm * TM * 2 + (cc << 6) + (ww & 63);
     }
     const unsigned char* gB[QB];
 #pragma unroll
@@ -116,7 +124,10 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
     dw_lds_byte* lbase = (dw_lds_byte*)smem;
     auto load_slice = [&](int stage, int t) __attribute__((always_inline)) {
         dw_lds_byte* sb = lbase + stage * STAGE + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const void*)(gA + (size_t)t * 64 * rowA), (void __attribute__((address_space(3)))*)sb, 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < QA; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(gA[q] + (size_t)t * 64 * rowA),
+                                             (void __attribute__((address_space(3)))*)(sb + q * NW * 1024), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < QB; ++q)
             __builtin_amdgcn_global_load_lds((const void*)(gB[q] + (size_t)t * 64 * rowB),
@@ -126,28 +137,38 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
     // ---- fragment addressing: a transposing read hands the 16 lanes of a group a [4 k][16 x] block (lane p fetches 8 bytes
     //      at k-row p >> 2, column (p & 3) * 4; lane i receives column i of the 4 rows).  Group g4 = lane >> 4: column half
     //      g4 & 1, k-group g4 >> 1 -- the MFMA 32x32x16 operand layout (lane = (row & 31, k-group)). ---------------------------
-    unsigned offA, offB;
+    unsigned offA, offB[NJ];
     {
         const int p16 = lane & 15, g4 = lane >> 4, s = p16 >> 2;
-        const int ca = (SA == 128) ? (wm ^ (s >> 1)) : 0;
+        const int ca = (SA >= 256) ? (wm ^ s) : (SA == 128) ? (wm ^ (s >> 1)) : 0;   // a wave's 32 rows = one 64-byte granule
         offA = (unsigned)(((g4 >> 1) * 8 + s) * SA + (ca << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
-        offB = (unsigned)(ABYTES + ((g4 >> 1) * 8 + s) * SBB + ((wn ^ s) << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
-    }
-    dw_f32x16 acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int j = 0; j < NJ; ++j)
+            offB[j] = (unsigned)(ABYTES + ((g4 >> 1) * 8 + s) * SBB + (((wn * NJ + j) ^ s) << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
+    }
+    dw_f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    constexpr int NR = 2 + 2 * NJ;   // LDS reads per fragment set
 
 #define DW_FRAG(F, kk)                                                   \
     dw_rdtr<((kk)*16) * SA>(F.alo, sbase + offA);                         \
     dw_rdtr<((kk)*16 + 4) * SA>(F.ahi, sbase + offA);                     \
-    dw_rdtr<((kk)*16) * SBB>(F.blo, sbase + offB);                        \
-    dw_rdtr<((kk)*16 + 4) * SBB>(F.bhi, sbase + offB);
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                      \
+        dw_rdtr<((kk)*16) * SBB>(F.blo[j], sbase + offB[j]);              \
+        dw_rdtr<((kk)*16 + 4) * SBB>(F.bhi[j], sbase + offB[j]);          \
+    }
 #define DW_MMA(F)                                                                                                        \
     {                                                                                                                    \
-        dw_u32x4 a_, b_;                                                                                                 \
+        dw_u32x4 a_;                                                                                                     \
         a_[0] = F.alo[0]; a_[1] = F.alo[1]; a_[2] = F.ahi[0]; a_[3] = F.ahi[1];                                          \
-        b_[0] = F.blo[0]; b_[1] = F.blo[1]; b_[2] = F.bhi[0]; b_[3] = F.bhi[1];                                          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dw_bf16x8, a_), __builtin_bit_cast(dw_bf16x8, b_), acc, 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                                 \
+            dw_u32x4 b_;                                                                                                 \
+            b_[0] = F.blo[j][0]; b_[1] = F.blo[j][1]; b_[2] = F.bhi[j][0]; b_[3] = F.bhi[j][1];                          \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dw_bf16x8, a_), __builtin_bit_cast(dw_bf16x8, b_), acc[j], 0, 0, 0); \
+        }                                                                                                                \
     }
 
     const int nk = p.k_slices;   // >= 2
@@ -165,16 +186,16 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
         }
         {
             const unsigned sbase = (unsigned)(size_t)(lbase + stage * STAGE);
-            DwFrag x, y;
+            DwFrag<NJ> x, y;
             DW_FRAG(x, 0)
             DW_FRAG(y, 1)
-            dw_wait_lgkm<4>();
+            dw_wait_lgkm<NR>();
             DW_MMA(x)
             DW_FRAG(x, 2)
-            dw_wait_lgkm<4>();
+            dw_wait_lgkm<NR>();
             DW_MMA(y)
             DW_FRAG(y, 3)
-            dw_wait_lgkm<4>();
+            dw_wait_lgkm<NR>();
             DW_MMA(x)
             dw_wait_lgkm<0>();
             DW_MMA(y)
@@ -189,7 +210,9 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* tile = (float*)smem;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) tile[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * 128 + wn * 32 + r] = acc[e];
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * 128 + (wn * NJ + j) * 32 + r] = acc[j][e];
     __syncthreads();
 
     float reg = 0.f;
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
     }
     const bool vec = (p.N_real & 3) == 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NP; ++q) {
         const int lr = q * RPP + rowl;
         const int row = tm * TM + lr;
         const dw_f32x4 g4 = *(const dw_f32x4*)(tile + lr * 128 + col4);
@@ -246,9 +269,9 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
                 mn[k] = m1;
                 vn[k] = v1;
             }
-            *(dw_f32x4*)(A.p + off) = pn;
-            *(dw_f32x4*)(A.m + off) = mn;
-            *(dw_f32x4*)(A.v + off) = vn;
+            dw_st_nt(A.p + off, pn);
+            dw_st_nt(A.m + off, mn);
+            dw_st_nt(A.v + off, vn);
             if (A.gkeep) *(dw_f32x4*)(A.gkeep + off) = g4;
             if (A.sh) store4<bf16_t>((bf16_t*)A.sh + (size_t)row * A.ld_sh + col, pn[0], pn[1], pn[2], pn[3]);
         } else {
@@ -267,29 +290,31 @@ __global__ __launch_bounds__(TMW * 256, 4) void rtx_dw_tn(const RtxDw p)
     }
 }
 
-template <int TMW, int NS, int EPI> static int dw_launch(const RtxDw& d, hipStream_t stream)
+template <int WM, int WN, int NS, int EPI> static int dw_launch(const RtxDw& d, hipStream_t stream)
 {
-    constexpr int TM = TMW * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
+    constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<TMW, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     const int total = d.m_tiles * d.n_tiles;
     const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
-    hipLaunchKernelGGL((rtx_dw_tn<TMW, NS, EPI>), grid, dim3(TMW * 256), LDS, stream, d);
+    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI>), grid, dim3(WM * WN * 64), LDS, stream, d);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
 
-int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : 32; }
+int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : cfg == RTX_DW_128x128 ? 128 : 32; }
 
 template <int EPI> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
 {
     switch (cfg) {
-    case RTX_DW_32x128: return dw_launch<1, 3, EPI>(d, stream);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
-    case RTX_DW_32x128_S2: return dw_launch<1, 2, EPI>(d, stream);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
-    default: return dw_launch<2, 3, EPI>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
+    case RTX_DW_32x128: return dw_launch<1, 4, 3, EPI>(d, stream);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
+    case RTX_DW_32x128_S2: return dw_launch<1, 4, 2, EPI>(d, stream);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
+    case RTX_DW_128x128: return dw_launch<4, 2, 2, EPI>(d, stream);     // 8 waves, 2 stages (64 KB), 32 x 64 per wave: half the
+                                                                         //   operand bytes per parameter of the 64-row tile
+    default: return dw_launch<2, 4, 3, EPI>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
     }
 }
 
@@ -299,7 +324,7 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     RTX_CHECK(d.A && d.B && d.m_tiles > 0 && d.n_tiles > 0 && d.k_slices >= 2, RTX_EINVAL, "dw: bad problem (%d x %d tiles, %d K slices)", d.m_tiles, d.n_tiles,
               d.k_slices);
     RTX_CHECK(epilogue == RTX_DW_GRAD || epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw: bad epilogue %d", epilogue);
-    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_32x128_S2, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
     if (epilogue == RTX_DW_ADAM) {
         RTX_CHECK((d.N_real & 3) == 0 && d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of a multiple of 4 floats (got %d)", d.N_real);

@@ -50,7 +50,8 @@ __device__ __forceinline__ int64_t csr_row(const RtxCsrView& v, int b) { return 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
 {
-    __shared__ __attribute__((aligned(16))) T row[RTX_GATHER_CHUNK];
+    constexpr int CH = 16384 / sizeof(T);   // elements per 16-KB LDS chunk
+    __shared__ __attribute__((aligned(16))) T row[CH];
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     T* X = (T*)a.X + (size_t)b * a.ldx;
@@ -62,29 +63,40 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
     const int64_t u = csr_row(a.in, b);
     const int64_t beg = a.in.indptr[u], end = a.in.indptr[u + 1];
     // ||x||_2 over the stored entries (F.normalize: x / max(||x||, 1e-12)); a conditioned row (Iin > I) is normalised
-    // over its item columns only (CMultiVAE_net.encode, reference nets.py:467-471)
+    // over its item columns only (CMultiVAE_net.encode, reference nets.py:467-471).  Implicit feedback (no value array,
+    // no condition columns): the squared norm and the target sum are just the numbers of stored entries.
     const bool cond = a.Iin > a.I;
-    float ss = 0.f;
-    for (int64_t k = beg + tid; k < end; k += 256) {
-        const float v = a.in.values ? a.in.values[k] : 1.f;
-        if (!cond || a.in.indices[k] < a.I) ss += v * v;
+    float ss;
+    if (!a.in.values && !cond) {
+        ss = (float)(end - beg);
+    } else {
+        ss = 0.f;
+        for (int64_t k = beg + tid; k < end; k += 256) {
+            const float v = a.in.values ? a.in.values[k] : 1.f;
+            if (!cond || a.in.indices[k] < a.I) ss += v * v;
+        }
+        ss = block_sum(ss, red);
     }
-    ss = block_sum(ss, red);
     const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
     // s_b = sum of the TARGET row
     {
         const int64_t ut = csr_row(a.target, b);
         const int64_t tb = a.target.indptr[ut], te = a.target.indptr[ut + 1];
-        float ts = 0.f;
-        for (int64_t k = tb + tid; k < te; k += 256)
-            if (!cond || a.target.indices[k] < a.I) ts += a.target.values ? a.target.values[k] : 1.f;
-        ts = block_sum(ts, red);
+        float ts;
+        if (!a.target.values && !cond) {
+            ts = (float)(te - tb);
+        } else {
+            ts = 0.f;
+            for (int64_t k = tb + tid; k < te; k += 256)
+                if (!cond || a.target.indices[k] < a.I) ts += a.target.values ? a.target.values[k] : 1.f;
+            ts = block_sum(ts, red);
+        }
         if (tid == 0) a.tsum[b] = ts;
     }
     const bool drop = a.training && a.dropout_p > 0.f;
     const float scale = drop ? (a.dropout_p < 1.f ? 1.f / (1.f - a.dropout_p) : 0.f) : 1.f;
-    for (int c0 = 0; c0 < a.ldx; c0 += RTX_GATHER_CHUNK) {
-        const int cn = min(RTX_GATHER_CHUNK, a.ldx - c0);
+    for (int c0 = 0; c0 < a.ldx; c0 += CH) {
+        const int cn = min(CH, a.ldx - c0);
         for (int i = tid * 4; i < cn; i += 256 * 4) store4<T>(row + i, 0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         for (int64_t k = beg + tid; k < end; k += 256) {
@@ -221,17 +233,21 @@ __global__ __launch_bounds__(256) void k_vae_fwd(const RtxVaeFwdArgs a)
     const int tid = threadIdx.x;
     const int j = blockIdx.x * 64 + (tid & 63), b0 = blockIdx.y * 16;
     const float* __restrict__ C = a.C;
-    float m[4], lv[4];
+    // slab sums: every load of a split is issued before the first add (out-of-range threads read a valid, clamped
+    // address and are masked later: a branch around the loads would serialise them)
+    float m[4] = {0.f, 0.f, 0.f, 0.f}, lv[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int jc = min(j, a.Z - 1);
+        const float* base[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int b = b0 + k * 4 + (tid >> 6);
-        m[k] = 0.f; lv[k] = 0.f;
-        if (b < a.B && j < a.Z) {
-            for (int s = 0; s < a.splits; ++s) {
-                const float* c = C + (size_t)s * a.slab_stride + (size_t)b * a.ldc;
-                m[k] += c[j];
-                lv[k] += c[a.Z + j];
-            }
+        for (int k = 0; k < 4; ++k) base[k] = C + (size_t)min(b0 + k * 4 + (tid >> 6), a.Bp - 1) * a.ldc + jc;
+#pragma unroll 2
+        for (int s = 0; s < a.splits; ++s) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { t0[k] = base[k][(size_t)s * a.slab_stride]; t1[k] = base[k][(size_t)s * a.slab_stride + a.Z]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { m[k] += t0[k]; lv[k] += t1[k]; }
         }
     }
 #pragma unroll
@@ -274,15 +290,24 @@ __global__ __launch_bounds__(256) void k_vae_bwd(const RtxVaeBwdArgs a)
     const int n = blockIdx.x * 64 + (tid & 63), b0 = blockIdx.y * 16;
     const float* __restrict__ C = a.C;
     const int j = (n < a.Z) ? n : n - a.Z;
-    float dz[4], mu[4], lv[4], ep[4];
+    float dz[4] = {0.f, 0.f, 0.f, 0.f}, mu[4], lv[4], ep[4];
+    {
+        const int jc = min(j, a.Z - 1);
+        const float* base[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int b = b0 + k * 4 + (tid >> 6);
-        dz[k] = 0.f; mu[k] = 0.f; lv[k] = 0.f; ep[k] = 0.f;
-        if (b < a.B && n < 2 * a.Z) {
-            for (int s = 0; s < a.splits; ++s) dz[k] += C[(size_t)s * a.slab_stride + (size_t)b * a.ldc + j];
-            const size_t o = (size_t)b * a.Z + j;
+        for (int k = 0; k < 4; ++k) {
+            const int bc = min(b0 + k * 4 + (tid >> 6), a.Bp - 1);
+            base[k] = C + (size_t)bc * a.ldc + jc;
+            const size_t o = (size_t)min(bc, a.B - 1) * a.Z + jc;
             mu[k] = a.mu32[o]; lv[k] = a.lv32[o]; ep[k] = a.eps32[o];
+        }
+#pragma unroll 2
+        for (int s = 0; s < a.splits; ++s) {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = base[k][(size_t)s * a.slab_stride];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dz[k] += t[k];
         }
     }
 #pragma unroll

@@ -106,15 +106,51 @@ class TorchNNTrainer(RecSysModel):
         raise NotImplementedError()
 
     def __str__(self):
-        s = self.__class__.__name__ + "(\n"
-        for k, v in self.__dict__.items():
-            sv = "\n".join(["  "+line for line in str(str(v)).split("\n")])[2:]
-            s += "  %s = %s,\n" % (k, sv)
-        s = s[:-2] + "\n)"
-        return s
+        # "ClassName(\n  attr = value,\n  ...\n)" with multi-line values indented under their attribute -- the layout of
+        # the reference's repr (models.py:313-322), which its users read in logs
+        fields = []
+        for name, value in vars(self).items():
+            first, *rest = str(value).split("\n")
+            fields.append("  %s = %s" % (name, "\n".join([first] + ["  " + ln for ln in rest])))
+        return "%s(\n%s\n)" % (type(self).__name__, ",\n".join(fields))
 
-    def __repr__(self):
-        return str(self)
+    __repr__ = __str__
+
+
+class _EpochLog:
+    """The reference's progress lines for one epoch (models.py:401-422): every ``max(10, n_batches // 10**verbose)``
+    batches ``| epoch e | i/n batches | ms/batch t | loss l |`` with the mean loss of that stretch, at the end
+    ``| epoch e | loss L | total time: Ts |`` with the mean over all batches.  One implementation for every trainer."""
+    def __init__(self, epoch, n_batches, verbose):
+        self.epoch, self.n_batches = epoch, n_batches
+        self.every = max(10, n_batches // 10 ** verbose)
+        self.t_epoch = self.t_stretch = time.time()
+        self.total = 0.0
+
+    def due(self, n_done):
+        return n_done % self.every == 0
+
+    def stretch(self, n_done, loss_sum):
+        """close a stretch of ``every`` batches whose losses sum to ``loss_sum``"""
+        now = time.time()
+        logger.info('| epoch %d | %d/%d batches | ms/batch %.2f | loss %.2f |', self.epoch, n_done, self.n_batches,
+                    (now - self.t_stretch) * 1000 / self.every, loss_sum / self.every)
+        self.total += loss_sum
+        self.t_stretch = time.time()
+
+    def finish(self, tail_loss_sum):
+        logger.info("| epoch %d | loss %.4f | total time: %.2fs |", self.epoch,
+                    (self.total + tail_loss_sum) / self.n_batches, time.time() - self.t_epoch)
+
+
+def _validate(model, epoch, valid_data, valid_metric, valid_func):
+    """one validation pass + the reference's log line; returns the mean of the metric (models.py:389-398, 881-889)"""
+    assert valid_metric is not None, \
+        "In case of validation 'valid_metric' must be provided"
+    per_user = valid_func(model, valid_data, valid_metric)
+    mean = np.mean(per_user)
+    logger.info('| epoch %d | %s %.3f (%.4f) |', epoch, valid_metric, mean, np.std(per_user) / np.sqrt(len(per_user)))
+    return mean
 
 
 class AETrainer(TorchNNTrainer):
@@ -133,8 +169,9 @@ class AETrainer(TorchNNTrainer):
         self.optimizer = optim.Adam(self.network.parameters(), lr=learning_rate)
         self.numerics = numerics
         self.predict_numerics = predict_numerics
-        # the single-GPU step fuses Adam into the weight-gradient GEMMs of the big matrices, so their gradients
-        # never reach HBM; set True to also materialise them in p.grad (costs the 4 B/param store back)
+        # the single-GPU bf16 step runs Adam inside the weight-gradient kernels (dw_adam.hip), so the gradients never
+        # reach HBM and p.grad is NOT refreshed; set True to also store them (4 B/param).  float32 numerics and the
+        # data-parallel step always store them.
         self.keep_grads = False
         self._rtx = _RtxState()
 
@@ -152,58 +189,35 @@ class AETrainer(TorchNNTrainer):
               valid_func=ValidFunc(evaluate),
               num_epochs=100,
               verbose=1):
-        r"""Training of a neural network-based model (reference models.py:379-398)."""
+        r"""Training of a neural network-based model (reference models.py:379-398): ``num_epochs`` epochs, each followed
+        by a validation pass when ``valid_data`` is given; Ctrl-C ends training early with a warning."""
         try:
             for epoch in range(1, num_epochs + 1):
                 self.train_epoch(epoch, train_data, verbose)
                 if valid_data is not None:
-                    assert valid_metric is not None, \
-                                "In case of validation 'valid_metric' must be provided"
-                    valid_res = valid_func(self, valid_data, valid_metric)
-                    mu_val = np.mean(valid_res)
-                    std_err_val = np.std(valid_res) / np.sqrt(len(valid_res))
-                    logger.info('| epoch %d | %s %.3f (%.4f) |',
-                                epoch, valid_metric, mu_val, std_err_val)
+                    _validate(self, epoch, valid_data, valid_metric, valid_func)
         except KeyboardInterrupt:
             logger.warning('Handled KeyboardInterrupt: exiting from training early')
 
     def train_epoch(self, epoch, train_loader, verbose=1):
-        r"""Training of a single epoch (reference models.py:401-422): same loop, same log lines.  With a
-        device-resident :class:`DataSampler` the batches are row numbers, steps are enqueued back to back
-        and the loss is read from the device only every ``log_delay`` batches."""
+        r"""Training of a single epoch (reference models.py:401-422): same progress lines.  With a device-resident
+        :class:`DataSampler` the batches are row numbers, steps are enqueued back to back and the loss is read from the
+        device only where a progress line needs it (the engine keeps a running sum)."""
         self.network.train()
-        train_loss = 0
-        partial_loss = 0
-        epoch_start_time = time.time()
-        start_time = time.time()
-        log_delay = max(10, len(train_loader) // 10**verbose)
-
-        fast = isinstance(train_loader, DataSampler) and train_loader.resident
-        batches = train_loader.iter_rows() if fast else train_loader
-        for batch_idx, item in enumerate(batches):
-            if fast:
-                if not self._uses_te and item.te is not None:
-                    item = RowBatch(item.tr, None, item.rows)
-                self._fused_step(item, None, want_loss=False)
+        log = _EpochLog(epoch, len(train_loader), verbose)
+        resident = isinstance(train_loader, DataSampler) and train_loader.resident
+        pending = 0.0                       # host path: losses of the current stretch
+        for done, item in enumerate(train_loader.iter_rows() if resident else train_loader, 1):
+            if resident:
+                rows = item if self._uses_te or item.te is None else RowBatch(item.tr, None, item.rows)
+                self._fused_step(rows, None, want_loss=False)
             else:
                 data, gt = item
-                partial_loss += self.train_batch(data, gt)
-            if (batch_idx+1) % log_delay == 0:
-                if fast:
-                    partial_loss = self._read_loss_sum()
-                elapsed = time.time() - start_time
-                logger.info('| epoch %d | %d/%d batches | ms/batch %.2f | loss %.2f |',
-                            epoch, (batch_idx+1), len(train_loader),
-                            elapsed * 1000 / log_delay,
-                            partial_loss / log_delay)
-                train_loss += partial_loss
-                partial_loss = 0.0
-                start_time = time.time()
-        if fast:
-            partial_loss = self._read_loss_sum()
-        total_loss = (train_loss + partial_loss) / len(train_loader)
-        time_diff = time.time() - epoch_start_time
-        logger.info("| epoch %d | loss %.4f | total time: %.2fs |", epoch, total_loss, time_diff)
+                pending += self.train_batch(data, gt)
+            if log.due(done):
+                log.stretch(done, self._read_loss_sum() if resident else pending)
+                pending = 0.0
+        log.finish(self._read_loss_sum() if resident else pending)
 
     def train_batch(self, tr_batch, te_batch=None):
         r"""Training of a single batch (reference models.py:424-447): the loss target is the batch itself
@@ -507,24 +521,18 @@ class MultiVAE(VAE):
               num_epochs=200,
               best_path="chkpt_best.pth",
               verbose=1):
-        r"""Training procedure for Multi-VAE (reference models.py:837-895): per epoch ``train_epoch``, then
-        validation with ``valid_func`` and a checkpoint to ``best_path`` whenever the mean of
-        ``valid_metric`` improves."""
+        r"""Training procedure for Multi-VAE (reference models.py:837-895): per epoch ``train_epoch``, then -- when
+        ``valid_data`` is truthy, as in the reference -- validation with ``valid_func`` and a checkpoint to ``best_path``
+        whenever the mean of ``valid_metric`` improves on the best so far (metrics are assumed non-negative)."""
+        best = -1.
         try:
-            best_perf = -1. #Assume the higher the better >= 0
             for epoch in range(1, num_epochs + 1):
                 self.train_epoch(epoch, train_data, verbose)
                 if valid_data:
-                    assert valid_metric is not None, \
-                                "In case of validation 'valid_metric' must be provided"
-                    valid_res = valid_func(self, valid_data, valid_metric)
-                    mu_val = np.mean(valid_res)
-                    std_err_val = np.std(valid_res) / np.sqrt(len(valid_res))
-                    logger.info('| epoch %d | %s %.3f (%.4f) |',
-                                epoch, valid_metric, mu_val, std_err_val)
-                    if best_perf < mu_val:
+                    score = _validate(self, epoch, valid_data, valid_metric, valid_func)
+                    if score > best:
                         self.save_model(best_path, epoch)
-                        best_perf = mu_val
+                        best = score
         except KeyboardInterrupt:
             logger.warning('Handled KeyboardInterrupt: exiting from training early')
 
@@ -759,29 +767,6 @@ class SVAE(MultiVAE):
         eng.train_step(tr_batch, te_batch, step, st.loss_buf[0:1], st.loss_buf[1:2])
         self.gradient_updates += 1.
         return st.loss_buf[0].item()
-
-    def train_epoch(self, epoch, train_loader, verbose=1):
-        r"""One pass over the user sequences (reference models.py:401-422, the loop of ``AETrainer``)."""
-        self.network.train()
-        train_loss = 0
-        partial_loss = 0
-        epoch_start_time = time.time()
-        start_time = time.time()
-        log_delay = max(10, len(train_loader) // 10**verbose)
-        for batch_idx, (data, gt) in enumerate(train_loader):
-            partial_loss += self.train_batch(data, gt)
-            if (batch_idx+1) % log_delay == 0:
-                elapsed = time.time() - start_time
-                logger.info('| epoch %d | %d/%d batches | ms/batch %.2f | loss %.2f |',
-                            epoch, (batch_idx+1), len(train_loader),
-                            elapsed * 1000 / log_delay,
-                            partial_loss / log_delay)
-                train_loss += partial_loss
-                partial_loss = 0.0
-                start_time = time.time()
-        total_loss = (train_loss + partial_loss) / len(train_loader)
-        time_diff = time.time() - epoch_start_time
-        logger.info("| epoch %d | loss %.4f | total time: %.2fs |", epoch, total_loss, time_diff)
 
     def predict(self, x, remove_train=True):
         r"""Scores of the step after the sequence ``x`` (reference models.py:1628-1635): ``(recon_x[:, -1, :], mu,

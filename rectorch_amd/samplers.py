@@ -33,22 +33,18 @@ class Sampler():
 
 
 class DataSampler(Sampler):
-    r"""Standard sampler returning batches without any particular constraint (reference samplers.py:43-107).
+    r"""Plain batches of users, in order or shuffled (counterpart of reference samplers.py:43-107).
 
-    Parameters
-    ----------
-    sparse_data_tr : :obj:`scipy.sparse.csr_matrix`
-        The training sparse user-item rating matrix.
-    sparse_data_te : :obj:`scipy.sparse.csr_matrix` [optional]
-        The test sparse user-item rating matrix (same shape), by default :obj:`None`.
-    batch_size : :obj:`int` [optional]
-        The size of the batches, by default 1.
-    shuffle : :obj:`bool` [optional]
-        Whether the data set must be randomly shuffled before creating the batches, by default ``True``.
-    device : :obj:`str` / :class:`torch.device` / ``None`` [optional, not in the reference]
-        ``None``: the MI355X if one is visible (resident CSR + gather kernel), else host tensors.
-        ``"cpu"`` forces the reference's host behaviour (yields ``torch.FloatTensor`` built with scipy);
-        it exists for host-only callers of the API and is not a compute path of this package.
+    Arguments (the first four are the reference's, positionally compatible; the attributes of the same names are public):
+
+    * ``sparse_data_tr`` -- scipy CSR matrix, one row per user: what the model reads.
+    * ``sparse_data_te`` -- optional CSR matrix of the same users: the second element of every yielded pair (held-out
+      items at evaluation time); ``None`` yields ``None`` there.
+    * ``batch_size`` -- users per batch (the last batch may be shorter); default 1.
+    * ``shuffle`` -- draw a fresh permutation of the users from numpy's GLOBAL generator at every ``iter()``; default on.
+    * ``device`` (not in the reference) -- ``None`` picks the MI355X when one is visible: the matrices are uploaded once
+      and batches are formed by the gather kernel; ``"cpu"`` reproduces the reference's host behaviour (scipy slicing +
+      ``toarray()``) for callers without a HIP device.  It is not a compute path of this package.
     """
     def __init__(self,
                  sparse_data_tr,
@@ -152,20 +148,10 @@ class ConditionedDataSampler(Sampler):
     objects (input rows, target rows) over small per-batch CSR matrices uploaded to HBM, so nothing dense of width
     ``n_items`` crosses PCIe.
 
-    Parameters
-    ----------
-    iid2cids : :obj:`dict` (key :obj:`int` - value :obj:`list` of :obj:`int`)
-        Maps each item (inner id) to the list of its valid conditions (integers in ``[0, n_cond)``).
-    n_cond : :obj:`int`
-        Number of possible conditions.
-    sparse_data_tr : :obj:`scipy.sparse.csr_matrix`
-        The training sparse user-item rating matrix.
-    sparse_data_te : :obj:`scipy.sparse.csr_matrix` [optional]
-        The test sparse user-item rating matrix (same shape), by default :obj:`None` (= the training matrix).
-    batch_size : :obj:`int` [optional]
-        The size of the batches, by default 1.
-    shuffle : :obj:`bool` [optional]
-        Whether the examples are shuffled (global numpy RNG, as in the reference) before batching, by default ``True``.
+    Arguments: ``iid2cids`` (dict item id -> list of the conditions, integers below ``n_cond``, the item satisfies),
+    ``n_cond`` (how many conditions exist), ``sparse_data_tr`` / ``sparse_data_te`` (CSR matrices of the users' input and
+    target items; the target defaults to the input), ``batch_size`` (examples per batch, default 1), ``shuffle``
+    (permute the examples with numpy's global generator before batching, default on), ``sparse`` (see above).
     """
     def __init__(self,
                  iid2cids,
@@ -249,11 +235,8 @@ class BalancedConditionedDataSampler(ConditionedDataSampler):
     unconditioned, plus for each condition *c* ``m = int(num_cond_examples * subsample / n_cond)`` users drawn with
     replacement (``np.random.choice``) among those knowing *c*.
 
-    Parameters
-    ----------
-    subsample : :obj:`float` [optional]
-        Fraction of the conditioned examples to keep, in (0, 1], by default 0.2.
-    (the others as in :class:`ConditionedDataSampler`; there is no ``shuffle`` argument, as in the reference)
+    ``subsample`` (in (0, 1], default 0.2) is the fraction of conditioned examples kept; the other arguments are
+    :class:`ConditionedDataSampler`'s, without ``shuffle`` (the reference has none here either).
     """
     def __init__(self,
                  iid2cids,
@@ -296,12 +279,7 @@ class EmptyConditionedDataSampler(Sampler):
     r"""Unconditioned batches for :class:`rectorch_amd.models.CMultiVAE` (reference samplers.py:341-419): like
     :class:`DataSampler`, with ``cond_size`` zero columns appended to the input rows.
 
-    Parameters
-    ----------
-    cond_size : :obj:`int`
-        Number of possible conditions.
-    sparse_data_tr, sparse_data_te, batch_size, shuffle
-        As in :class:`DataSampler`.
+    ``cond_size`` is the number of condition columns to append; the remaining arguments are :class:`DataSampler`'s.
     """
     def __init__(self,
                  cond_size,
@@ -349,22 +327,11 @@ class SVAE_Sampler(Sampler):
     With ``sparse=True`` (not in the reference) ``y`` is a :class:`rectorch_amd.engine.SvaeTarget` -- the same rows as
     a CSR on the device -- so no ``T x num_items`` dense tensor is built or copied per user.
 
-    Parameters
-    ----------
-    num_items : :obj:`int`
-        Number of items.
-    dict_data_tr : :obj:`dict` (key :obj:`int` - value :obj:`list` of :obj:`int`)
-        The users' item sequences (inner ids), keys ``0 .. n_users - 1``.
-    dict_data_te : :obj:`dict` or :obj:`None` [optional]
-        The users' test items (needed when ``is_training`` is ``False``), by default :obj:`None`.
-    pred_type : :obj:`str` in {``'next_k'``, ``'next'``, ``'postfix'``} [optional]
-        The variant of the target, by default ``'next_k'``.
-    k : :obj:`int` [optional]
-        Number of items to predict in the ``'next_k'`` variant, by default 1.
-    shuffle : :obj:`bool` [optional]
-        Whether the users are visited in random order (global numpy RNG), by default ``True``.
-    is_training : :obj:`bool` [optional]
-        Whether the sampler is used during training, by default ``True``.
+    Arguments: ``num_items``; ``dict_data_tr`` (dict user -> list of item ids in interaction order, users numbered from
+    0); ``dict_data_te`` (dict user -> test items; required when ``is_training`` is off); ``pred_type`` (``'next_k'``
+    -- the default -- ``'next'`` or ``'postfix'``); ``k`` (items to predict for ``'next_k'``, at least 1); ``shuffle``
+    (visit the users in a random order drawn from numpy's global generator, default on); ``is_training`` (default on);
+    ``sparse`` (see above).
     """
     def __init__(self,
                  num_items,

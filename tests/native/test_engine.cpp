@@ -172,7 +172,7 @@ static std::vector<float> d2h(const float* d, size_t n)
 }
 
 static int g_fail = 0;
-static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 0, g_opt_ntreg = 0;   // rtx_engine_set_option values applied to every engine a case creates
+static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
 static void apply_options(rtx_engine* eng)
 {
     rtx_engine_set_option(eng, "fuse_adam", g_opt_fuse);
@@ -515,7 +515,7 @@ int main(int argc, char** argv)
         g_opt_fuse = 0;
         parity_case("wide-vae-unfused-step", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_fuse = 1;
-        for (int cfg = 1; cfg <= 2; ++cfg) {
+        for (int cfg = 1; cfg <= 3; ++cfg) {
             g_opt_dw_cfg = cfg;
             parity_case("wide-vae-dwcfg", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
             parity_case("mid-dae-dwcfg", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
@@ -524,22 +524,22 @@ int main(int argc, char** argv)
         g_opt_lse = 0;
         parity_case("wide-vae-nolsefuse", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_lse = 1;
-        g_opt_two = 1;
-        parity_case("wide-vae-two-streams", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
-        parity_case("mid-dae-two-streams", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
         g_opt_two = 0;
+        parity_case("wide-vae-one-stream", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+        parity_case("mid-dae-one-stream", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
+        g_opt_two = 1;
+        g_opt_ntreg = 0;     // every NT contraction on the LDS-DMA kernel (log-sum-exp partials from its epilogue)
+        parity_case("wide-vae-nt-dma", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_ntreg = 1;
-        parity_case("wide-vae-nt-regstage", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
-        g_opt_ntreg = 0;
         parity_case("mid-dae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
     }
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration
-        g_opt_two = 1; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 0;     // weight-gradient kernels on a side stream
-        g_opt_ntreg = 1; perf_case(RTX_BF16, B, 50, 0);                  // register-staged NT GEMMs (+ LSE pass in the loss kernel)
-        g_opt_two = 1; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 0; g_opt_ntreg = 0;
-        g_opt_dw_cfg = 2; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0;
+        g_opt_dw_cfg = 3; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0;   // 128x128 weight-gradient tiles
+        g_opt_two = 0; perf_case(RTX_BF16, B, 50, 0);                        // one stream
+        g_opt_dw_cfg = 3; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0; g_opt_two = 1;
+        g_opt_ntreg = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_ntreg = 1;     // NT GEMMs on the LDS-DMA kernel
         if (argc > 3) {
             g_opt_fuse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_fuse = 1;
             perf_case(RTX_FP32, B, 20, 0);

@@ -561,7 +561,7 @@ int main(int argc, char** argv)
         }
         fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
     }
-    for (int cfg = 0; cfg < 3; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages)
+    for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
         fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
@@ -593,7 +593,7 @@ int main(int argc, char** argv)
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NN, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_512x128, 4096, 4096, 4096, 1, RTX_EPI_STORE);
-        for (int cfg = 0; cfg < 3; ++cfg) {
+        for (int cfg = 0; cfg < 4; ++cfg) {
             perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500);
             perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500);
             perf_dw("dW4 grad", cfg, RTX_DW_GRAD, 20108, 600, 500);
