@@ -152,6 +152,27 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
 /* the compute copy of layer `layer`'s weight matrix in HBM: [padded_rows][ld] elements of elem_bytes bytes (bf16 or
  * float32), padded_rows a multiple of 128; valid until the next rtx_engine_train_step (which may swap buffers) */
 int rtx_engine_shadow_region(rtx_engine* e, int32_t layer, void** base, int32_t* padded_rows, int32_t* ld, int32_t* elem_bytes);
+/* ---- RCCL hooks: what a host that is not Python needs for the data-parallel step.  One communicator
+ * per process / GPU; RCCL (librccl.so) is bound at run time on first use.  Rank 0 creates the id, the host distributes
+ * its RTX_COMM_ID_BYTES bytes out of band, every rank calls rtx_comm_init.  All collectives are IN PLACE and enqueue on
+ * `stream`: a step is  rtx_engine_loss_grads -> rtx_comm_allreduce[_many] of the gradient buffers (or
+ * rtx_comm_reduce_scatter of a weight matrix's padded region) -> rtx_engine_apply_adam[_layers|_rows] ->
+ * rtx_comm_allgather of rtx_engine_shadow_region when the optimizer is sharded. */
+#define RTX_COMM_ID_BYTES 128
+typedef struct rtx_comm rtx_comm;
+int rtx_comm_unique_id(uint8_t* id_out /* [RTX_COMM_ID_BYTES], host */);
+int rtx_comm_init(const uint8_t* id /* host */, int32_t rank, int32_t world, rtx_comm** out);
+int rtx_comm_destroy(rtx_comm* c);
+int rtx_comm_rank(const rtx_comm* c, int32_t* rank, int32_t* world);
+/* sum over the ranks of n elements (dtype RTX_FP32 or RTX_BF16) */
+int rtx_comm_allreduce(rtx_comm* c, void* buf, int64_t n, int32_t dtype, void* stream);
+/* the same for several buffers in one RCCL group (the per-tensor gradient buffers of an engine); bufs / counts: HOST arrays */
+int rtx_comm_allreduce_many(rtx_comm* c, void* const* bufs, const int64_t* counts, int32_t n_bufs, int32_t dtype, void* stream);
+/* n_total elements = world equal blocks; afterwards block `rank` holds the sum of that block over the ranks */
+int rtx_comm_reduce_scatter(rtx_comm* c, void* buf, int64_t n_total, int32_t dtype, void* stream);
+/* bytes_total = world equal blocks; block r is replaced by rank r's block on every rank */
+int rtx_comm_allgather(rtx_comm* c, void* buf, int64_t bytes_total, void* stream);
+
 /* float32 -> bfloat16 (round to nearest even) of n contiguous elements: stages a gradient bucket for a bf16 all-reduce */
 int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* both of the above: one full train_batch */

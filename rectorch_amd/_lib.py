@@ -76,6 +76,14 @@ SIGNATURES = {
     "rtx_engine_apply_adam_layers": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, _P, _P]),
     "rtx_engine_apply_adam_rows": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "rtx_engine_shadow_region": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rtx_comm_unique_id": (C.c_int, [_P]),
+    "rtx_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "rtx_comm_destroy": (C.c_int, [_P]),
+    "rtx_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rtx_comm_allreduce": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "rtx_comm_allreduce_many": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "rtx_comm_reduce_scatter": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "rtx_comm_allgather": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),

@@ -83,7 +83,7 @@ struct rtx_engine {
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
-    int opt_lse_fuse = 1;       // bf16: log-sum-exp partials from the logits GEMM's epilogue
+    int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
@@ -365,6 +365,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             } else {
                 g.tile_shape = RTX_TILE_128x128;
                 g.m_tiles = Bp / 128; g.n_tiles = l.outp / 128;
+                if (want_lse && e->opt_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }
                 RTX_TRY(rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_BIAS_ROWS, st));
             }
             break;
@@ -732,6 +733,7 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 // optimizer's HBM traffic overlaps the matrix work); biases and the remaining tensors follow in one small launch.
 // Otherwise the gradients land in the bound buffers (data-parallel exchange, p.grad, float32 parity mode).
 static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && (l.in & 3) == 0 && l.in >= 4; }
+static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
 
 static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                            rtx_layer_cb cb, void* user, hipStream_t st, bool fuse)
@@ -753,7 +755,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RtxDlogitsArgs a = {};
         a.loss.Y = e->Y; a.loss.ldy = e->Ip; a.loss.B = B; a.loss.I = e->I; a.loss.target = tg; a.loss.tsum = e->tsum;
         a.loss.lse = e->lse; a.loss.row_loss = e->row_loss; a.loss.inv_batch = step->inv_batch;
-        if (e->bf16 && e->opt_lse_fuse && !e->opt_nt_regstage) { a.loss.part = e->lse_part; a.loss.n_strips = e->lse_strips; a.loss.part_ld = e->lse_strips; }
+        if (e->opt_lse_fuse) { a.loss.part = e->lse_part; a.loss.n_strips = e->lse_strips; a.loss.part_ld = e->lse_strips; }
         if (e->vae) { a.loss.mu32 = e->mu32; a.loss.lv32 = e->lv32; a.loss.Z = e->Z; a.loss.beta = step->beta; }
         a.Bp = Bp; a.D = e->L[NL - 1].D; a.ldd = e->Ip;
         TIMED("dlogits_loss");
@@ -762,72 +764,73 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     RtxAdamArgs rest = {};   // tensors whose Adam is NOT fused into a weight-gradient kernel (odd-width matrices + their biases)
     int rest_ids[RTX_MAX_TENSORS];
     rest.n = 0;
-    // Fused step: the weight-gradient + Adam kernels are HBM / load-path streaming kernels that depend only on D[l] and
-    // A[l]; the data-gradient chain (dX GEMM -> activation derivative, layer by layer) is a chain of short latency-bound
-    // launches.  They run on two streams: `ws` takes layer l's weight kernel as soon as D[l] exists, the caller's stream
-    // goes on down the chain.  The fused optimizer writes the NEXT step's compute copy (Wsh_alt), so the chain can still
-    // read this step's.
+    // Fused step, two streams.  After the loss kernel the critical path would be
+    //     dX chain (short latency-bound launches)  ->  every weight-gradient + Adam kernel (long streaming launches).
+    // The weight kernel of layer l needs only D[l] and A[l], so the two BIG ones run on a side stream: the decoder matrix
+    // beside the whole chain, the encoder matrix as soon as the chain has produced D[0]; the small layers' kernels follow
+    // the chain on the caller's stream, beside the encoder matrix.  A big layer's fused optimizer writes the NEXT step's
+    // compute copy (Wsh_alt; swapped at the end), because the chain still reads this step's.
     const bool two = fuse && e->opt_two_stream;
-    hipStream_t ws = st;
-    if (two) {
-        if (!e->side) {
-            RTX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-            for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
-            RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
-        }
-        ws = e->side;
-        RTX_HIP(hipEventRecord(e->ev_d[NL - 1], st));   // D[NL-1] (and the loss inputs) are complete
+    if (two && !e->side) {
+        RTX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     }
-    {
+    auto on_side = [&](int li) { return two && layer_is_big(e->L[li]); };
+    auto reduce_loss = [&]() -> int {
         TIMED("reduce_loss");
         const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);
-        RTX_TRY(rtx_launch_reduce_loss(e->row_loss, B * rtx_dlogits_chunks(e->Ip), step->lam, reg_in_loss ? e->sumsq : nullptr, 2 * NL, loss_out, loss_accum, st));
-    }
+        return rtx_launch_reduce_loss(e->row_loss, B * rtx_dlogits_chunks(e->Ip), step->lam, reg_in_loss ? e->sumsq : nullptr, 2 * NL, loss_out,
+                                      loss_accum, st);
+    };
+    // weight + bias gradient of layer li on stream ws: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column
+    // `in` of the product (the ones column of A) is the bias gradient
+    auto weight_grad = [&](int li, hipStream_t ws) -> int {
+        Layer& l = e->L[li];
+        const bool fused = fuse && layer_fusable(e, l);
+        const char* site = li == NL - 1 ? (fused ? "dW_adam_out" : "gemm_dW_out") : (li == 0 ? (fused ? "dW_adam_in" : "gemm_dW_in") : (fused ? "dW_adam_hidden" : "gemm_dW_hidden"));
+        ScopedTimer tm(e, site, ws);
+        if (e->bf16) {
+            RtxDw d = {};
+            d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
+            d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+            d.M_real = l.out; d.N_real = l.in;
+            if (fused) {
+                RtxAdamArgs sc = {};
+                fill_adam_scalars(e, step, sc, 2 * li);
+                const bool keep = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
+                d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
+                d.adam.gkeep = keep ? e->grads[2 * li] : nullptr;
+                d.gbias = keep ? e->grads[2 * li + 1] : nullptr;
+                d.adam.sh = on_side(li) ? l.Wsh_alt : l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
+                d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
+                d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
+                d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
+                d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
+                d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
+                return rtx_dw_launch(d, RTX_DW_ADAM, e->opt_dw_cfg, ws);
+            }
+            d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
+            return rtx_dw_launch(d, RTX_DW_GRAD, e->opt_dw_cfg, ws);
+        }
+        RtxGemm g = {};
+        g.form = RTX_FORM_TN;
+        g.A = l.D; g.lda = l.outp; g.B = l.A; g.ldb = l.inp;
+        g.k_slices = Bp / 32; g.tile_shape = RTX_TILE_128x128; g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
+        g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
+        g.M_real = l.out; g.N_real = l.in;
+        return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
+    };
+    if (!two) RTX_TRY(reduce_loss());
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
-        // (1) weight + bias gradient: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column `in` of the
-        //     product (the ones column of A) is the bias gradient
-        const bool fused = fuse && layer_fusable(e, l);
-        auto weight_grad = [&]() -> int {
-            const char* site = li == NL - 1 ? (fused ? "dW_adam_out" : "gemm_dW_out") : (li == 0 ? (fused ? "dW_adam_in" : "gemm_dW_in") : (fused ? "dW_adam_hidden" : "gemm_dW_hidden"));
-            ScopedTimer tm(e, site, ws);
-            if (e->bf16) {
-                RtxDw d = {};
-                d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-                d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
-                d.M_real = l.out; d.N_real = l.in;
-                if (fused) {
-                    RtxAdamArgs sc = {};
-                    fill_adam_scalars(e, step, sc, 2 * li);
-                    const bool keep = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
-                    d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
-                    d.adam.gkeep = keep ? e->grads[2 * li] : nullptr;
-                    d.gbias = keep ? e->grads[2 * li + 1] : nullptr;
-                    d.adam.sh = two ? l.Wsh_alt : l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
-                    d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
-                    d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
-                    d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
-                    d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
-                    d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
-                    return rtx_dw_launch(d, RTX_DW_ADAM, e->opt_dw_cfg, ws);
-                }
-                d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
-                return rtx_dw_launch(d, RTX_DW_GRAD, e->opt_dw_cfg, ws);
-            }
-            RtxGemm g = {};
-            g.form = RTX_FORM_TN;
-            g.A = l.D; g.lda = l.outp; g.B = l.A; g.ldb = l.inp;
-            g.k_slices = Bp / 32; g.tile_shape = RTX_TILE_128x128; g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
-            g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
-            g.M_real = l.out; g.N_real = l.in;
-            return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
-        };
-        if (two) {   // the long kernel first: it only needs D[li]
-            RTX_HIP(hipStreamWaitEvent(ws, e->ev_d[li], 0));
-            RTX_TRY(weight_grad());
+        if (on_side(li)) {   // the long kernel first: it only needs D[li], which exists now
+            RTX_HIP(hipEventRecord(e->ev_d[li], st));
+            RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[li], 0));
+            RTX_TRY(weight_grad(li, e->side));
         }
-        // (2) data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come
-        //     before (1), whose fused optimizer epilogue overwrites this layer's compute copy.
+        // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
+        // the weight kernel of this layer, whose fused optimizer epilogue overwrites the compute copy.
         if (li > 0) {
             int splits = 1;
             {
@@ -851,10 +854,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
                 TIMED("post_bwd");
                 RTX_TRY(rtx_launch_post(a, RTX_POST_BWD, e->bf16, st));
             }
-            if (two) RTX_HIP(hipEventRecord(e->ev_d[li - 1], st));
         }
-        if (!two) RTX_TRY(weight_grad());
-        if (fuse && !fused) {   // what is left for the small multi-tensor Adam launch at the end of the step
+        if (!two) RTX_TRY(weight_grad(li, st));
+        if (fuse && !layer_fusable(e, l)) {   // what is left for the multi-tensor Adam launch at the end of the step
             RtxAdamArgs one = {};
             fill_adam_tensors(e, one, li, li + 1);
             rest_ids[rest.n] = 2 * li; rest.t[rest.n++] = one.t[0];
@@ -862,18 +864,30 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         }
         if (cb) cb(li, user);
     }
+    hipStream_t rs = st;    // the stream the leftover Adam launch runs on
+    if (two) {
+        // behind the chain, beside the encoder matrix's kernel: the small layers' weight kernels (their compute copies have
+        // no reader left on this stream) and the loss reduction
+        for (int li = NL - 1; li >= 0; --li)
+            if (!on_side(li)) RTX_TRY(weight_grad(li, st));
+        RTX_TRY(reduce_loss());
+        if (rest.n > 0) {   // gradients from both streams feed it: the side stream waits for this one, then runs it
+            RTX_HIP(hipEventRecord(e->ev_d[NL], st));
+            RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[NL], 0));
+            rs = e->side;
+        }
+    }
     if (fuse) {
         if (rest.n > 0) {
-            // (on the side stream these in-place updates come after every reader of this step: ws has waited for ev_d[0])
             fill_adam_scalars(e, step, rest, 0, rest_ids);
-            ScopedTimer tm(e, "adam_small", ws);
-            RTX_TRY(rtx_launch_adam(rest, e->bf16, ws));
+            ScopedTimer tm(e, "adam_small", rs);
+            RTX_TRY(rtx_launch_adam(rest, e->bf16, rs));
         }
         if (two) {
             for (int li = 0; li < NL; ++li)
-                if (layer_fusable(e, e->L[li])) std::swap(e->L[li].Wsh, e->L[li].Wsh_alt);
+                if (on_side(li) && layer_fusable(e, e->L[li])) std::swap(e->L[li].Wsh, e->L[li].Wsh_alt);
             // everything the step did is ordered on the caller's stream when the call returns
-            RTX_HIP(hipEventRecord(e->ev_done, ws));
+            RTX_HIP(hipEventRecord(e->ev_done, e->side));
             RTX_HIP(hipStreamWaitEvent(st, e->ev_done, 0));
         }
         e->shadows_valid = true;

@@ -222,80 +222,77 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
     // Per-column values (bias, column validity) are fetched ONCE before the store loop: a load inside the loop
     // makes hipcc wait vmcnt(0) per element, which also drains the stores (CDNA counts them in vmcnt) and
     // serialised the whole epilogue (12 us of the logits GEMM).
-    const int row_base = tm * BM + wm * 64 + 4 * g;
-    const int col_base = tn * BN + wn * (NB * 32) + r;
-    float bj[NB];
-    bool cok[NB];
+    if constexpr (EPI == RTX_EPI_BIAS_ROWS) {
+        // Logits epilogue through LDS (the operand stages are dead): each wave parks 32 x 64 of C at a time in a private
+        // region and re-reads it row-wise -- two lanes per row, 32 columns each -- so the stores are 16-byte pieces of
+        // 128-byte row segments and the online-softmax partial (max, sum exp) of a row over the wave's 64-column strip
+        // needs ONE shuffle.  (Round 1 reduced in the MFMA layout: 32 shuffle chains, +12 us; stores were 4 bytes per lane.)
+        typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+        constexpr int WCOLS = NB * 32, WLD = WCOLS + 4, HC = WCOLS / 2, NQ = HC / 4;
+        static_assert(WM * WN * 32 * WLD * 4 <= 2 * STAGE, "epilogue scratch must fit in the stages");
+        __syncthreads();   // every wave has finished reading the operand stages
+        float* wreg = (float*)smem + wave * (32 * WLD);
+        const int erow = lane >> 1, ehalf = lane & 1;
+        const int col0 = tn * BN + wn * WCOLS;
+        float bj[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int col = col_base + j * 32;
-        cok[j] = col < p.N_real;
-        bj[j] = 0.f;
-        if (EPI == RTX_EPI_BIAS_ROWS && p.bias) bj[j] = p.bias[cok[j] ? col : 0];
-    }
-    if (EPI == RTX_EPI_BIAS_ROWS) {
-        // add the bias to every accumulator up front (unconditional VALU): the single wait for the bias load sits
-        // here, not in front of each guarded store
+        for (int j = 0; j < NB; ++j) {
+            const int col = col0 + j * 32 + r;
+            bj[j] = p.bias ? p.bias[col < p.N_real ? col : 0] : 0.f;
+        }
+        const long ld = p.ldc;
+        const bool vec_ok = ((ld & 3) == 0) && (((uintptr_t)p.C & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float t = acc[i][j][e] + bj[j];
-                    asm volatile("" : "+v"(t));   // keep the add here: hipcc sinks it back into the guarded blocks
-                    acc[i][j][e] = t;
-                }
-    }
-    if (EPI == RTX_EPI_BIAS_ROWS && p.lse_part) {
-        // online-softmax partials of this wave's 64-column strip: (max, sum exp(y - max)) per row, reduced over the
-        // 32 lanes that hold one row (xor-shuffles stay inside a half-wave), written by lane 0 of each half.
-        // All 32 rows advance through each shuffle step together (32 independent ds_bpermute in flight) instead of
-        // one dependent 10-shuffle chain per row.
-        const int strip = tn * WN + wn;
-        float mx[2][16], sm[2][16];
+                for (int e = 0; e < 16; ++e) wreg[((e & 3) + 8 * (e >> 2) + 4 * g) * WLD + j * 32 + r] = acc[i][j][e] + bj[j];
+            __builtin_amdgcn_wave_barrier();
+            f32x4_t v[NQ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int q = 0; q < NQ; ++q) v[q] = *(const f32x4_t*)(wreg + erow * WLD + ehalf * HC + q * 4);
+            __builtin_amdgcn_wave_barrier();
+            const int row = tm * BM + wm * 64 + i * 32 + erow;
+            const int colh = col0 + ehalf * HC;
+            if (p.lse_part) {
                 float m = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    if (cok[j]) m = fmaxf(m, acc[i][j][e]);
-                mx[i][e] = m;
-            }
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mx[i][e] = fmaxf(mx[i][e], __shfl_xor(mx[i][e], o, 64));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
+                    for (int k = 0; k < 4; ++k)
+                        if (colh + q * 4 + k < p.N_real) m = fmaxf(m, v[q][k]);
+                const float mm = fmaxf(m, __shfl_xor(m, 1, 64));
                 float sum = 0.f;
+                if (mm != -INFINITY) {
 #pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    if (cok[j]) sum += __expf(acc[i][j][e] - mx[i][e]);
-                sm[i][e] = sum;
-            }
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sm[i][e] += __shfl_xor(sm[i][e], o, 64);
-        if (r == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = row_base + i * 32 + (e & 3) + 8 * (e >> 2);
-                    if (row < p.M_real) p.lse_part[(size_t)row * p.lse_ld + strip] = make_float2(mx[i][e], sm[i][e]);
+                        for (int k = 0; k < 4; ++k)
+                            if (colh + q * 4 + k < p.N_real) sum += __expf(v[q][k] - mm);
                 }
+                sum += __shfl_xor(sum, 1, 64);
+                if (ehalf == 0 && row < p.M_real) p.lse_part[(size_t)row * p.lse_ld + (tn * WN + wn)] = make_float2(mm, sum);
+            }
+            if (row < p.M_real) {
+                float* dst = p.C + (size_t)row * ld + colh;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int c = colh + q * 4;
+                    if (vec_ok && c + 3 < p.N_real) {
+                        *(f32x4_t*)(dst + q * 4) = v[q];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (c + k < p.N_real) dst[q * 4 + k] = v[q][k];
+                    }
+                }
+            }
         }
+        return;
     }
+    const int row_base = tm * BM + wm * 64 + 4 * g;
+    const int col_base = tn * BN + wn * (NB * 32) + r;
     // one 64-bit base per lane; every element offset is (compile-time constant) * ld + constant -> scalar math
     const long ld = (EPI == RTX_EPI_GRAD) ? (long)p.N_real : p.ldc;
     float* cp = p.C + (EPI == RTX_EPI_STORE ? (size_t)split * p.slab_stride : (size_t)0) + (size_t)row_base * ld + col_base;
@@ -312,11 +309,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
                 float* dst = cp + (long)dr * ld + j * 32;
                 if (EPI == RTX_EPI_STORE) {
                     *dst = v;
-                } else if (EPI == RTX_EPI_BIAS_ROWS) {
-                    if (row < p.M_real && cok[j]) *dst = v;
                 } else {  // RTX_EPI_GRAD
                     if (row < p.M_real) {
-                        if (cok[j])
+                        if (col < p.N_real)
                             *dst = v;
                         else if (col == p.N_real && p.gbias)
                             p.gbias[row] = v;

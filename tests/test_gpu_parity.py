@@ -1239,3 +1239,59 @@ def test_svae_vs_oracle_ml1m_widths():
             assert rel(prm.grad.cpu(), orc.last_grads[k]) < 5e-4, (T, k)
             dlt = np.abs(prm.detach().cpu().numpy() - orc.p[k])
             assert float(dlt.max()) < 1e-3 and float(np.mean(dlt > 2e-5)) < 1e-4, (T, k, float(dlt.max()))
+
+
+def test_c_abi_rccl_hooks_one_rank():
+    """rtx_comm_* (RCCL bound at run time by librectorch_hip): a one-rank communicator built from the C ABI alone; the in-place
+    all-reduce / reduce-scatter / all-gather leave a one-rank buffer unchanged and the data-parallel step written with them
+    (loss_grads -> rtx_comm_allreduce_many of the bound gradient buffers -> apply_adam) equals train_step"""
+    import ctypes as C
+    from rectorch_amd import _lib
+    from rectorch_amd.utils.hashinit import hash_state_dict
+    L_ = _lib.lib()
+    ident = (C.c_uint8 * 128)()
+    _lib.check(L_.rtx_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(L_.rtx_comm_init(ident, 0, 1, C.byref(comm)))
+    r, w = C.c_int32(-1), C.c_int32(-1)
+    _lib.check(L_.rtx_comm_rank(comm, C.byref(r), C.byref(w)))
+    assert (r.value, w.value) == (0, 1)
+    st = _lib.stream_ptr()
+    x = torch.arange(4096, dtype=torch.float32, device="cuda") * 0.5
+    ref = x.clone()
+    _lib.check(L_.rtx_comm_allreduce(comm, C.c_void_p(x.data_ptr()), x.numel(), _lib.RTX_FP32, st))
+    _lib.check(L_.rtx_comm_reduce_scatter(comm, C.c_void_p(x.data_ptr()), x.numel(), _lib.RTX_FP32, st))
+    _lib.check(L_.rtx_comm_allgather(comm, C.c_void_p(x.data_ptr()), x.numel() * 4, st))
+    xb = ref.to(torch.bfloat16)
+    _lib.check(L_.rtx_comm_allreduce(comm, C.c_void_p(xb.data_ptr()), xb.numel(), _lib.RTX_BF16, st))
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and torch.equal(xb, ref.to(torch.bfloat16))
+    # the data-parallel step through the C ABI only
+    I, H, L, B = 300, 40, 12, 32
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 9, 1.0)
+    rng = np.random.RandomState(1)
+    xs = torch.from_numpy((rng.rand(B, I) < 0.1).astype(np.float32))
+    outs = []
+    for use_comm in (False, True):
+        net, model = make_vae([I, H, L], [L, H, I], 0.0, sd, beta=0.3, numerics="fp32")
+        stt, params, m, v = model._ensure_train_state()
+        eng = net.rtx_engine("fp32", B, train_buffers=(stt.grads, m, v))
+        g = model.optimizer.param_groups[0]
+        step = eng._step(seed=77, beta=0.3, lam=0.0, inv_batch=1.0 / B, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
+                         weight_decay=g["weight_decay"], step=1)
+        loss = torch.zeros(1, device="cuda")
+        if not use_comm:
+            eng.train_step(xs.cuda(), None, step, loss)
+        else:
+            eng.loss_grads(xs.cuda(), None, step, loss)
+            n = len(stt.grads)
+            bufs = (C.c_void_p * n)(*[t.data_ptr() for t in stt.grads])
+            cnts = (C.c_int64 * n)(*[t.numel() for t in stt.grads])
+            _lib.check(L_.rtx_comm_allreduce_many(comm, bufs, cnts, n, _lib.RTX_FP32, st))
+            eng.apply_adam(step)
+        torch.cuda.synchronize()
+        outs.append((float(loss.item()), [p.detach().cpu().numpy().copy() for p in net.parameters()]))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+    _lib.check(L_.rtx_comm_destroy(comm))
