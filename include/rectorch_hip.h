@@ -248,8 +248,8 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
                         const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream);
 
 /* measurement knobs of one engine (the defaults are the shipped configuration): key "fuse_adam" (0/1, bf16 step:
- * Adam inside the weight-gradient kernels), "two_stream" (0/1: those kernels on a second stream beside the
- * data-gradient chain), "lse_fuse" (0/1: log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the
+ * Adam inside the weight-gradient kernels), "two_stream" (0/1: the two big ones on a second stream beside the
+ * data-gradient chain), "side_low_prio" (0/1: that stream at the lowest priority; before the first step), "lse_fuse" (0/1: log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the
  * big NT contractions on the register-staged GEMM instead of the LDS-DMA one), "dw_cfg" (0..2: tile configuration of
  * the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic).  Replaces round 1's
  * RTX_* environment switches. */

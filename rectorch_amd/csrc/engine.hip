@@ -85,6 +85,7 @@ struct rtx_engine {
     int opt_dw_cfg = RTX_DW_64x128;
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
+    int opt_side_low_prio = 1;  // ... created with the lowest stream priority
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -772,7 +773,12 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     // compute copy (Wsh_alt; swapped at the end), because the chain still reads this step's.
     const bool two = fuse && e->opt_two_stream;
     if (two && !e->side) {
-        RTX_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        // lowest priority: the long streaming kernels take the workgroup slots the short launches of the chain leave free,
+        // not the other way round (with equal priorities the chain's kernels waited for slots: k_reduce_loss 17 us, k_post
+        // 16 us under contention against 5 and 8 us alone)
+        int prio_least = 0, prio_greatest = 0;
+        RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
         for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     }
@@ -1014,6 +1020,10 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "two_stream") e->opt_two_stream = value != 0;
+    else if (k == "side_low_prio") {
+        RTX_CHECK(!e->side, RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
+        e->opt_side_low_prio = value != 0;
+    }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
@@ -1034,7 +1044,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, nt_regstage, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;
