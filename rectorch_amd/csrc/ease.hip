@@ -170,8 +170,7 @@ static int dgemm(const double* A, long lda, const double* B, long ldb, int m_til
     // all but the top two levels of the recursion have too few 128x128 tiles to fill 256 compute units: quarter tiles
     // put them on 4x as many (the triangular K ranges and the lower-only rule are tile-relative, so they carry over
     // with the finer grid).  Measured fit time by threshold: 0 -> 252.7 ms, 16 -> 241.4, 400..1600 -> 230.8, all -> 238.3
-    static int small_max = -1;
-    if (small_max < 0) { const char* v = getenv("RTX_EASE_SMALL_TILES"); small_max = v ? atoi(v) : 1024; }
+    constexpr int small_max = 1024;
     if (m_tiles * n_tiles <= small_max) { g.small_tile = 1; g.m_tiles = 2 * m_tiles; g.n_tiles = 2 * n_tiles; }
     return rtx_dgemm_launch(g, st);
 }
@@ -259,9 +258,6 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
             }
             if (gram != RTX_DT_F32 && mx * mx * (double)U >= 16777216.0) gram = RTX_DT_F32;
             if (gram == RTX_DT_FP8 && mx > 16.0) gram = RTX_DT_BF16;
-            const char* force = getenv("RTX_EASE_GRAM");   // "bf16" / "f64": measurement switch
-            if (force && gram == RTX_DT_FP8 && !strcmp(force, "bf16")) gram = RTX_DT_BF16;
-            if (force && !strcmp(force, "f64")) gram = RTX_DT_F32;
             if (gram == RTX_DT_F32) vscale = 1.f;
         }
         EASE_TRY(dalloc((void**)&A, sizeof(double) * (size_t)np * np, pool));
@@ -280,16 +276,7 @@ int rtx_ease_fit(const rtx_csr* X, double lam, rtx_ease** out, void* stream)
                 hipLaunchKernelGGL(k_ease_scatter_T8, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, vscale, Up, (uint8_t*)XT);
             else
                 hipLaunchKernelGGL(k_ease_scatter_T16, dim3((unsigned)U), dim3(256), 0, st, X->indptr, X->indices, X->values, vscale, Up, (bf16_t*)XT);
-            const char* sy = getenv("RTX_EASE_SYRK");   // "0": the general GEMM with its lower-triangle patch order (measurement switch)
-            if (sy && !strcmp(sy, "0")) {
-                RtxGemm g = {};
-                g.A = XT; g.B = XT; g.lda = Up; g.ldb = Up; g.tile_shape = RTX_TILE_128x128;
-                g.m_tiles = KB; g.n_tiles = KB; g.k_slices = (int)(Up * esz / 128); g.splits = 1; g.syrk_lower = 1;
-                g.C = G32; g.ldc = np; g.slab_stride = 0; g.M_real = np; g.N_real = np;
-                EASE_TRY(rtx_gemm_launch(g, gram, RTX_EPI_STORE, st));
-            } else {
-                EASE_TRY(rtx_syrk_lower_launch(XT, Up * esz, 128, (int)(np256 / 256), KB, (int)(Up * esz / 128), gram == RTX_DT_FP8, G32, np, st));
-            }
+            EASE_TRY(rtx_syrk_lower_launch(XT, Up * esz, 128, (int)(np256 / 256), KB, (int)(Up * esz / 128), gram == RTX_DT_FP8, G32, np, st));
             hipLaunchKernelGGL(k_ease_init<float>, dim3((unsigned)(((long)np * np + 255) / 256)), dim3(256), 0, st, G32, (long)np, A, n, np, lam,
                                1.0 / ((double)vscale * vscale));
         } else {

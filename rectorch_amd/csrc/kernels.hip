@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
     // strides) are re-read from that XCD's L2 instead of being fetched from HBM by two different L2s
     // (PMC: FETCH_SIZE was 1.37x the algorithmic read bytes with the plain order).
     const int per_xcd = (a.total_tiles + 7) / 8;
-    const int tile_id = a.plain_order ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int tile_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (tile_id >= a.total_tiles) return;
     int ti = 0;
 #pragma unroll 1
@@ -872,9 +872,6 @@ int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
     }
     if (tiles == 0) return RTX_OK;
     a.total_tiles = tiles;
-    static int plain = -1;
-    if (plain < 0) { const char* v = getenv("RTX_ADAM_PLAIN_ORDER"); plain = v ? atoi(v) : 0; }
-    a.plain_order = plain;
     const int grid = 8 * ((tiles + 7) / 8);
     if (is_bf16)
         hipLaunchKernelGGL(k_adam<bf16_t>, dim3(grid), dim3(256), 0, stream, a);

@@ -157,7 +157,6 @@ struct RtxAdamArgs {
     RtxAdamTensor t[RTX_MAX_TENSORS];
     int n;
     int total_tiles;   // filled by rtx_launch_adam
-    int plain_order;   // experiments: 1 = tile b handled by workgroup b (no XCD-contiguous order)
     int update;        // 0: only refresh the shadows from the master parameters
     float step_size;   // lr / (1 - beta1^t)
     float bc2_sqrt;    // sqrt(1 - beta2^t)
