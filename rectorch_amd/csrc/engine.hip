@@ -799,7 +799,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d = {};
             d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-            d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+            // the panel-resident kernel is for the big matrices (hundreds of tiles per panel); small layers keep the tile kernel
+            const int dw_cfg = (e->opt_dw_cfg == RTX_DW_PANEL && !layer_is_big(l)) ? RTX_DW_64x128 : e->opt_dw_cfg;
+            d.m_tiles = l.outp / rtx_dw_tile_rows(dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
             d.M_real = l.out; d.N_real = l.in;
             if (fused) {
                 RtxAdamArgs sc = {};
@@ -814,10 +816,10 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
                 d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
                 d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
                 d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
-                return rtx_dw_launch(d, RTX_DW_ADAM, e->opt_dw_cfg, ws);
+                return rtx_dw_launch(d, RTX_DW_ADAM, dw_cfg, ws);
             }
             d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
-            return rtx_dw_launch(d, RTX_DW_GRAD, e->opt_dw_cfg, ws);
+            return rtx_dw_launch(d, RTX_DW_GRAD, dw_cfg, ws);
         }
         RtxGemm g = {};
         g.form = RTX_FORM_TN;
@@ -1026,7 +1028,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "dw_cfg") {
-        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
+        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_PANEL, RTX_EINVAL, "set_option: dw_cfg must be 0..4");
         e->opt_dw_cfg = value;
     } else if (k == "splitk") {
         RTX_CHECK(value >= 0, RTX_EINVAL, "set_option: splitk must be >= 0");

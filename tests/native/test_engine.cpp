@@ -516,7 +516,7 @@ int main(int argc, char** argv)
         g_opt_fuse = 0;
         parity_case("wide-vae-unfused-step", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_fuse = 1;
-        for (int cfg = 1; cfg <= 3; ++cfg) {
+        for (int cfg = 1; cfg <= 4; ++cfg) {
             g_opt_dw_cfg = cfg;
             parity_case("wide-vae-dwcfg", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
             parity_case("mid-dae-dwcfg", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
@@ -537,9 +537,9 @@ int main(int argc, char** argv)
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration
-        g_opt_lowprio = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_lowprio = 1;  // side stream at normal priority
+        g_opt_dw_cfg = 4; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0;    // panel-resident weight-gradient + Adam kernel
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration again (box drift)
-        g_opt_dw_cfg = 2; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0;    // 32x128 weight-gradient tiles, 4 workgroups / CU
+        g_opt_dw_cfg = 4; g_opt_two = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_dw_cfg = 0; g_opt_two = 1;   // panel kernel, one stream
         g_opt_two = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 1;          // one stream
         if (argc > 3) {
             g_opt_fuse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_fuse = 1;

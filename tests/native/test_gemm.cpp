@@ -432,43 +432,55 @@ static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_rea
     return bad != 0;
 }
 
-static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, int K_real)
+// `sets` > 1: that many separate p / m / v / compute-copy buffer sets used round-robin, so that a launch never finds its
+// optimizer state in the 256-MiB Infinity Cache left there by the launch before (what happens inside a training step)
+static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, int K_real, int sets = 1)
 {
     const int Mp = rtx_pad(M_real), Np = rtx_pad(N_real), Kp = rtx_pad_batch(K_real);
     std::vector<bf16_t> hD((size_t)Kp * Mp), hX((size_t)Kp * Np);
     for (auto& x : hD) x = f32_to_bf16(frand() * 0.01f);
     for (auto& x : hX) x = f32_to_bf16(frand());
     const size_t P = (size_t)M_real * N_real;
-    bf16_t *D, *X, *sh;
-    float *p, *m, *v, *gb, *gW;
+    bf16_t *D, *X;
+    float *gb, *gW;
+    std::vector<float*> p(sets), m(sets), v(sets);
+    std::vector<bf16_t*> sh(sets);
     CK(hipMalloc(&D, hD.size() * 2)); CK(hipMalloc(&X, hX.size() * 2));
-    CK(hipMalloc(&p, P * 4)); CK(hipMalloc(&m, P * 4)); CK(hipMalloc(&v, P * 4)); CK(hipMalloc(&gW, P * 4));
-    CK(hipMalloc(&gb, Mp * 4)); CK(hipMalloc(&sh, (size_t)Mp * Np * 2));
+    for (int i = 0; i < sets; ++i) {
+        CK(hipMalloc(&p[i], P * 4)); CK(hipMalloc(&m[i], P * 4)); CK(hipMalloc(&v[i], P * 4)); CK(hipMalloc(&sh[i], (size_t)Mp * Np * 2));
+        CK(hipMemset(p[i], 0, P * 4)); CK(hipMemset(m[i], 0, P * 4)); CK(hipMemset(v[i], 0, P * 4));
+    }
+    CK(hipMalloc(&gW, P * 4));
+    CK(hipMalloc(&gb, Mp * 4));
     CK(hipMemcpy(D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
-    CK(hipMemset(p, 0, P * 4)); CK(hipMemset(m, 0, P * 4)); CK(hipMemset(v, 0, P * 4));
     RtxDw d = {};
     d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
     d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
     d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
-    d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.sh = sh; d.adam.ld_sh = Np;
+    d.adam.ld_sh = Np;
     d.adam.step_size = 1e-3f; d.adam.bc2_sqrt = 0.05f; d.adam.beta1 = 0.9f; d.adam.beta2 = 0.999f; d.adam.eps = 1e-8f;
     d.gW = gW;
+    auto go = [&](int i) {
+        d.adam.p = p[i % sets]; d.adam.m = m[i % sets]; d.adam.v = v[i % sets]; d.adam.sh = sh[i % sets];
+        rtx_dw_launch(d, epi, cfg, 0);
+    };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) rtx_dw_launch(d, epi, cfg, 0);
+    for (int i = 0; i < 3; ++i) go(i);
     CK(hipEventRecord(e0, 0));
     const int it = 20;
-    for (int i = 0; i < it; ++i) rtx_dw_launch(d, epi, cfg, 0);
+    for (int i = 0; i < it; ++i) go(i);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1000.0 / it;
     const double bytes = (epi == RTX_DW_ADAM ? 26.0 : 4.0) * P + 2.0 * Kp * (Mp + Np);
-    printf("[perf dw %s] cfg%d epi=%d %dx%d K=%d: %.1f us  %.2f TB/s (p,m,v r+w + compute copy + operands)  %.1f TFLOP/s\n", name, cfg, epi, M_real, N_real,
-           K_real, us, bytes / us * 1e-6, 2.0 * P * Kp / us * 1e-6);
-    hipFree(D); hipFree(X); hipFree(p); hipFree(m); hipFree(v); hipFree(gW); hipFree(gb); hipFree(sh);
+    printf("[perf dw %s%s] cfg%d epi=%d %dx%d K=%d: %.1f us  %.2f TB/s (p,m,v r+w + compute copy + operands)  %.1f TFLOP/s\n", name,
+           sets > 1 ? " cold" : "", cfg, epi, M_real, N_real, K_real, us, bytes / us * 1e-6, 2.0 * P * Kp / us * 1e-6);
+    hipFree(D); hipFree(X); hipFree(gW); hipFree(gb);
+    for (int i = 0; i < sets; ++i) { hipFree(p[i]); hipFree(m[i]); hipFree(v[i]); hipFree(sh[i]); }
 }
 
 // ---- float32 GEMM with a K-major operand (gemm_f32.hip) ------------------------------------------------------------------------------
@@ -561,7 +573,7 @@ int main(int argc, char** argv)
         }
         fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
     }
-    for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
+    for (int cfg = 0; cfg < 5; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / panel-resident
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
         fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
@@ -570,6 +582,13 @@ int main(int argc, char** argv)
         fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
         fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
     }
+    // panel-resident kernel: several tiles per workgroup (the ring and the optimizer stream run across tile boundaries), both
+    // orientations, chunks without tiles
+    fails += run_dw_case("panel-out", RTX_DW_PANEL, RTX_DW_ADAM, 2000, 600, 500, 0.f, 0.f, 1);
+    fails += run_dw_case("panel-in", RTX_DW_PANEL, RTX_DW_ADAM, 600, 2000, 500, 0.f, 0.f, 0);
+    fails += run_dw_case("panel-long-out", RTX_DW_PANEL, RTX_DW_ADAM, 49152 + 17, 100, 100, 0.1f, 0.001f, 1);
+    fails += run_dw_case("panel-long-in", RTX_DW_PANEL, RTX_DW_ADAM, 100, 49152 + 20, 100, 0.f, 0.f, 1);
+
     for (int form : {RTX_FORM_NN, RTX_FORM_TN}) {
         fails += run_f32_case("store", form, 256, 384, 352, 1, RTX_EPI_STORE, 256, 384);
         fails += run_f32_case("splitk3", form, 256, 384, 352, 3, RTX_EPI_STORE, 256, 384);
@@ -593,10 +612,12 @@ int main(int argc, char** argv)
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NN, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_512x128, 4096, 4096, 4096, 1, RTX_EPI_STORE);
-        for (int cfg = 0; cfg < 4; ++cfg) {
+        for (int cfg : {0, 2, 4}) {
             perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500);
             perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500);
-            perf_dw("dW4 grad", cfg, RTX_DW_GRAD, 20108, 600, 500);
+            perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
+            perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
+            if (cfg != 4) perf_dw("dW4 grad", cfg, RTX_DW_GRAD, 20108, 600, 500);
         }
         perf_dw("dW-hidden+adam", 0, RTX_DW_ADAM, 400, 600, 500);
         // ml-20m step shapes: fwd-1 / dH3 (skinny, split-K), logits, dW4 / dW1

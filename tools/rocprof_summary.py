@@ -42,5 +42,23 @@ def bygrid(path):
         print("%-40s grid=(%s,%s) calls=%d total=%.1f avg=%.2f" % (n[:40], x, y, c, sm / 1e3, a / 1e3))
 
 
+def timeline(path, anchor="k_gather", nth=40, count=2):
+    """start / end of every kernel of `count` consecutive steps (a step begins at the `nth` launch of the `anchor` kernel), in
+    us from the step's first kernel, with the queue it ran on: shows what overlaps what and the gaps between dependent kernels"""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
+    idx = [i for i, r in enumerate(rows) if anchor in r[0]]
+    if len(idx) < nth + count + 1:
+        nth = max(0, len(idx) - count - 1)
+    lo, hi = idx[nth], idx[nth + count]
+    t0 = rows[lo][1]
+    print("# kernel timeline of %d step(s): start_us end_us dur_us gap_to_prev_end_on_same_queue queue stream kernel" % count)
+    last_end = {}
+    for n, st, en, q, sid in rows[lo:hi]:
+        gap = (st - last_end[q]) / 1e3 if q in last_end else 0.0
+        last_end[q] = en
+        print("%9.2f %9.2f %8.2f %8.2f  q%-3s s%-3s %s" % ((st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3, gap, q, sid, n[:70]))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "bygrid": bygrid}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline}[sys.argv[1]](sys.argv[2])
