@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--users", type=int, default=None)
     ap.add_argument("--items", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-defer", action="store_true", help="every step joins its side-stream kernels before it returns (train_batch semantics)")
     ap.add_argument("--no-fp32-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cond-dim", type=int, default=0,
@@ -223,8 +224,11 @@ def main():
     torch.manual_seed(1000 + rank)
 
     def run(n, start):
+        # what MultiVAE.train_epoch does with a device-resident sampler: back-to-back steps that leave their two big optimizer
+        # kernels running for the next step to join (RTX_STEP_DEFER_JOIN), and one join at the end of the stretch
         for i in range(n):
-            model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
+            model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False, defer=not args.no_defer)
+        model._join()
 
     run(args.warmup, 0)
     torch.cuda.synchronize()

@@ -23,6 +23,11 @@
 //   * tiles are ordered with the SHORT matrix dimension fastest and every XCD gets one contiguous run of them, so the
 //     128-byte lines that straddle neighbouring tiles (rows are 2400 B / 80432 B long: never line-aligned) are merged in
 //     one L2, and the operand panel shared by a run stays in that L2.
+// Measured alternatives that are not in the source any more (profiles/r2_dw_panel_experiment.log): a persistent
+// variant that keeps the short-dimension operand resident as MFMA fragments in registers (8 B instead of 24 B of operand bytes
+// per parameter delivered to the CUs, matrix / optimizer wave roles, p / m / v prefetched a whole tile ahead) reaches the same
+// 72 us on the n_items x 600 matrix: the kernel is bound by HBM at the read / write mix of an Adam update (4.7 - 4.9 TB/s of
+// measured traffic, what the stand-alone k_adam reaches as well), not by operand delivery.
 // The gradient never reaches HBM (RTX_DW_ADAM).  RTX_DW_GRAD stores it instead (float32 and / or a bf16 image) for the
 // data-parallel path, rtx_engine_loss_grads and tensors whose rows are not 16-byte periodic.
 #include "rtx_gemm.h"
@@ -317,279 +322,7 @@ template <int WM, int WN, int NS, int EPI> static int dw_launch(const RtxDw& d, 
     return RTX_OK;
 }
 
-// ---- panel-resident variant (RTX_DW_PANEL) ---------------------------------------------------------------------------
-// What bounds rtx_dw_tn at a B = 500 step is not HBM but the bytes DELIVERED to the compute units (L2 -> CU fabric, about
-// 7.7 TB/s chip-wide, measured): a 64 x 128 tile pulls 192 KB of operand slices for 8192 parameters -- 24 B per parameter on
-// top of the 12 B of p / m / v -- and the same slices are pulled again by every tile that shares them.  Here the operand of
-// the SHORT matrix dimension stays put: a workgroup owns one 128-wide panel R of it for its whole life, held in the matrix
-// waves' REGISTERS as ready MFMA fragments (K = 512: 32 k-steps x 4 registers = 128 VGPRs, loaded once), and walks 64-wide
-// tiles S of the long dimension whose slices alone stream in by LDS-DMA: 8 B per parameter instead of 24.
-// One workgroup per CU, eight waves in two roles:
-//   waves 0-3 (matrix): DMA ring of 4 x 8 KB S slices that never drains (it runs across tile boundaries), transposing LDS
-//       reads for the S fragments, 8 MFMA 32x32x16 per slice, gradient tile parked in LDS (two parking buffers);
-//   waves 4-7 (stream): the optimizer.  Each thread owns 32 parameters of a tile (8 x float4 of p, m, v = 96 VGPRs): while
-//       the matrix waves multiply tile i it finishes tile i-1 -- gradient from the parking buffer, Adam, stores -- chunk by
-//       chunk, and refills every chunk's registers with tile i's values the moment they are free.  Its loads therefore
-//       fly for a whole tile time (a wave's vector-memory queue completes in order: in rtx_dw_tn, where one wave does both
-//       jobs, the first operand wait also waits for the p / m / v loads issued before it).
-// The two roles meet at one s_barrier per K slice (the barrier the DMA ring needs anyway).
-// IN = 0: tall matrix [M >= N] (decoder output layer): R = activation columns (MFMA B operand), S = delta rows, tile 64 x 128.
-// IN = 1: wide matrix (encoder input layer): R = delta rows (A operand), S = activation columns, tile 128 x 64.
-template <int IN, int NKS>
-__global__ __launch_bounds__(512, 2) void rtx_dw_panel(const RtxDw p, int n_panels, int s_tiles, int groups_per_xcd)
-{
-    constexpr int SLICE = 64 * 128;                         // [64 k][64 elements] bf16
-    constexpr int NST = 4;                                  // ring stages; 3 slices in flight
-    constexpr int PLD = IN ? 68 : 132;                      // parked tile row stride (floats): +4 against bank conflicts
-    constexpr int PARK = 128 * 68 * 4;                      // bytes of one parking buffer (>= 64 * 132 * 4)
-    constexpr int CPS = 8 / NKS;                            // stream chunks per K slice
-    static_assert(NKS == 8 || NKS == 4 || NKS == 2, "K_pad = 512 / 256 / 128");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // NST * SLICE | 2 * PARK
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool matrix = wave < 4;
-    const int w = wave & 3;
-
-    int panel, t0, n_my;
-    {
-        const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
-        if (j >= groups_per_xcd * n_panels) return;
-        const int group = j / n_panels;
-        panel = j % n_panels;
-        const int chunks = 8 * groups_per_xcd, chunk = xcd * groups_per_xcd + group;
-        t0 = (int)((long)chunk * s_tiles / chunks);
-        n_my = (int)((long)(chunk + 1) * s_tiles / chunks) - t0;
-        if (n_my <= 0) return;
-    }
-    dw_lds_byte* ring = (dw_lds_byte*)smem;
-    float* park0 = (float*)(smem + NST * SLICE);
-
-    // ---- matrix role state --------------------------------------------------------------------------------------------------
-    // ONE register array serves both roles (the allocator cannot know that a wave never holds both): the matrix waves keep
-    // their R fragments in it, the stream waves their p / m / v float4s (chunk c at [c], [8 + c], [16 + c])
-    constexpr int NBIG = NKS * 4 > 24 ? NKS * 4 : 24;
-    dw_u32x4 big[NBIG];
-    dw_f32x16 acc[2];
-    const unsigned char* gS[2] = {nullptr, nullptr};
-    unsigned offS[2] = {0, 0};
-    const size_t rowS = (size_t)(IN ? p.ldb : p.lda) * 2;
-    // ---- stream role state --------------------------------------------------------------------------------------------------
-    const int st = tid - 256;
-    const int srow = IN ? (st >> 4) : (st >> 5), scol4 = IN ? (st & 15) * 4 : (st & 31) * 4;
-    float reg = 0.f;
-
-    auto s_offset = [&](int tile, int c, int srow) __attribute__((always_inline)) -> size_t {   // clamped element offset of chunk c's float4
-        const int lr = c * (IN ? 16 : 8) + srow;
-        const int row = IN ? panel * 128 + lr : tile * 64 + lr;
-        const int col = IN ? tile * 64 + scol4 : panel * 128 + scol4;
-        return (size_t)min(row, p.M_real - 1) * p.N_real + min(col, p.N_real - 4);
-    };
-
-    if (matrix) {
-        // R fragments: lane (n = lane & 31, k-group = lane >> 5) of k-step kk holds R[kk * 16 + 8 * kgroup + 0..7][n]
-        const unsigned short* R = (const unsigned short*)(IN ? p.A : p.B);
-        const size_t ldR = (size_t)(IN ? p.lda : p.ldb);
-        const unsigned short* q = R + (size_t)((lane >> 5) * 8) * ldR + panel * 128 + w * 32 + (lane & 31);
-#pragma unroll
-        for (int kk = 0; kk < NKS * 4; ++kk) {
-            unsigned e[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) e[jj] = q[(size_t)(kk * 16 + jj) * ldR];
-            big[kk][0] = e[0] | (e[1] << 16);
-            big[kk][1] = e[2] | (e[3] << 16);
-            big[kk][2] = e[4] | (e[5] << 16);
-            big[kk][3] = e[6] | (e[7] << 16);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        const unsigned char* S = (const unsigned char*)(IN ? p.B : p.A);
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const int o = (w + qq * 4) * 1024 + lane * 16;   // physical byte of this lane's piece in the slice image
-            const int rr = o >> 7, ww = o & 127;
-            const int cc = (ww >> 6) ^ ((rr >> 1) & 1);
-            gS[qq] = S + (size_t)rr * rowS + (cc << 6) + (ww & 63);
-        }
-        const int p16 = lane & 15, g4 = lane >> 4, s4 = p16 >> 2;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            offS[j] = (unsigned)(((g4 >> 1) * 8 + s4) * 128 + ((j ^ (s4 >> 1)) << 6) + (g4 & 1) * 32 + (p16 & 3) * 8);
-    } else {
-        reg = dw_dae_reg(p);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const size_t off = s_offset(t0, c, srow);
-            big[c] = __builtin_bit_cast(dw_u32x4, dw_ld_nt(p.adam.p + off));
-            big[8 + c] = __builtin_bit_cast(dw_u32x4, dw_ld_nt(p.adam.m + off));
-            big[16 + c] = __builtin_bit_cast(dw_u32x4, dw_ld_nt(p.adam.v + off));
-        }
-    }
-    const int total_slices = n_my * NKS;
-    auto dma_slice = [&](int gidx) __attribute__((always_inline)) {   // global slice index -> ring stage gidx % NST
-        const int gc = min(gidx, total_slices - 1);                   // past the end: a harmless reload into a free stage
-        const int tile = t0 + gc / NKS, ks = gc % NKS;
-        dw_lds_byte* sb = ring + (gidx & (NST - 1)) * SLICE + w * 1024;
-        const size_t go = (size_t)tile * 128 + (size_t)ks * 64 * rowS;
-        __builtin_amdgcn_global_load_lds((const void*)(gS[0] + go), (void __attribute__((address_space(3)))*)(sb), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)(gS[1] + go), (void __attribute__((address_space(3)))*)(sb + 4096), 16, 0, 0);
-    };
-    if (matrix) {
-        dma_slice(0);
-        dma_slice(1);
-        dma_slice(2);
-    }
-
-    // The two roles run their OWN copies of the tile loop (same barrier count): in one shared loop the compiler sees the stream
-    // role's loads into the shared register array as pending in front of the matrix role's MFMAs and drains the queue there.
-    if (matrix) {
-        for (int it = 0; it < n_my; ++it) {
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                const int gidx = it * NKS + s;
-                dw_wait_vm<4>();                  // my pieces of slice gidx have landed (gidx + 1, gidx + 2 may be in flight)
-                __builtin_amdgcn_s_barrier();     // everybody's have; slice gidx - 1 is consumed; the tile parked before this barrier is visible
-                dma_slice(gidx + 3);
-                const unsigned sbase = (unsigned)(size_t)(ring + (gidx & (NST - 1)) * SLICE);
-                dw_u32x2 lo[4][2], hi[4][2];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (kk == 0) { dw_rdtr<0>(lo[kk][j], sbase + offS[j]); dw_rdtr<4 * 128>(hi[kk][j], sbase + offS[j]); }
-                        if (kk == 1) { dw_rdtr<16 * 128>(lo[kk][j], sbase + offS[j]); dw_rdtr<20 * 128>(hi[kk][j], sbase + offS[j]); }
-                        if (kk == 2) { dw_rdtr<32 * 128>(lo[kk][j], sbase + offS[j]); dw_rdtr<36 * 128>(hi[kk][j], sbase + offS[j]); }
-                        if (kk == 3) { dw_rdtr<48 * 128>(lo[kk][j], sbase + offS[j]); dw_rdtr<52 * 128>(hi[kk][j], sbase + offS[j]); }
-                    }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (kk == 0) dw_wait_lgkm<12>();
-                    if (kk == 1) dw_wait_lgkm<8>();
-                    if (kk == 2) dw_wait_lgkm<4>();
-                    if (kk == 3) dw_wait_lgkm<0>();
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        dw_u32x4 sv;
-                        sv[0] = lo[kk][j][0]; sv[1] = lo[kk][j][1]; sv[2] = hi[kk][j][0]; sv[3] = hi[kk][j][1];
-                        if (IN)
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dw_bf16x8, big[s * 4 + kk]), __builtin_bit_cast(dw_bf16x8, sv), acc[j], 0, 0, 0);
-                        else
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(dw_bf16x8, sv), __builtin_bit_cast(dw_bf16x8, big[s * 4 + kk]), acc[j], 0, 0, 0);
-                    }
-                }
-            }
-            // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-            float* park_w = park0 + (size_t)(it & 1) * (PARK / 4);
-            const int r = lane & 31, g = lane >> 5;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * g;
-                    if (IN) park_w[(w * 32 + rr) * PLD + j * 32 + r] = acc[j][e];
-                    else park_w[(j * 32 + rr) * PLD + w * 32 + r] = acc[j][e];
-                    acc[j][e] = 0.f;
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) __builtin_amdgcn_s_barrier();   // the stream waves finish the last tile
-    } else {
-        // tile t0's p / m / v are on their way (above).  Iteration 0: the matrix waves multiply tile t0, nothing to finish yet.
-        // Iterations 1 .. n_my - 1: finish tile it - 1 chunk by chunk and refill each chunk's registers with tile it -- the loop
-        // body has NO conditional memory instruction on its main path, so the compiler's own count of the queue (21 loads and
-        // seven chunks of stores between a refill and its use) stands.  The last iteration only finishes.
-        auto finish_chunk = [&](int c, int tile, const float* park_r, int srow_t) __attribute__((always_inline)) {
-            const int lr = c * (IN ? 16 : 8) + srow_t;
-            const dw_f32x4 g4 = *(const dw_f32x4*)(park_r + lr * PLD + scol4);
-            dw_finish4<RTX_DW_ADAM>(p, IN ? panel * 128 + lr : tile * 64 + lr, IN ? tile * 64 + scol4 : panel * 128 + scol4, g4,
-                                    __builtin_bit_cast(dw_f32x4, big[c]), __builtin_bit_cast(dw_f32x4, big[8 + c]),
-                                    __builtin_bit_cast(dw_f32x4, big[16 + c]), reg);
-        };
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) __builtin_amdgcn_s_barrier();
-        for (int it = 1; it < n_my; ++it) {
-            const float* park_r = park0 + (size_t)((it + 1) & 1) * (PARK / 4);
-            // the wide orientation's row offsets do not change from tile to tile: left to itself the compiler hoists eight chunks'
-            // worth of 64-bit addresses (x p, m, v, copy) out of the loop and spills; an opaque copy per tile keeps them short-lived
-            int srow_t = srow;
-            asm volatile("" : "+v"(srow_t));
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int cc = 0; cc < CPS; ++cc) {
-                    const int c = s * CPS + cc;
-                    finish_chunk(c, t0 + it - 1, park_r, srow_t);
-                    const size_t off = s_offset(t0 + it, c, srow_t);
-                    big[c] = __builtin_bit_cast(dw_u32x4, dw_ld_nt(p.adam.p + off));
-                    big[8 + c] = __builtin_bit_cast(dw_u32x4, dw_ld_nt(p.adam.m + off));
-                    big[16 + c] = __builtin_bit_cast(dw_u32x4, dw_ld_nt(p.adam.v + off));
-                }
-            }
-        }
-        {
-            const float* park_r = park0 + (size_t)((n_my + 1) & 1) * (PARK / 4);
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int cc = 0; cc < CPS; ++cc) finish_chunk(s * CPS + cc, t0 + n_my - 1, park_r, srow);
-            }
-        }
-    }
-    dw_wait_vm<0>();   // the ring's trailing reloads must not outlive the workgroup
-}
-
-static int dw_panel_ok(const RtxDw& d, int cfg_tile_rows)
-{
-    const int Mp = d.m_tiles * cfg_tile_rows, Np = d.n_tiles * 128;
-    if (d.k_slices != 8 && d.k_slices != 4 && d.k_slices != 2) return 0;
-    if ((d.N_real & 3) != 0 || d.N_real < 4) return 0;
-    const bool in = Np > Mp;
-    const int n_panels = in ? Mp / 128 : Np / 128;
-    if ((in ? Mp : Np) % 128 != 0 || n_panels < 1 || n_panels > 16) return 0;
-    return 1;
-}
-
-static int dw_panel_launch(const RtxDw& d, int cfg_tile_rows, hipStream_t stream)
-{
-    constexpr int LDS = 4 * 64 * 128 + 2 * 128 * 68 * 4;
-    const int Mp = d.m_tiles * cfg_tile_rows, Np = d.n_tiles * 128;
-    const bool in = Np > Mp;
-    const int n_panels = in ? Mp / 128 : Np / 128, s_tiles = (in ? Np : Mp) / 64;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        RTX_HIP(hipGetDevice(&dev));
-        RTX_HIP(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount;
-    }
-    const int per_xcd = cus / 8 > 0 ? cus / 8 : 1;
-    const int groups = per_xcd / n_panels > 0 ? per_xcd / n_panels : 1;
-    const dim3 grid((unsigned)(8 * groups * n_panels));
-#define DW_PANEL_GO(IN_, NKS_)                                                                                                     \
-    {                                                                                                                              \
-        static bool configured = false;                                                                                            \
-        if (!configured) {                                                                                                         \
-            RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_panel<IN_, NKS_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));     \
-            configured = true;                                                                                                     \
-        }                                                                                                                          \
-        hipLaunchKernelGGL((rtx_dw_panel<IN_, NKS_>), grid, dim3(512), LDS, stream, d, n_panels, s_tiles, groups);                   \
-    }
-    if (in) {
-        if (d.k_slices == 8) DW_PANEL_GO(1, 8) else if (d.k_slices == 4) DW_PANEL_GO(1, 4) else DW_PANEL_GO(1, 2)
-    } else {
-        if (d.k_slices == 8) DW_PANEL_GO(0, 8) else if (d.k_slices == 4) DW_PANEL_GO(0, 4) else DW_PANEL_GO(0, 2)
-    }
-#undef DW_PANEL_GO
-    RTX_HIP(hipGetLastError());
-    return RTX_OK;
-}
-
-int rtx_dw_tile_rows(int cfg) { return (cfg == RTX_DW_64x128 || cfg == RTX_DW_PANEL) ? 64 : cfg == RTX_DW_128x128 ? 128 : 32; }
+int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : cfg == RTX_DW_128x128 ? 128 : 32; }
 
 template <int EPI> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
 {
@@ -608,16 +341,13 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     RTX_CHECK(d.A && d.B && d.m_tiles > 0 && d.n_tiles > 0 && d.k_slices >= 2, RTX_EINVAL, "dw: bad problem (%d x %d tiles, %d K slices)", d.m_tiles, d.n_tiles,
               d.k_slices);
     RTX_CHECK(epilogue == RTX_DW_GRAD || epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw: bad epilogue %d", epilogue);
-    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_PANEL, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
     if (epilogue == RTX_DW_ADAM) {
         RTX_CHECK((d.N_real & 3) == 0 && d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of a multiple of 4 floats (got %d)", d.N_real);
         RTX_CHECK(d.adam.p && d.adam.m && d.adam.v, RTX_EINVAL, "dw: Adam state is NULL");
         RTX_CHECK((((uintptr_t)d.adam.p | (uintptr_t)d.adam.m | (uintptr_t)d.adam.v | (uintptr_t)d.adam.gkeep) & 15) == 0, RTX_EINVAL,
                   "dw: Adam buffers must be 16-byte aligned");
-        // the panel-resident kernel takes the shapes it is built for (K_pad <= 512, a short dimension of <= 16 panels); everything
-        // else -- and every RTX_DW_GRAD launch -- runs the tile kernel with the same 64-row tiling
-        if (cfg == RTX_DW_PANEL && dw_panel_ok(d, 64)) return dw_panel_launch(d, 64, stream);
         return dw_launch_cfg<RTX_DW_ADAM>(d, cfg, stream);
     }
     RTX_CHECK((d.N_real & 3) != 0 || ((((uintptr_t)d.gW) & 15) == 0 && (((uintptr_t)d.g16) & 7) == 0), RTX_EINVAL, "dw: gradient buffers must be 16-byte aligned");

@@ -35,6 +35,8 @@ struct Layer {
     int in = 0, out = 0, inp = 0, outp = 0;
     bool tanh_act = false;
     void* Wsh = nullptr;      // the compute copy every reader of this step uses
+    void* A_alt = nullptr;    // layer 0: second input buffer (they alternate: the next step's gather runs while the encoder matrix's
+                              // weight kernel of a RTX_STEP_DEFER_JOIN step still reads this one, see loss_grads_impl)
     void* Wsh_alt = nullptr;  // the fused optimizer writes the NEXT step's copy here (they swap after the step), so the
                               // weight-gradient kernels may run beside the data-gradient chain that still reads Wsh
     void* A = nullptr;
@@ -79,13 +81,20 @@ struct rtx_engine {
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
-    hipEvent_t ev_done = nullptr;
+    hipEvent_t ev_in_done = nullptr;   // everything the step put on the side stream is complete
+    // RTX_STEP_DEFER_JOIN: work of the last fused step that the caller's stream has not been ordered behind yet
+    bool pend_in = false;    // (recorded in ev_in_done)
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
+    int opt_defer = 1;          // steps flagged RTX_STEP_DEFER_JOIN: the caller's stream is not ordered behind the side stream at the end
+                                //   of the step but where the NEXT step first needs it, so its gather runs beside the encoder matrix's
+                                //   kernel (358 -> 347.5 us/step).  (Also moving the decoder matrix's kernel beside the next forward
+                                //   pass instead of beside the data-gradient chain was measured at 360-365 us: it slows the forward's
+                                //   short launches by more than it frees the chain's; not kept.)  0 = off
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -347,6 +356,9 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     }
     for (int li = l0; li < l1; ++li) {
         Layer& l = e->L[li];
+        // a deferred step's side-stream work is joined where it is first needed: before the first product (the gather above ran
+        // beside the encoder matrix's weight kernel)
+        if (e->pend_in) { RTX_HIP(hipStreamWaitEvent(st, e->ev_in_done, 0)); e->pend_in = false; }
         if (li == e->NL - 1) {
             // logits = A x Wsh^T + b, one launch; K = hidden (short), output [Bp][n_items] f32
             RtxGemm g = {};
@@ -406,6 +418,14 @@ static int check_ready(rtx_engine* e, bool train)
     RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
     RTX_CHECK(e->bound, RTX_ESTATE, "rtx_engine_bind() has not been called");
     RTX_CHECK(!train || e->can_train, RTX_ESTATE, "engine was bound without gradient / Adam buffers");
+    return RTX_OK;
+}
+
+// Order `st` behind whatever a deferred step left running on the side stream.  Every entry point that reads or writes engine
+// state calls this first (the fused training step itself joins later, where it first needs the results).
+static int join_side(rtx_engine* e, hipStream_t st)
+{
+    if (e->pend_in) { RTX_HIP(hipStreamWaitEvent(st, e->ev_in_done, 0)); e->pend_in = false; }
     return RTX_OK;
 }
 
@@ -490,7 +510,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 3; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default
+int32_t rtx_abi_version(void) { return 4; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: RTX_STEP_DEFER_JOIN, rtx_engine_join, rtx_comm_*
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -582,6 +602,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
         ALLOC(l.Wsh, (size_t)l.outp * l.inp * es);
         if (e->bf16) ALLOC(l.Wsh_alt, (size_t)l.outp * l.inp * es);
         ALLOC(l.A, Bp * l.inp * es);
+        if (e->bf16 && li == 0) ALLOC(l.A_alt, Bp * l.inp * es);
         if (li < e->NL - 1) ALLOC(l.O32, Bp * l.outp * sizeof(float));
         ALLOC(l.D, Bp * l.outp * es);
         // scratch for the forward output and the backward-data output of this layer (with split-K slabs), at any batch
@@ -616,7 +637,7 @@ int rtx_engine_destroy(rtx_engine* e)
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_d)
         if (ev) (void)hipEventDestroy(ev);
-    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+    if (e->ev_in_done) (void)hipEventDestroy(e->ev_in_done);
     if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
@@ -636,6 +657,10 @@ int rtx_engine_tensor_shape(const rtx_engine* e, int32_t t, int32_t* rows, int32
 int rtx_engine_bind(rtx_engine* e, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq)
 {
     RTX_CHECK(e && params, RTX_EINVAL, "engine_bind: NULL argument");
+    if (e->pend_in) {   // a deferred step still writes through the pointers bound before
+        RTX_HIP(hipStreamSynchronize(e->side));
+        e->pend_in = false;
+    }
     const int n = 2 * e->NL;
     for (int t = 0; t < n; ++t) {
         RTX_CHECK(params[t], RTX_EINVAL, "engine_bind: params[%d] is NULL", t);
@@ -662,6 +687,7 @@ int rtx_engine_sync_shadows(rtx_engine* e, void* stream)
 {
     RTX_TRY(check_ready(e, false));
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
     a.update = 0;
@@ -679,6 +705,7 @@ int rtx_engine_forward(rtx_engine* e, const rtx_batch* batch, int32_t training, 
     RTX_TRY(check_ready(e, false));
     RTX_CHECK(logits, RTX_EINVAL, "forward: logits is NULL");
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
@@ -696,6 +723,7 @@ int rtx_engine_encode(rtx_engine* e, const rtx_batch* batch, int32_t training, c
     RTX_TRY(check_ready(e, false));
     RTX_CHECK(out0, RTX_EINVAL, "encode: out0 is NULL");
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
@@ -716,6 +744,7 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
     RTX_CHECK(z && logits, RTX_EINVAL, "decode: NULL argument");
     RTX_CHECK(batch >= 1 && batch <= e->cfg.max_batch, RTX_EINVAL, "decode: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     const int ne = e->cfg.n_enc, Bp = rtx_pad_batch(batch);
     Layer& l = e->L[ne];
@@ -741,12 +770,18 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
+    const bool dae_reg = !e->vae && step->lam != 0.f;
+    // RTX_STEP_DEFER_JOIN (fused two-stream step only; not with the DAE regulariser, whose norms read every parameter at the
+    // top of the step, nor when the caller wants the gradients kept): this step joins the side stream lazily (run_forward) and
+    // leaves its own side-stream work unjoined for the next call
+    const bool lazy = fuse && e->opt_two_stream && e->opt_defer > 0 && (step->flags & RTX_STEP_DEFER_JOIN) && !dae_reg &&
+                      !(step->flags & RTX_STEP_KEEP_GRADS) && !cb && e->shadows_valid;
+    if (!lazy) RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
     const int B = batch->batch, Bp = rtx_pad_batch(B), NL = e->NL;
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
-    const bool dae_reg = !e->vae && step->lam != 0.f;
     if (dae_reg) {
         TIMED("sumsq");
         RTX_TRY(launch_sumsq(e, st));
@@ -780,7 +815,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
         for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&e->ev_in_done, hipEventDisableTiming));
     }
     auto on_side = [&](int li) { return two && layer_is_big(e->L[li]); };
     auto reduce_loss = [&]() -> int {
@@ -799,8 +834,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d = {};
             d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-            // the panel-resident kernel is for the big matrices (hundreds of tiles per panel); small layers keep the tile kernel
-            const int dw_cfg = (e->opt_dw_cfg == RTX_DW_PANEL && !layer_is_big(l)) ? RTX_DW_64x128 : e->opt_dw_cfg;
+            const int dw_cfg = e->opt_dw_cfg;
             d.m_tiles = l.outp / rtx_dw_tile_rows(dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
             d.M_real = l.out; d.N_real = l.in;
             if (fused) {
@@ -892,11 +926,17 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             RTX_TRY(rtx_launch_adam(rest, e->bf16, rs));
         }
         if (two) {
+            RTX_HIP(hipEventRecord(e->ev_in_done, e->side));
             for (int li = 0; li < NL; ++li)
                 if (on_side(li) && layer_fusable(e, e->L[li])) std::swap(e->L[li].Wsh, e->L[li].Wsh_alt);
-            // everything the step did is ordered on the caller's stream when the call returns
-            RTX_HIP(hipEventRecord(e->ev_done, e->side));
-            RTX_HIP(hipStreamWaitEvent(st, e->ev_done, 0));
+            if (lazy) {
+                // the next step's gather runs while the encoder matrix's kernel still reads this step's input: it gets the other buffer
+                if (on_side(0) && e->L[0].A_alt) std::swap(e->L[0].A, e->L[0].A_alt);
+                e->pend_in = true;
+            } else {
+                // everything the step did is ordered on the caller's stream when the call returns
+                RTX_HIP(hipStreamWaitEvent(st, e->ev_in_done, 0));
+            }
         }
         e->shadows_valid = true;
     }
@@ -914,6 +954,7 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "apply_adam: step count must be >= 1");
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
     fill_adam_scalars(e, step, a, 0);
@@ -931,6 +972,7 @@ int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t la
     RTX_CHECK(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= e->NL, RTX_EINVAL, "apply_adam_layers: bad layer range [%d, %d) of %d",
               layer_lo, layer_hi, e->NL);
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a, layer_lo, layer_hi);
     if (grads_bf16)
@@ -956,6 +998,7 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
     const Layer& l = e->L[layer];
     RTX_CHECK(row_lo >= 0 && row_lo <= row_hi && row_hi <= l.outp, RTX_EINVAL, "apply_adam_rows: bad row range [%d, %d) of %d", row_lo, row_hi, l.outp);
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(join_side(e, st));
     RtxAdamArgs full = {}, a = {};
     fill_adam_tensors(e, full, layer, layer + 1);
     int ids[2];
@@ -989,6 +1032,10 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
 int rtx_engine_shadow_region(rtx_engine* e, int32_t layer, void** base, int32_t* padded_rows, int32_t* ld, int32_t* elem_bytes)
 {
     RTX_CHECK(e && layer >= 0 && layer < e->NL, RTX_EINVAL, "shadow_region: bad arguments");
+    if (e->pend_in) {   // no stream to order: wait for the deferred step's kernels here
+        RTX_HIP(hipStreamSynchronize(e->side));
+        e->pend_in = false;
+    }
     const Layer& l = e->L[layer];
     if (base) *base = l.Wsh;
     if (padded_rows) *padded_rows = l.outp;
@@ -1014,6 +1061,14 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
     return rtx_engine_apply_adam(e, step, stream);
 }
 
+// Orders `stream` behind everything steps flagged RTX_STEP_DEFER_JOIN left running: after this call (in stream order) the
+// parameters, the optimizer state and the compute copies are those of the last step.
+int rtx_engine_join(rtx_engine* e, void* stream)
+{
+    RTX_CHECK(e, RTX_EINVAL, "join: engine is NULL");
+    return join_side(e, (hipStream_t)stream);
+}
+
 // measurement knobs: one entry point instead of environment variables scattered over the kernels' launchers
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
 {
@@ -1027,8 +1082,13 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
         e->opt_side_low_prio = value != 0;
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
+    else if (k == "defer") {
+        RTX_CHECK(value == 0 || value == 1, RTX_EINVAL, "set_option: defer must be 0 or 1");
+        RTX_CHECK(!e->pend_in, RTX_ESTATE, "set_option: call rtx_engine_join() before changing 'defer'");
+        e->opt_defer = value;
+    }
     else if (k == "dw_cfg") {
-        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_PANEL, RTX_EINVAL, "set_option: dw_cfg must be 0..4");
+        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;
     } else if (k == "splitk") {
         RTX_CHECK(value >= 0, RTX_EINVAL, "set_option: splitk must be >= 0");
@@ -1046,7 +1106,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, defer, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;

@@ -573,7 +573,7 @@ int main(int argc, char** argv)
         }
         fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
     }
-    for (int cfg = 0; cfg < 5; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / panel-resident
+    for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
         fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
@@ -582,13 +582,6 @@ int main(int argc, char** argv)
         fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
         fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
     }
-    // panel-resident kernel: several tiles per workgroup (the ring and the optimizer stream run across tile boundaries), both
-    // orientations, chunks without tiles
-    fails += run_dw_case("panel-out", RTX_DW_PANEL, RTX_DW_ADAM, 2000, 600, 500, 0.f, 0.f, 1);
-    fails += run_dw_case("panel-in", RTX_DW_PANEL, RTX_DW_ADAM, 600, 2000, 500, 0.f, 0.f, 0);
-    fails += run_dw_case("panel-long-out", RTX_DW_PANEL, RTX_DW_ADAM, 49152 + 17, 100, 100, 0.1f, 0.001f, 1);
-    fails += run_dw_case("panel-long-in", RTX_DW_PANEL, RTX_DW_ADAM, 100, 49152 + 20, 100, 0.f, 0.f, 1);
-
     for (int form : {RTX_FORM_NN, RTX_FORM_TN}) {
         fails += run_f32_case("store", form, 256, 384, 352, 1, RTX_EPI_STORE, 256, 384);
         fails += run_f32_case("splitk3", form, 256, 384, 352, 3, RTX_EPI_STORE, 256, 384);
@@ -612,12 +605,12 @@ int main(int argc, char** argv)
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NN, RTX_DMA_256x256, 4096, 4096, 4096, 1, RTX_EPI_STORE);
         perf_dma("sq4k", RTX_FORM_NT, RTX_DMA_512x128, 4096, 4096, 4096, 1, RTX_EPI_STORE);
-        for (int cfg : {0, 2, 4}) {
+        for (int cfg : {0, 2}) {
             perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500);
             perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500);
             perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
             perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
-            if (cfg != 4) perf_dw("dW4 grad", cfg, RTX_DW_GRAD, 20108, 600, 500);
+            perf_dw("dW4 grad", cfg, RTX_DW_GRAD, 20108, 600, 500);
         }
         perf_dw("dW-hidden+adam", 0, RTX_DW_ADAM, 400, 600, 500);
         // ml-20m step shapes: fwd-1 / dH3 (skinny, split-K), logits, dW4 / dW1
