@@ -58,8 +58,9 @@ def parse():
     ap.add_argument("--users", type=int, default=None)
     ap.add_argument("--items", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-defer", action="store_true", help="every step joins its side-stream kernels before it returns (train_batch semantics)")
     ap.add_argument("--no-fp32-parity", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="engine measurement knob for an A/B run (include/rectorch_hip.h, rtx_engine_set_option)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cond-dim", type=int, default=0,
                     help="measure the conditioned variant (CMultiVAE, SURVEY 8f-4): this many condition columns are "
@@ -224,12 +225,14 @@ def main():
     torch.manual_seed(1000 + rank)
 
     def run(n, start):
-        # what MultiVAE.train_epoch does with a device-resident sampler: back-to-back steps that leave their two big optimizer
-        # kernels running for the next step to join (RTX_STEP_DEFER_JOIN), and one join at the end of the stretch
         for i in range(n):
-            model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False, defer=not args.no_defer)
-        model._join()
+            model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
 
+    if args.opt:
+        run(1, 0)                                       # the first step creates the engine
+        for kv in args.opt:                             # measurement knobs (rtx_engine_set_option), e.g. --opt two_stream=0
+            k, v = kv.split("=")
+            net._rtx_engines[args.numerics].set_option(k, int(v))
     run(args.warmup, 0)
     torch.cuda.synchronize()
     _flush_c_stdio()

@@ -85,12 +85,6 @@ typedef struct {
 /* Mult-DAE under data parallelism: the regulariser lam * sum ||W||_2 is the same on every rank, so only ONE rank may add
  * it to the loss it reports before the ranks' losses are summed; the others set this bit (the update itself is unchanged) */
 #define RTX_STEP_NO_REG_IN_LOSS 2
-/* Training loops (bf16 fused step): do not order the caller's stream behind the step's side-stream kernels (the two big weight-
- * gradient + Adam launches) when the call returns; the NEXT rtx_engine_train_step joins them where it first needs their results
- * -- its input gather runs beside the encoder matrix's kernel -- and every other engine entry point joins them on entry.  The caller promises not to touch the bound parameter /
- * optimizer-state buffers from outside the engine until it has called rtx_engine_join() (or any other engine entry point) on
- * the stream it uses.  Ignored (the step joins as usual) in float32 numerics, with the Mult-DAE regulariser and with KEEP_GRADS. */
-#define RTX_STEP_DEFER_JOIN 4
 
 /* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
  * have been enqueued; layers complete in reverse order (last decoder layer first).  A data-parallel
@@ -253,14 +247,9 @@ int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* 
 int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
                         const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream);
 
-/* Orders `stream` behind everything steps flagged RTX_STEP_DEFER_JOIN left running on the engine's side stream: after it (in
- * stream order) parameters, optimizer state and compute copies are those of the last step.  A no-op when nothing is pending. */
-int rtx_engine_join(rtx_engine* e, void* stream);
-
 /* measurement knobs of one engine (the defaults are the shipped configuration): key "fuse_adam" (0/1, bf16 step:
  * Adam inside the weight-gradient kernels), "two_stream" (0/1: the two big ones on a second stream beside the
- * data-gradient chain), "side_low_prio" (0/1: that stream at the lowest priority; before the first step), "defer" (0/1: whether steps
- * flagged RTX_STEP_DEFER_JOIN really defer the join), "lse_fuse" (0/1:
+ * data-gradient chain), "side_low_prio" (0/1: that stream at the lowest priority; before the first step), "lse_fuse" (0/1:
  * log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the big NT contractions on the register-staged GEMM
  * instead of the LDS-DMA one), "dw_cfg" (0..3: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic).  Replaces round 1's
  * RTX_* environment switches. */

@@ -17,7 +17,6 @@ RTX_VAE, RTX_DAE = 0, 1
 RTX_FP32, RTX_BF16 = 0, 1
 RTX_STEP_KEEP_GRADS = 1
 RTX_STEP_NO_REG_IN_LOSS = 2
-RTX_STEP_DEFER_JOIN = 4
 NUMERICS = {"fp32": RTX_FP32, "bf16": RTX_BF16}
 
 
@@ -104,7 +103,6 @@ SIGNATURES = {
     "rtx_svae_forward": (C.c_int, [_P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P, _P, _P, _P]),
     "rtx_svae_train_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(Step), _P, _P, _P]),
     "rtx_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
-    "rtx_engine_join": (C.c_int, [_P, _P]),
     "rtx_engine_set_timing": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rtx_engine_get_timings": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     "rtx_engine_step_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -141,7 +141,7 @@ __device__ __forceinline__ float dw_dae_reg(const RtxDw& p)
 
 // WM x WN waves; a wave owns 32 x (128 / WN) of the tile (NJ = 4 / WN accumulators): tile = (32 WM) x 128
 template <int WM, int WN, int NS, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn(const RtxDw p)
+__device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   // bid: workgroup number within this problem's grid
 {
     constexpr int NW = WM * WN, NTH = NW * 64, TM = WM * 32, NJ = 4 / WN;
     constexpr int SA = TM * 2, SBB = 256;                       // bytes of one k-row of the A / B slice images
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 
     {
         const int total = p.m_tiles * p.n_tiles;
         const int per_xcd = (total + 7) / 8;
-        const int id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        const int id = (int)(bid & 7) * per_xcd + (int)(bid >> 3);
         if (id >= total) return;
         if (p.n_tiles <= p.m_tiles) { tm = id / p.n_tiles; tn = id % p.n_tiles; }
         else { tn = id / p.m_tiles; tm = id % p.m_tiles; }
@@ -307,17 +307,65 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 
     }
 }
 
+template <int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn(const RtxDw p)
+{
+    dw_tile<WM, WN, NS, EPI>(p, blockIdx.x);
+}
+
+// Several matrices in ONE launch (same K, same tile configuration, same epilogue): problem k owns the workgroups
+// [first[k], first[k + 1]) -- every count a multiple of 8, so a workgroup's XCD is the same as in a launch of its own.
+// The engine folds the small layers' weight kernels into the encoder matrix's launch: beside a 1580-workgroup streaming kernel
+// a 35-workgroup launch of its own waits for slots and crawls (53 + 33 us measured for two kernels that take 12 us each alone).
+struct RtxDwGroup {
+    int n;
+    unsigned first[RTX_DW_GROUP_MAX + 1];
+    RtxDw p[RTX_DW_GROUP_MAX];
+};
+template <int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn_group(const RtxDwGroup g)
+{
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < RTX_DW_GROUP_MAX; ++q)
+        if (q < g.n && blockIdx.x >= g.first[q]) k = q;
+    dw_tile<WM, WN, NS, EPI>(g.p[k], blockIdx.x - g.first[k]);
+}
+
+template <int WM, int WN, int NS, int EPI> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream)
+{
+    constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
+    static bool configured = false;
+    if (!configured) {
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn_group<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        configured = true;
+    }
+    RtxDwGroup g = {};
+    g.n = n;
+    unsigned total = 0;
+    for (int k = 0; k < n; ++k) {
+        g.first[k] = total;
+        g.p[k] = d[k];
+        total += (unsigned)(8 * ((d[k].m_tiles * d[k].n_tiles + 7) / 8));
+    }
+    g.first[n] = total;
+    hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
 template <int WM, int WN, int NS, int EPI> static int dw_launch(const RtxDw& d, hipStream_t stream)
 {
     constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
     const int total = d.m_tiles * d.n_tiles;
     const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
-    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI>), grid, dim3(WM * WN * 64), LDS, stream, d);
+    const int lds = LDS + (d.lds_pad > 0 ? d.lds_pad : 0) > 160 * 1024 ? 160 * 1024 : LDS + (d.lds_pad > 0 ? d.lds_pad : 0);
+    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI>), grid, dim3(WM * WN * 64), lds, stream, d);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -352,4 +400,26 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     }
     RTX_CHECK((d.N_real & 3) != 0 || ((((uintptr_t)d.gW) & 15) == 0 && (((uintptr_t)d.g16) & 7) == 0), RTX_EINVAL, "dw: gradient buffers must be 16-byte aligned");
     return dw_launch_cfg<RTX_DW_GRAD>(d, cfg, stream);
+}
+
+// d[0..n): same d.k_slices; small problems first keeps the big one's tail free of stragglers
+int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_t stream)
+{
+    RTX_CHECK(d && n >= 1 && n <= RTX_DW_GROUP_MAX, RTX_EINVAL, "dw group: 1..%d problems (got %d)", RTX_DW_GROUP_MAX, n);
+    if (n == 1) return rtx_dw_launch(d[0], epilogue, cfg, stream);
+    RTX_CHECK(epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw group: only the fused Adam epilogue is launched in groups");
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    for (int k = 0; k < n; ++k) {
+        const RtxDw& q = d[k];
+        RTX_CHECK(q.A && q.B && q.m_tiles > 0 && q.n_tiles > 0 && q.k_slices >= 2 && q.k_slices == d[0].k_slices, RTX_EINVAL, "dw group: bad problem %d", k);
+        RTX_CHECK(q.M_real >= 1 && (q.N_real & 3) == 0 && q.N_real >= 4 && q.adam.p && q.adam.m && q.adam.v, RTX_EINVAL, "dw group: problem %d is not fusable", k);
+        RTX_CHECK((((uintptr_t)q.adam.p | (uintptr_t)q.adam.m | (uintptr_t)q.adam.v | (uintptr_t)q.adam.gkeep) & 15) == 0, RTX_EINVAL,
+                  "dw: Adam buffers must be 16-byte aligned");
+    }
+    switch (cfg) {
+    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, RTX_DW_ADAM>(d, n, stream);
+    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, RTX_DW_ADAM>(d, n, stream);
+    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, RTX_DW_ADAM>(d, n, stream);
+    default: return dw_launch_group<2, 4, 3, RTX_DW_ADAM>(d, n, stream);
+    }
 }

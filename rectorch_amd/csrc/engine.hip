@@ -35,8 +35,6 @@ struct Layer {
     int in = 0, out = 0, inp = 0, outp = 0;
     bool tanh_act = false;
     void* Wsh = nullptr;      // the compute copy every reader of this step uses
-    void* A_alt = nullptr;    // layer 0: second input buffer (they alternate: the next step's gather runs while the encoder matrix's
-                              // weight kernel of a RTX_STEP_DEFER_JOIN step still reads this one, see loss_grads_impl)
     void* Wsh_alt = nullptr;  // the fused optimizer writes the NEXT step's copy here (they swap after the step), so the
                               // weight-gradient kernels may run beside the data-gradient chain that still reads Wsh
     void* A = nullptr;
@@ -81,20 +79,16 @@ struct rtx_engine {
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
-    hipEvent_t ev_in_done = nullptr;   // everything the step put on the side stream is complete
-    // RTX_STEP_DEFER_JOIN: work of the last fused step that the caller's stream has not been ordered behind yet
-    bool pend_in = false;    // (recorded in ev_in_done)
+    hipEvent_t ev_done = nullptr;      // everything the step put on the side stream is complete
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
-    int opt_defer = 1;          // steps flagged RTX_STEP_DEFER_JOIN: the caller's stream is not ordered behind the side stream at the end
-                                //   of the step but where the NEXT step first needs it, so its gather runs beside the encoder matrix's
-                                //   kernel (358 -> 347.5 us/step).  (Also moving the decoder matrix's kernel beside the next forward
-                                //   pass instead of beside the data-gradient chain was measured at 360-365 us: it slows the forward's
-                                //   short launches by more than it frees the chain's; not kept.)  0 = off
+    int opt_event_device_scope = 1;   // events released at device scope (set before the first step)
+    int opt_out_lds_pad = 0;    // extra dynamic LDS (bytes) requested by the decoder matrix's kernel: > 8 KB leaves one workgroup per CU
+    int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -170,7 +164,7 @@ struct ScopedTimer {
             if (!e->event_pool.empty()) {
                 ev = e->event_pool.back();
                 e->event_pool.pop_back();
-            } else if (hipEventCreate(&ev) != hipSuccess) {
+            } else if (hipEventCreateWithFlags(&ev, e->opt_event_device_scope ? hipEventReleaseToDevice : hipEventDefault) != hipSuccess) {
                 ev = nullptr;
             }
             return ev;
@@ -356,9 +350,6 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     }
     for (int li = l0; li < l1; ++li) {
         Layer& l = e->L[li];
-        // a deferred step's side-stream work is joined where it is first needed: before the first product (the gather above ran
-        // beside the encoder matrix's weight kernel)
-        if (e->pend_in) { RTX_HIP(hipStreamWaitEvent(st, e->ev_in_done, 0)); e->pend_in = false; }
         if (li == e->NL - 1) {
             // logits = A x Wsh^T + b, one launch; K = hidden (short), output [Bp][n_items] f32
             RtxGemm g = {};
@@ -418,14 +409,6 @@ static int check_ready(rtx_engine* e, bool train)
     RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
     RTX_CHECK(e->bound, RTX_ESTATE, "rtx_engine_bind() has not been called");
     RTX_CHECK(!train || e->can_train, RTX_ESTATE, "engine was bound without gradient / Adam buffers");
-    return RTX_OK;
-}
-
-// Order `st` behind whatever a deferred step left running on the side stream.  Every entry point that reads or writes engine
-// state calls this first (the fused training step itself joins later, where it first needs the results).
-static int join_side(rtx_engine* e, hipStream_t st)
-{
-    if (e->pend_in) { RTX_HIP(hipStreamWaitEvent(st, e->ev_in_done, 0)); e->pend_in = false; }
     return RTX_OK;
 }
 
@@ -510,7 +493,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 4; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: RTX_STEP_DEFER_JOIN, rtx_engine_join, rtx_comm_*
+int32_t rtx_abi_version(void) { return 4; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -602,7 +585,6 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
         ALLOC(l.Wsh, (size_t)l.outp * l.inp * es);
         if (e->bf16) ALLOC(l.Wsh_alt, (size_t)l.outp * l.inp * es);
         ALLOC(l.A, Bp * l.inp * es);
-        if (e->bf16 && li == 0) ALLOC(l.A_alt, Bp * l.inp * es);
         if (li < e->NL - 1) ALLOC(l.O32, Bp * l.outp * sizeof(float));
         ALLOC(l.D, Bp * l.outp * es);
         // scratch for the forward output and the backward-data output of this layer (with split-K slabs), at any batch
@@ -637,7 +619,7 @@ int rtx_engine_destroy(rtx_engine* e)
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_d)
         if (ev) (void)hipEventDestroy(ev);
-    if (e->ev_in_done) (void)hipEventDestroy(e->ev_in_done);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
@@ -657,10 +639,6 @@ int rtx_engine_tensor_shape(const rtx_engine* e, int32_t t, int32_t* rows, int32
 int rtx_engine_bind(rtx_engine* e, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq)
 {
     RTX_CHECK(e && params, RTX_EINVAL, "engine_bind: NULL argument");
-    if (e->pend_in) {   // a deferred step still writes through the pointers bound before
-        RTX_HIP(hipStreamSynchronize(e->side));
-        e->pend_in = false;
-    }
     const int n = 2 * e->NL;
     for (int t = 0; t < n; ++t) {
         RTX_CHECK(params[t], RTX_EINVAL, "engine_bind: params[%d] is NULL", t);
@@ -687,7 +665,6 @@ int rtx_engine_sync_shadows(rtx_engine* e, void* stream)
 {
     RTX_TRY(check_ready(e, false));
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
     a.update = 0;
@@ -705,7 +682,6 @@ int rtx_engine_forward(rtx_engine* e, const rtx_batch* batch, int32_t training, 
     RTX_TRY(check_ready(e, false));
     RTX_CHECK(logits, RTX_EINVAL, "forward: logits is NULL");
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
@@ -723,7 +699,6 @@ int rtx_engine_encode(rtx_engine* e, const rtx_batch* batch, int32_t training, c
     RTX_TRY(check_ready(e, false));
     RTX_CHECK(out0, RTX_EINVAL, "encode: out0 is NULL");
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
@@ -744,7 +719,6 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
     RTX_CHECK(z && logits, RTX_EINVAL, "decode: NULL argument");
     RTX_CHECK(batch >= 1 && batch <= e->cfg.max_batch, RTX_EINVAL, "decode: batch %d outside [1,%d]", batch, e->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     const int ne = e->cfg.n_enc, Bp = rtx_pad_batch(batch);
     Layer& l = e->L[ne];
@@ -771,12 +745,6 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
     const bool dae_reg = !e->vae && step->lam != 0.f;
-    // RTX_STEP_DEFER_JOIN (fused two-stream step only; not with the DAE regulariser, whose norms read every parameter at the
-    // top of the step, nor when the caller wants the gradients kept): this step joins the side stream lazily (run_forward) and
-    // leaves its own side-stream work unjoined for the next call
-    const bool lazy = fuse && e->opt_two_stream && e->opt_defer > 0 && (step->flags & RTX_STEP_DEFER_JOIN) && !dae_reg &&
-                      !(step->flags & RTX_STEP_KEEP_GRADS) && !cb && e->shadows_valid;
-    if (!lazy) RTX_TRY(join_side(e, st));
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
@@ -814,46 +782,62 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         int prio_least = 0, prio_greatest = 0;
         RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
-        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&e->ev_in_done, hipEventDisableTiming));
+        // the events order two streams of ONE device: a device-scope release (no system-scope cache write-back at the record)
+        const unsigned evf = hipEventDisableTiming | (e->opt_event_device_scope ? hipEventReleaseToDevice : 0);
+        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], evf));
+        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, evf));
     }
-    auto on_side = [&](int li) { return two && layer_is_big(e->L[li]); };
-    auto reduce_loss = [&]() -> int {
-        TIMED("reduce_loss");
+    // The encoder matrix's kernel is the END of the step's critical path (it needs D[0], the last thing the chain produces, and
+    // the next step's first product needs its result).  A cross-stream dependency costs about 18 us from the event's record to
+    // the first workgroup of the waiting stream and a record about 7 us on the recording stream (profiles/r2_step_timeline.txt),
+    // so that kernel stays on the CALLER's stream right behind the chain -- no hop before it, none after it -- and takes the small
+    // layers' weight kernels with it in the same launch (as launches of their own beside it they crawl: 53 + 33 us).
+    const int main_li = (two && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
+    auto on_side = [&](int li) { return two && layer_is_big(e->L[li]) && li != main_li; };
+    auto reduce_loss = [&](hipStream_t ws) -> int {
+        ScopedTimer tm(e, "reduce_loss", ws);
         const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);
         return rtx_launch_reduce_loss(e->row_loss, B * rtx_dlogits_chunks(e->Ip), step->lam, reg_in_loss ? e->sumsq : nullptr, 2 * NL, loss_out,
-                                      loss_accum, st);
+                                      loss_accum, ws);
     };
     // weight + bias gradient of layer li on stream ws: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column
     // `in` of the product (the ones column of A) is the bias gradient
+    // bf16: the weight-gradient problem of layer li (fused with Adam where the layer allows it)
+    auto make_dw = [&](int li, RtxDw& d) -> bool {
+        Layer& l = e->L[li];
+        const bool fused = fuse && layer_fusable(e, l);
+        d = RtxDw{};
+        d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
+        d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+        d.M_real = l.out; d.N_real = l.in;
+        if (fused) {
+            RtxAdamArgs sc = {};
+            fill_adam_scalars(e, step, sc, 2 * li);
+            const bool keep = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
+            d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
+            d.adam.gkeep = keep ? e->grads[2 * li] : nullptr;
+            d.gbias = keep ? e->grads[2 * li + 1] : nullptr;
+            d.adam.sh = on_side(li) ? l.Wsh_alt : l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
+            d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
+            d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
+            d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
+            d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
+            d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
+        } else {
+            d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
+        }
+        return fused;
+    };
     auto weight_grad = [&](int li, hipStream_t ws) -> int {
         Layer& l = e->L[li];
         const bool fused = fuse && layer_fusable(e, l);
         const char* site = li == NL - 1 ? (fused ? "dW_adam_out" : "gemm_dW_out") : (li == 0 ? (fused ? "dW_adam_in" : "gemm_dW_in") : (fused ? "dW_adam_hidden" : "gemm_dW_hidden"));
         ScopedTimer tm(e, site, ws);
         if (e->bf16) {
-            RtxDw d = {};
-            d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-            const int dw_cfg = e->opt_dw_cfg;
-            d.m_tiles = l.outp / rtx_dw_tile_rows(dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
-            d.M_real = l.out; d.N_real = l.in;
-            if (fused) {
-                RtxAdamArgs sc = {};
-                fill_adam_scalars(e, step, sc, 2 * li);
-                const bool keep = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
-                d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
-                d.adam.gkeep = keep ? e->grads[2 * li] : nullptr;
-                d.gbias = keep ? e->grads[2 * li + 1] : nullptr;
-                d.adam.sh = on_side(li) ? l.Wsh_alt : l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
-                d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
-                d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
-                d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
-                d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
-                d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
-                return rtx_dw_launch(d, RTX_DW_ADAM, dw_cfg, ws);
-            }
-            d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
-            return rtx_dw_launch(d, RTX_DW_GRAD, dw_cfg, ws);
+            RtxDw d;
+            make_dw(li, d);
+            if (ws == e->side && ws != st && li == NL - 1) d.lds_pad = e->opt_out_lds_pad;
+            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, e->opt_dw_cfg, ws);
         }
         RtxGemm g = {};
         g.form = RTX_FORM_TN;
@@ -863,7 +847,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         g.M_real = l.out; g.N_real = l.in;
         return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
     };
-    if (!two) RTX_TRY(reduce_loss());
+    if (!two) RTX_TRY(reduce_loss(st));
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
         if (on_side(li)) {   // the long kernel first: it only needs D[li], which exists now
@@ -907,12 +891,36 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (cb) cb(li, user);
     }
     hipStream_t rs = st;    // the stream the leftover Adam launch runs on
-    if (two) {
+    if (two && main_li >= 0) {
+        // behind the chain, on this stream: the encoder matrix's kernel and the small layers' (their compute copies have no
+        // reader left) ...
+        // ... ONE launch for the encoder matrix and the small fusable layers (small problems first); small layers that are not
+        // fusable store their gradients first, for the leftover Adam launch.  The loss reduction only needs what the loss kernel
+        // wrote: it goes behind the decoder matrix's kernel on the side stream (no new event).
+        RtxDw grp[RTX_DW_GROUP_MAX];
+        int ng = 0;
+        for (int li = NL - 1; li >= 1; --li) {
+            if (on_side(li)) continue;
+            if (fuse && layer_fusable(e, e->L[li]) && ng < RTX_DW_GROUP_MAX - 1) make_dw(li, grp[ng++]);
+            else RTX_TRY(weight_grad(li, st));
+        }
+        make_dw(main_li, grp[ng++]);
+        {
+            ScopedTimer tm(e, "dW_adam_in", st);
+            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, e->opt_dw_cfg, st));
+        }
+        RTX_TRY(reduce_loss(e->side));
+        if (rest.n > 0) {   // gradients from both streams feed the leftover Adam launch: the side stream waits for this one, then runs it
+            RTX_HIP(hipEventRecord(e->ev_d[NL], st));
+            RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[NL], 0));
+            rs = e->side;
+        }
+    } else if (two) {
         // behind the chain, beside the encoder matrix's kernel: the small layers' weight kernels (their compute copies have
         // no reader left on this stream) and the loss reduction
         for (int li = NL - 1; li >= 0; --li)
             if (!on_side(li)) RTX_TRY(weight_grad(li, st));
-        RTX_TRY(reduce_loss());
+        RTX_TRY(reduce_loss(st));
         if (rest.n > 0) {   // gradients from both streams feed it: the side stream waits for this one, then runs it
             RTX_HIP(hipEventRecord(e->ev_d[NL], st));
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[NL], 0));
@@ -926,17 +934,11 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             RTX_TRY(rtx_launch_adam(rest, e->bf16, rs));
         }
         if (two) {
-            RTX_HIP(hipEventRecord(e->ev_in_done, e->side));
             for (int li = 0; li < NL; ++li)
                 if (on_side(li) && layer_fusable(e, e->L[li])) std::swap(e->L[li].Wsh, e->L[li].Wsh_alt);
-            if (lazy) {
-                // the next step's gather runs while the encoder matrix's kernel still reads this step's input: it gets the other buffer
-                if (on_side(0) && e->L[0].A_alt) std::swap(e->L[0].A, e->L[0].A_alt);
-                e->pend_in = true;
-            } else {
-                // everything the step did is ordered on the caller's stream when the call returns
-                RTX_HIP(hipStreamWaitEvent(st, e->ev_in_done, 0));
-            }
+            // everything the step did is ordered on the caller's stream when the call returns
+            RTX_HIP(hipEventRecord(e->ev_done, e->side));
+            RTX_HIP(hipStreamWaitEvent(st, e->ev_done, 0));
         }
         e->shadows_valid = true;
     }
@@ -954,7 +956,6 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "apply_adam: step count must be >= 1");
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
     fill_adam_scalars(e, step, a, 0);
@@ -972,7 +973,6 @@ int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t la
     RTX_CHECK(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= e->NL, RTX_EINVAL, "apply_adam_layers: bad layer range [%d, %d) of %d",
               layer_lo, layer_hi, e->NL);
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a, layer_lo, layer_hi);
     if (grads_bf16)
@@ -998,7 +998,6 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
     const Layer& l = e->L[layer];
     RTX_CHECK(row_lo >= 0 && row_lo <= row_hi && row_hi <= l.outp, RTX_EINVAL, "apply_adam_rows: bad row range [%d, %d) of %d", row_lo, row_hi, l.outp);
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(join_side(e, st));
     RtxAdamArgs full = {}, a = {};
     fill_adam_tensors(e, full, layer, layer + 1);
     int ids[2];
@@ -1032,10 +1031,6 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
 int rtx_engine_shadow_region(rtx_engine* e, int32_t layer, void** base, int32_t* padded_rows, int32_t* ld, int32_t* elem_bytes)
 {
     RTX_CHECK(e && layer >= 0 && layer < e->NL, RTX_EINVAL, "shadow_region: bad arguments");
-    if (e->pend_in) {   // no stream to order: wait for the deferred step's kernels here
-        RTX_HIP(hipStreamSynchronize(e->side));
-        e->pend_in = false;
-    }
     const Layer& l = e->L[layer];
     if (base) *base = l.Wsh;
     if (padded_rows) *padded_rows = l.outp;
@@ -1061,14 +1056,6 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
     return rtx_engine_apply_adam(e, step, stream);
 }
 
-// Orders `stream` behind everything steps flagged RTX_STEP_DEFER_JOIN left running: after this call (in stream order) the
-// parameters, the optimizer state and the compute copies are those of the last step.
-int rtx_engine_join(rtx_engine* e, void* stream)
-{
-    RTX_CHECK(e, RTX_EINVAL, "join: engine is NULL");
-    return join_side(e, (hipStream_t)stream);
-}
-
 // measurement knobs: one entry point instead of environment variables scattered over the kernels' launchers
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
 {
@@ -1082,10 +1069,14 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
         e->opt_side_low_prio = value != 0;
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
-    else if (k == "defer") {
-        RTX_CHECK(value == 0 || value == 1, RTX_EINVAL, "set_option: defer must be 0 or 1");
-        RTX_CHECK(!e->pend_in, RTX_ESTATE, "set_option: call rtx_engine_join() before changing 'defer'");
-        e->opt_defer = value;
+    else if (k == "in_on_main") e->opt_in_on_main = value != 0;
+    else if (k == "event_device_scope") {
+        RTX_CHECK(!e->side, RTX_ESTATE, "set_option: event_device_scope must be set before the first training step");
+        e->opt_event_device_scope = value != 0;
+    }
+    else if (k == "out_lds_pad") {
+        RTX_CHECK(value >= 0 && value <= 80 * 1024, RTX_EINVAL, "set_option: out_lds_pad must be 0..81920 bytes");
+        e->opt_out_lds_pad = value;
     }
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
@@ -1106,7 +1097,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, defer, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, event_device_scope, out_lds_pad, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;

@@ -101,9 +101,13 @@ struct RtxDw {
     float* bias_m;       //   with the scalars of `adam`
     float* bias_v;
     const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
+    int lds_pad;         // extra dynamic LDS bytes to request (occupancy throttle for a launch that runs beside latency-bound kernels)
 };
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
+#define RTX_DW_GROUP_MAX 6
+// the same for up to RTX_DW_GROUP_MAX matrices in ONE launch (RTX_DW_ADAM only; equal k_slices)
+int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_t stream);
 
 // Gram matrix of the EASE solver (syrk.hip): C[m][n] = sum_k A[m][k] A[n][k] for the 128-column tiles on or below the
 // diagonal; A has 256 * rows256 zero-padded rows of k_slices * 128 bytes (fp8 e4m3 or bf16; element (row, slice ks) at

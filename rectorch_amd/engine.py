@@ -277,13 +277,9 @@ class Engine:
         check(lib().rtx_engine_train_step(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           stream_ptr()))
 
-    def join(self):
-        """Order the current stream behind what steps flagged RTX_STEP_DEFER_JOIN left running (include/rectorch_hip.h)."""
-        check(lib().rtx_engine_join(self.handle, stream_ptr()))
-
     # ---- instrumentation --------------------------------------------------------------------------
     def set_option(self, key, value):
-        """measurement knobs of the engine ("fuse_adam", "two_stream", "defer", "lse_fuse", "dw_cfg", "splitk", ...; include/rectorch_hip.h)"""
+        """measurement knobs of the engine ("fuse_adam", "two_stream", "lse_fuse", "dw_cfg", "splitk", ...; include/rectorch_hip.h)"""
         check(lib().rtx_engine_set_option(self.handle, key.encode(), int(value)))
 
     def set_timing(self, site=None, enable=True):

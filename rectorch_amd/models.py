@@ -55,7 +55,6 @@ class _RtxState:
         self.loss_buf = None      # [0] = last loss, [1] = running sum since the last read-back
         self.reducer = None       # data parallel: rectorch_amd.parallel.GradAllReducer
         self.masters_sharded = False   # sharded optimizer: the float32 master rows of other ranks are stale until gathered
-        self.defer_engine = None  # the engine whose last steps were flagged RTX_STEP_DEFER_JOIN and have not been joined yet
         self.inject = None        # parity tests: (dropout keep-mask, eps) captured from the reference's RNG
 
     def __repr__(self):
@@ -211,25 +210,14 @@ class AETrainer(TorchNNTrainer):
         for done, item in enumerate(train_loader.iter_rows() if resident else train_loader, 1):
             if resident:
                 rows = item if self._uses_te or item.te is None else RowBatch(item.tr, None, item.rows)
-                # back-to-back steps: each one leaves its two big optimizer kernels running and the next joins them where it
-                # needs their results (RTX_STEP_DEFER_JOIN); nothing outside the engine looks at the parameters in between
-                self._fused_step(rows, None, want_loss=False, defer=True)
+                self._fused_step(rows, None, want_loss=False)
             else:
                 data, gt = item
                 pending += self.train_batch(data, gt)
             if log.due(done):
                 log.stretch(done, self._read_loss_sum() if resident else pending)
                 pending = 0.0
-        self._join()
         log.finish(self._read_loss_sum() if resident else pending)
-
-    def _join(self):
-        """After deferred steps: order the current stream behind the engine's side stream, so that the parameters and the
-        optimizer state can be read with ordinary torch operations again."""
-        eng = self._rtx.defer_engine
-        if eng is not None:
-            eng.join()
-            self._rtx.defer_engine = None
 
     def train_batch(self, tr_batch, te_batch=None):
         r"""Training of a single batch (reference models.py:424-447): the loss target is the batch itself
@@ -278,7 +266,7 @@ class AETrainer(TorchNNTrainer):
         v = [self.optimizer.state[p]['exp_avg_sq'] for p in params]
         return st, params, m, v
 
-    def _fused_step(self, x, target, want_loss=True, defer=False):
+    def _fused_step(self, x, target, want_loss=True):
         _lib.require_gpu()
         st, params, m, v = self._ensure_train_state()
         if not isinstance(x, RowBatch):
@@ -299,18 +287,11 @@ class AETrainer(TorchNNTrainer):
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
                          eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
                          flags=(_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0) |
-                               (_lib.RTX_STEP_DEFER_JOIN if defer and red is None else 0) |
                                # data parallel: the (rank-independent) DAE regulariser enters the summed loss once
                                (_lib.RTX_STEP_NO_REG_IN_LOSS if red is not None and red.rank != 0 else 0))
         loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]
         if red is None:
-            if st.defer_engine is not None and st.defer_engine is not eng:
-                self._join()                # a different engine (batch capacity changed) took over: finish the old one's work first
             eng.train_step(x, target, step, loss_out, loss_acc)
-            if defer:
-                st.defer_engine = eng
-            elif st.defer_engine is eng:
-                st.defer_engine = None      # a step without the flag joins on entry
         else:
             if getattr(red, "bucket_adam", False):
                 g16 = red.grads16_ptrs()

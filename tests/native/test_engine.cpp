@@ -172,7 +172,7 @@ static std::vector<float> d2h(const float* d, size_t n)
 }
 
 static int g_fail = 0;
-static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_defer = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
+static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1, g_opt_evdev = 1, g_opt_outpad = 0;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
 static void apply_options(rtx_engine* eng)
 {
     rtx_engine_set_option(eng, "fuse_adam", g_opt_fuse);
@@ -181,7 +181,9 @@ static void apply_options(rtx_engine* eng)
     rtx_engine_set_option(eng, "two_stream", g_opt_two);
     rtx_engine_set_option(eng, "nt_regstage", g_opt_ntreg);
     rtx_engine_set_option(eng, "side_low_prio", g_opt_lowprio);
-    rtx_engine_set_option(eng, "defer", g_opt_defer);
+    rtx_engine_set_option(eng, "in_on_main", g_opt_inmain);
+    rtx_engine_set_option(eng, "event_device_scope", g_opt_evdev);
+    rtx_engine_set_option(eng, "out_lds_pad", g_opt_outpad);
 }
 static void check(const char* what, double err, double tol)
 {
@@ -428,7 +430,7 @@ static void philox_case()
 
 static void perf_case(int numerics, int B, int steps, int splitk)
 {
-    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d defer=%d nt_regstage=%d dw_cfg=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_defer, g_opt_ntreg, g_opt_dw_cfg);
+    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d ev_dev=%d out_pad=%d nt_regstage=%d dw_cfg=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_evdev, g_opt_outpad, g_opt_ntreg, g_opt_dw_cfg);
     Net net = make_net({20108, 600, 200}, {200, 600, 20108}, ORC_VAE, 0.5f, 0.1f);
     const int I = 20108, U = 4096;
     Csr tr;
@@ -463,14 +465,12 @@ static void perf_case(int numerics, int B, int steps, int splitk)
     bt.csr = ctr; bt.row_ids = d_ids; bt.batch = B;
     rtx_step sp = {};
     sp.beta = 0.1f; sp.inv_batch = 1.f / B; sp.lr = 1e-3f; sp.beta1 = .9f; sp.beta2 = .999f; sp.eps = 1e-8f; sp.seed = 1;
-    sp.flags = g_opt_defer ? RTX_STEP_DEFER_JOIN : 0;   // a training loop: back-to-back steps, one join at the end
     for (int i = 0; i < 5; ++i) { sp.step = i + 1; sp.offset = i; RT(rtx_engine_train_step(eng, &bt, &sp, d_loss, d_loss + 1, nullptr)); }
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < steps; ++i) { sp.step = 6 + i; sp.offset = 6 + i; RT(rtx_engine_train_step(eng, &bt, &sp, d_loss, d_loss + 1, nullptr)); }
-    RT(rtx_engine_join(eng, nullptr));
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -494,71 +494,6 @@ static void perf_case(int numerics, int B, int steps, int splitk)
     printf("      %-18s %26.1f us/step (event-bracketed sum)\n", "TOTAL", sum * 1000.0 / tsteps);
     RT(rtx_engine_set_timing(eng, nullptr, 0));
     rtx_engine_destroy(eng); rtx_csr_destroy(ctr); dt.release(); hipFree(d_ids); hipFree(d_loss);
-}
-
-// Steps flagged RTX_STEP_DEFER_JOIN (side-stream kernels joined lazily by the next step, whose gather runs beside them into the
-// alternate input buffer) must leave EXACTLY the state of steps that join before they return: same
-// kernels, same arithmetic, only their order on the streams differs.  Compared bit for bit after four steps and a join,
-// together with an evaluation forward through the refreshed compute copies; a foreign entry point (forward) in the middle of
-// the run must join by itself.
-static void defer_case(const char* name, const Net& net, int B, int U, float density)
-{
-    printf("[defer] %s B=%d\n", name, B);
-    const int I = net.enc[0], nt = (int)net.params.size();
-    Csr tr = make_csr(U, I, density, false, -1);
-    std::vector<std::vector<float>> ref_p, ref_m, ref_v;
-    std::vector<float> ref_logits;
-    for (int mode = 0; mode <= 1; ++mode) {
-        rtx_cfg rc = rcfg(net, RTX_BF16, B);
-        rtx_engine* eng;
-        RT(rtx_engine_create(&rc, &eng));
-        apply_options(eng);
-        RT(rtx_engine_set_option(eng, "defer", mode));
-        DevTensors dt;
-        dt.alloc(net);
-        RT(rtx_engine_bind(eng, dt.p.data(), dt.g.data(), dt.m.data(), dt.v.data()));
-        rtx_csr* ctr;
-        RT(rtx_csr_upload(tr.indptr.data(), tr.indices.data(), nullptr, tr.rows, I, &ctr));
-        std::vector<int32_t> ids(B);
-        for (int b = 0; b < B; ++b) ids[b] = (int32_t)((b * 7 + 3) % U);
-        int32_t* d_ids;
-        float *d_loss, *d_logits;
-        CK(hipMalloc(&d_ids, B * 4)); CK(hipMemcpy(d_ids, ids.data(), B * 4, hipMemcpyHostToDevice));
-        CK(hipMalloc(&d_loss, 8)); CK(hipMemset(d_loss, 0, 8));
-        CK(hipMalloc(&d_logits, (size_t)B * I * 4));
-        rtx_batch bt = {};
-        bt.csr = ctr; bt.row_ids = d_ids; bt.batch = B;
-        rtx_step sp = {};
-        sp.beta = 0.1f; sp.inv_batch = 1.f / B; sp.lr = 1e-3f; sp.beta1 = .9f; sp.beta2 = .999f; sp.eps = 1e-8f; sp.seed = 77;
-        sp.flags = mode ? RTX_STEP_DEFER_JOIN : 0;
-        for (int i = 0; i < 4; ++i) {
-            sp.step = i + 1; sp.offset = i;
-            RT(rtx_engine_train_step(eng, &bt, &sp, d_loss, d_loss + 1, nullptr));
-            if (i == 1) RT(rtx_engine_forward(eng, &bt, 0, nullptr, 0, d_logits, nullptr, nullptr, nullptr));   // joins on entry
-        }
-        RT(rtx_engine_join(eng, nullptr));
-        RT(rtx_engine_forward(eng, &bt, 0, nullptr, 0, d_logits, nullptr, nullptr, nullptr));
-        CK(hipDeviceSynchronize());
-        auto lg = d2h(d_logits, (size_t)B * I);
-        long diff = 0;
-        for (int t = 0; t < nt; ++t) {
-            auto pp = d2h(dt.p[t], net.params[t].size()), mm = d2h(dt.m[t], net.params[t].size()), vv = d2h(dt.v[t], net.params[t].size());
-            if (mode == 0) { ref_p.push_back(pp); ref_m.push_back(mm); ref_v.push_back(vv); }
-            else
-                for (size_t k = 0; k < pp.size(); ++k)
-                    diff += (memcmp(&pp[k], &ref_p[t][k], 4) != 0) + (memcmp(&mm[k], &ref_m[t][k], 4) != 0) + (memcmp(&vv[k], &ref_v[t][k], 4) != 0);
-        }
-        if (mode == 0) ref_logits = lg;
-        else {
-            for (size_t k = 0; k < lg.size(); ++k) diff += memcmp(&lg[k], &ref_logits[k], 4) != 0;
-            char nm[96];
-            snprintf(nm, sizeof nm, "defer=%d: parameters, moments and eval logits bit-identical to joined steps (differing words)", mode);
-            check(nm, (double)diff, 0.0);
-        }
-        float acc = d2h(d_loss + 1, 1)[0];
-        printf("    defer=%d loss_accum %.4f\n", mode, acc);
-        rtx_engine_destroy(eng); rtx_csr_destroy(ctr); dt.release(); hipFree(d_ids); hipFree(d_loss); hipFree(d_logits);
-    }
 }
 
 int main(int argc, char** argv)
@@ -593,6 +528,10 @@ int main(int argc, char** argv)
         g_opt_lse = 0;
         parity_case("wide-vae-nolsefuse", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_lse = 1;
+        g_opt_inmain = 0;    // the encoder matrix's kernel on the side stream as well (small layers + loss reduction on the caller's)
+        parity_case("wide-vae-in-on-side", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+        parity_case("mid-dae-in-on-side", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
+        g_opt_inmain = 1;
         g_opt_two = 0;
         parity_case("wide-vae-one-stream", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         parity_case("mid-dae-one-stream", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
@@ -602,14 +541,14 @@ int main(int argc, char** argv)
         g_opt_ntreg = 1;
         parity_case("mid-dae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
     }
-    defer_case("wide-vae", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), 500, 700, 0.01f);
-    defer_case("wide-vae-odd-batch", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), 333, 700, 0.01f);
-    defer_case("small-vae (no side-stream layers)", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), 9, 12, 0.2f);
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration
-        g_opt_defer = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_defer = 1;   // every step joins before it returns
+        g_opt_evdev = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_evdev = 1;     // events with the default (system-scope) release
+        g_opt_outpad = 16 * 1024; perf_case(RTX_BF16, B, 50, 0);        // decoder matrix's kernel: one workgroup per CU (88 KB of LDS)
+        g_opt_outpad = 0;
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration again (box drift)
+        g_opt_inmain = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_inmain = 1;   // encoder matrix's kernel on the side stream
         g_opt_two = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 1;          // one stream
         if (argc > 3) {
             g_opt_fuse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_fuse = 1;

@@ -483,6 +483,67 @@ static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, 
     for (int i = 0; i < sets; ++i) { hipFree(p[i]); hipFree(m[i]); hipFree(v[i]); hipFree(sh[i]); }
 }
 
+// Several matrices in one launch (rtx_dw_launch_group) must produce, bit for bit, what one launch per matrix produces.
+static int run_dw_group_case(int cfg)
+{
+    const int K_real = 250, Kp = rtx_pad_batch(K_real);
+    const int shapes[3][2] = {{70, 132}, {300, 200}, {130, 600}};
+    struct Buf { bf16_t *D, *X, *sh[2]; float *p[2], *m[2], *v[2], *bp[2], *bm[2], *bv[2]; int Mp, Np; size_t P; };
+    Buf b[3];
+    RtxDw d[2][3];
+    for (int k = 0; k < 3; ++k) {
+        const int M = shapes[k][0], N = shapes[k][1];
+        b[k].Mp = rtx_pad(M); b[k].Np = rtx_pad(N); b[k].P = (size_t)M * N;
+        std::vector<bf16_t> hD((size_t)Kp * b[k].Mp, 0), hX((size_t)Kp * b[k].Np, 0);
+        for (int r = 0; r < K_real; ++r) {
+            for (int c = 0; c < b[k].Mp; ++c) hD[(size_t)r * b[k].Mp + c] = f32_to_bf16(frand() * 0.05f);
+            for (int c = 0; c < N; ++c) hX[(size_t)r * b[k].Np + c] = f32_to_bf16(frand());
+            hX[(size_t)r * b[k].Np + N] = f32_to_bf16(1.f);
+        }
+        std::vector<float> hp(b[k].P), hm(b[k].P), hv(b[k].P), hb(b[k].Mp);
+        for (size_t i = 0; i < b[k].P; ++i) { hp[i] = frand(); hm[i] = frand() * 0.01f; hv[i] = fabsf(frand()) * 1e-4f; }
+        for (auto& x : hb) x = frand() * 0.1f;
+        CK(hipMalloc(&b[k].D, hD.size() * 2)); CK(hipMalloc(&b[k].X, hX.size() * 2));
+        CK(hipMemcpy(b[k].D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b[k].X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+        for (int s = 0; s < 2; ++s) {
+            CK(hipMalloc(&b[k].p[s], b[k].P * 4)); CK(hipMalloc(&b[k].m[s], b[k].P * 4)); CK(hipMalloc(&b[k].v[s], b[k].P * 4));
+            CK(hipMalloc(&b[k].bp[s], b[k].Mp * 4)); CK(hipMalloc(&b[k].bm[s], b[k].Mp * 4)); CK(hipMalloc(&b[k].bv[s], b[k].Mp * 4));
+            CK(hipMalloc(&b[k].sh[s], (size_t)b[k].Mp * b[k].Np * 2)); CK(hipMemset(b[k].sh[s], 0, (size_t)b[k].Mp * b[k].Np * 2));
+            CK(hipMemcpy(b[k].p[s], hp.data(), b[k].P * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b[k].m[s], hm.data(), b[k].P * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(b[k].v[s], hv.data(), b[k].P * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(b[k].bp[s], hb.data(), b[k].Mp * 4, hipMemcpyHostToDevice)); CK(hipMemset(b[k].bm[s], 0, b[k].Mp * 4)); CK(hipMemset(b[k].bv[s], 0, b[k].Mp * 4));
+            RtxDw& q = d[s][k];
+            q = RtxDw{};
+            q.A = b[k].D; q.lda = b[k].Mp; q.B = b[k].X; q.ldb = b[k].Np;
+            q.m_tiles = b[k].Mp / rtx_dw_tile_rows(cfg); q.n_tiles = b[k].Np / 128; q.k_slices = Kp / 64;
+            q.M_real = M; q.N_real = N;
+            q.adam.p = b[k].p[s]; q.adam.m = b[k].m[s]; q.adam.v = b[k].v[s]; q.adam.sh = b[k].sh[s]; q.adam.ld_sh = b[k].Np;
+            q.adam.step_size = 1e-3f * (k + 1); q.adam.bc2_sqrt = 0.05f; q.adam.beta1 = 0.9f; q.adam.beta2 = 0.999f; q.adam.eps = 1e-8f;
+            q.bias_p = b[k].bp[s]; q.bias_m = b[k].bm[s]; q.bias_v = b[k].bv[s];
+        }
+    }
+    int rc = rtx_dw_launch_group(d[0], 3, RTX_DW_ADAM, cfg, 0);
+    for (int k = 0; k < 3 && !rc; ++k) rc = rtx_dw_launch(d[1][k], RTX_DW_ADAM, cfg, 0);
+    if (rc) { printf("[dw group cfg%d] launch failed rc=%d: %s\n", cfg, rc, rtx_last_error_str()); return 1; }
+    CK(hipDeviceSynchronize());
+    long diff = 0;
+    for (int k = 0; k < 3; ++k) {
+        auto cmp = [&](const void* x, const void* y, size_t bytes) {
+            std::vector<unsigned char> hx(bytes), hy(bytes);
+            CK(hipMemcpy(hx.data(), x, bytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy.data(), y, bytes, hipMemcpyDeviceToHost));
+            diff += memcmp(hx.data(), hy.data(), bytes) != 0;
+        };
+        cmp(b[k].p[0], b[k].p[1], b[k].P * 4); cmp(b[k].m[0], b[k].m[1], b[k].P * 4); cmp(b[k].v[0], b[k].v[1], b[k].P * 4);
+        cmp(b[k].bp[0], b[k].bp[1], b[k].Mp * 4); cmp(b[k].bm[0], b[k].bm[1], b[k].Mp * 4); cmp(b[k].bv[0], b[k].bv[1], b[k].Mp * 4);
+        cmp(b[k].sh[0], b[k].sh[1], (size_t)b[k].Mp * b[k].Np * 2);
+        hipFree(b[k].D); hipFree(b[k].X);
+        for (int s = 0; s < 2; ++s) { hipFree(b[k].p[s]); hipFree(b[k].m[s]); hipFree(b[k].v[s]); hipFree(b[k].bp[s]); hipFree(b[k].bm[s]); hipFree(b[k].bv[s]); hipFree(b[k].sh[s]); }
+    }
+    printf("[dw group] cfg%d 3 matrices in one launch vs one launch each: %ld differing buffers -> %s\n", cfg, diff, diff ? "FAIL" : "ok");
+    return diff ? 1 : 0;
+}
+
 // ---- float32 GEMM with a K-major operand (gemm_f32.hip) ------------------------------------------------------------------------------
 static int run_f32_case(const char* name, int form, int M, int N, int K, int splits, int epi, int M_real, int N_real)
 {
@@ -581,6 +642,7 @@ int main(int argc, char** argv)
         fails += run_dw_case("grad", cfg, RTX_DW_GRAD, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
         fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
+        fails += run_dw_group_case(cfg);
     }
     for (int form : {RTX_FORM_NN, RTX_FORM_TN}) {
         fails += run_f32_case("store", form, 256, 384, 352, 1, RTX_EPI_STORE, 256, 384);

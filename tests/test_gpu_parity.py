@@ -370,51 +370,6 @@ def test_ndcg_recall_parity_vs_oracle_ml20m_items(numerics):
         assert np.max(np.abs(res["ndcg@100"] - ro["ndcg@100"])) < 1e-3
 
 
-def test_train_epoch_deferred_joins_equal_joined_steps():
-    """MultiVAE.train_epoch over a device-resident sampler flags its steps RTX_STEP_DEFER_JOIN (the two big optimizer kernels of
-    a step are still running when the call returns; the next step joins them where it needs them, its gather runs beside them
-    into the alternate input buffer).  Same seeds -> parameters, Adam moments and predictions BIT-identical to the same batches
-    stepped one by one through train-batch semantics (every step joined before it returns); validation in the middle of
-    training (another entry point) and reading the parameters after the epoch see the finished state."""
-    from rectorch_amd.utils import synth_interactions, hash_state_dict
-    from rectorch_amd.samplers import DataSampler
-    I, H, L, B = 8100, 600, 200, 500
-    X = synth_interactions(1800, I, seed=9)
-    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 13, bias_std=0.05)
-    net_a, model_a = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=1000, numerics="bf16")
-    net_b, model_b = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=1000, numerics="bf16")
-    smp = DataSampler(X, batch_size=B, shuffle=False)
-    assert smp.resident
-    torch.manual_seed(3)
-    for epoch in range(2):
-        model_a.train_epoch(epoch, smp, verbose=0)
-        assert model_a._rtx.defer_engine is None                    # joined at the end of the epoch
-    pa = [p.detach().clone() for p in net_a.parameters()]           # plain torch reads, after the join
-    torch.manual_seed(3)
-    for epoch in range(2):
-        for rb in smp.iter_rows():
-            model_b._fused_step(rb, None, want_loss=False)           # no flag: each step joins before it returns
-    for x, y in zip(pa, net_b.parameters()):
-        assert torch.equal(x, y)
-    for x, y in zip(net_a.parameters(), net_b.parameters()):
-        sa, sb = model_a.optimizer.state[x], model_b.optimizer.state[y]
-        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
-    d = smp._csr_tr.gather_dense(next(iter(smp.iter_rows())).rows)
-    assert torch.equal(model_a.predict(d)[0], model_b.predict(d)[0])
-    # a deferred step followed directly by another entry point of the engine (predict joins on entry)
-    torch.manual_seed(4)
-    rb0 = next(iter(smp.iter_rows()))
-    model_a._fused_step(rb0, None, want_loss=False, defer=True)
-    assert model_a._rtx.defer_engine is not None
-    pred_a = model_a.predict(d)[0]
-    model_a._join()
-    torch.manual_seed(4)
-    model_b._fused_step(rb0, None, want_loss=False)
-    assert torch.equal(pred_a, model_b.predict(d)[0])
-    for x, y in zip(net_a.parameters(), net_b.parameters()):
-        assert torch.equal(x, y)
-
-
 # ---------------------------------------------------------------------------------------------- properties at the full shape
 def test_full_size_properties_b500():
     """ml-20m shape, B = 500, bf16: properties that need no reference at this size."""

@@ -1,10 +1,18 @@
-mkdir -p gpurun_out/r2i
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2i/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r2i/pytest.log
-timeout 300 python bench.py > gpurun_out/r2i/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r2i/bench.log | cut -c1-400
-timeout 200 python bench.py --no-defer --no-cpu-baseline --no-fp32-parity > gpurun_out/r2i/bench_nodefer.log 2>&1; tail -1 gpurun_out/r2i/bench_nodefer.log | cut -c1-300
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_r2i
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_r2i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-fp32-parity > $GRAFT_REPO_ROOT/gpurun_out/r2i/bench_prof.log 2>&1
-DB=$(find /tmp/prof_r2i -name "*.db" | head -1)
-python $GRAFT_REPO_ROOT/tools/rocprof_summary.py stats $DB > $GRAFT_REPO_ROOT/gpurun_out/r2i/kernel_stats.txt
-python $GRAFT_REPO_ROOT/tools/rocprof_summary.py timeline $DB > $GRAFT_REPO_ROOT/gpurun_out/r2i/timeline.txt
-head -20 $GRAFT_REPO_ROOT/gpurun_out/r2i/kernel_stats.txt
+#!/bin/bash
+# One GPU-box pass of the round's checks: native tests (+ perf variants), pytest -m gpu, bench.py (default line), and a
+# rocprofv3 kernel trace of bench.py turned into the per-kernel summary and a two-step timeline.  Outputs: gpurun_out/$1/.
+OUT=gpurun_out/${1:-check}
+mkdir -p $OUT
+if [ "$2" != "quick" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $OUT/pytest.log
+fi
+timeout 500 build/native/test_engine perf > $OUT/engine.log 2>&1; echo "engine rc=$?"; grep -E "FAIL|TESTS" $OUT/engine.log; grep -A1 "^\[perf\]" $OUT/engine.log | grep -v "^--"
+timeout 300 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?"; tail -1 $OUT/bench.log | cut -c1-330
+timeout 200 python bench.py --opt out_lds_pad=16384 --no-cpu-baseline --no-fp32-parity > $OUT/bench_ab.log 2>&1; tail -1 $OUT/bench_ab.log | cut -c1-330
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_rc
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_rc -o p -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-fp32-parity > $R/$OUT/bench_prof.log 2>&1
+DB=$(find /tmp/prof_rc -name "*.db" | head -1)
+python $R/tools/rocprof_summary.py stats $DB > $R/$OUT/kernel_stats.txt
+python $R/tools/rocprof_summary.py timeline $DB > $R/$OUT/timeline.txt
+head -16 $R/$OUT/kernel_stats.txt
