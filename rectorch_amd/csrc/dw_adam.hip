@@ -359,13 +359,12 @@ template <int WM, int WN, int NS, int EPI> static int dw_launch(const RtxDw& d, 
     constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     const int total = d.m_tiles * d.n_tiles;
     const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
-    const int lds = LDS + (d.lds_pad > 0 ? d.lds_pad : 0) > 160 * 1024 ? 160 * 1024 : LDS + (d.lds_pad > 0 ? d.lds_pad : 0);
-    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI>), grid, dim3(WM * WN * 64), lds, stream, d);
+    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI>), grid, dim3(WM * WN * 64), LDS, stream, d);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

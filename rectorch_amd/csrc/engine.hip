@@ -86,8 +86,6 @@ struct rtx_engine {
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
-    int opt_event_device_scope = 1;   // events released at device scope (set before the first step)
-    int opt_out_lds_pad = 0;    // extra dynamic LDS (bytes) requested by the decoder matrix's kernel: > 8 KB leaves one workgroup per CU
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
@@ -164,7 +162,7 @@ struct ScopedTimer {
             if (!e->event_pool.empty()) {
                 ev = e->event_pool.back();
                 e->event_pool.pop_back();
-            } else if (hipEventCreateWithFlags(&ev, e->opt_event_device_scope ? hipEventReleaseToDevice : hipEventDefault) != hipSuccess) {
+            } else if (hipEventCreate(&ev) != hipSuccess) {
                 ev = nullptr;
             }
             return ev;
@@ -782,10 +780,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         int prio_least = 0, prio_greatest = 0;
         RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
-        // the events order two streams of ONE device: a device-scope release (no system-scope cache write-back at the record)
-        const unsigned evf = hipEventDisableTiming | (e->opt_event_device_scope ? hipEventReleaseToDevice : 0);
-        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], evf));
-        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, evf));
+        // (events created with hipEventReleaseToDevice -- a device-scope release at the record -- measure the same: 328.0 vs 327.7 us)
+        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     }
     // The encoder matrix's kernel is the END of the step's critical path (it needs D[0], the last thing the chain produces, and
     // the next step's first product needs its result).  A cross-stream dependency costs about 18 us from the event's record to
@@ -836,7 +833,6 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d;
             make_dw(li, d);
-            if (ws == e->side && ws != st && li == NL - 1) d.lds_pad = e->opt_out_lds_pad;
             return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, e->opt_dw_cfg, ws);
         }
         RtxGemm g = {};
@@ -1070,14 +1066,6 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
-    else if (k == "event_device_scope") {
-        RTX_CHECK(!e->side, RTX_ESTATE, "set_option: event_device_scope must be set before the first training step");
-        e->opt_event_device_scope = value != 0;
-    }
-    else if (k == "out_lds_pad") {
-        RTX_CHECK(value >= 0 && value <= 80 * 1024, RTX_EINVAL, "set_option: out_lds_pad must be 0..81920 bytes");
-        e->opt_out_lds_pad = value;
-    }
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;
@@ -1097,7 +1085,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, event_device_scope, out_lds_pad, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;

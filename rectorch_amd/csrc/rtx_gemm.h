@@ -101,7 +101,6 @@ struct RtxDw {
     float* bias_m;       //   with the scalars of `adam`
     float* bias_v;
     const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
-    int lds_pad;         // extra dynamic LDS bytes to request (occupancy throttle for a launch that runs beside latency-bound kernels)
 };
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);

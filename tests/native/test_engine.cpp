@@ -172,7 +172,7 @@ static std::vector<float> d2h(const float* d, size_t n)
 }
 
 static int g_fail = 0;
-static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1, g_opt_evdev = 1, g_opt_outpad = 0;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
+static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
 static void apply_options(rtx_engine* eng)
 {
     rtx_engine_set_option(eng, "fuse_adam", g_opt_fuse);
@@ -182,8 +182,6 @@ static void apply_options(rtx_engine* eng)
     rtx_engine_set_option(eng, "nt_regstage", g_opt_ntreg);
     rtx_engine_set_option(eng, "side_low_prio", g_opt_lowprio);
     rtx_engine_set_option(eng, "in_on_main", g_opt_inmain);
-    rtx_engine_set_option(eng, "event_device_scope", g_opt_evdev);
-    rtx_engine_set_option(eng, "out_lds_pad", g_opt_outpad);
 }
 static void check(const char* what, double err, double tol)
 {
@@ -430,7 +428,7 @@ static void philox_case()
 
 static void perf_case(int numerics, int B, int steps, int splitk)
 {
-    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d ev_dev=%d out_pad=%d nt_regstage=%d dw_cfg=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_evdev, g_opt_outpad, g_opt_ntreg, g_opt_dw_cfg);
+    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d nt_regstage=%d dw_cfg=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_ntreg, g_opt_dw_cfg);
     Net net = make_net({20108, 600, 200}, {200, 600, 20108}, ORC_VAE, 0.5f, 0.1f);
     const int I = 20108, U = 4096;
     Csr tr;
@@ -544,9 +542,6 @@ int main(int argc, char** argv)
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration
-        g_opt_evdev = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_evdev = 1;     // events with the default (system-scope) release
-        g_opt_outpad = 16 * 1024; perf_case(RTX_BF16, B, 50, 0);        // decoder matrix's kernel: one workgroup per CU (88 KB of LDS)
-        g_opt_outpad = 0;
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration again (box drift)
         g_opt_inmain = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_inmain = 1;   // encoder matrix's kernel on the side stream
         g_opt_two = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 1;          // one stream
