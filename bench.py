@@ -276,7 +276,8 @@ def main():
         kn = n_out + n_in
         kus = (t_out + t_in) * 1e3 / max(kn, 1)
         kbytes = 24.0 * I * H
-        kname = "rtx_dw_tn<RTX_DW_ADAM> (weight gradient fused with Adam; decoder and encoder n_items x 600 matrices, 2 launches/step)"
+        kname = ("rtx_dw_tn / rtx_dw_tn_group <64x128, RTX_DW_ADAM> (weight gradient fused with Adam: the decoder n_items x 600 matrix on "
+                 "the side stream, the encoder matrix + the hidden layers' in one launch on the caller's; 2 launches/step)")
         pmc = os.path.join(ROOT, "profiles", "r2_pmc_dw_adam.json")
         if os.path.exists(pmc):
             try:
