@@ -246,6 +246,16 @@ int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* 
  * either a CSR over the T steps (device int64 indptr [T+1], int32 indices, implicit ones) or a dense device [T][n_items]. */
 int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
                         const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream);
+/* NOT in the reference (which takes one Adam step per user; samplers.py:517-571, models.py:1609-1635): `n_seq` user sequences
+ * in ONE optimizer step.  The sequences are concatenated -- items [total_steps], rows [seq_ptr[u], seq_ptr[u+1]) belong to
+ * sequence u (device int32 [n_seq+1]; max_len of the handle bounds total_steps) -- and the step minimises
+ * sum_t nll_scale[t] * NLL_t + sum_t kl_scale[t] * KL_t (device float [total_steps] each): with nll_scale = 1 / (d_u * n_seq) and
+ * kl_scale = beta / (T_u * n_seq) that is the mean over the pack of the reference's per-user loss -- gradient accumulation
+ * over the pack, then one Adam step.  The products become [total_steps, .] GEMMs, the recurrences run one workgroup per
+ * sequence side by side.  With n_seq = 1 it computes what rtx_svae_train_step computes.  step->inv_batch / beta are ignored. */
+int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, const int32_t* seq_ptr, int32_t n_seq, const float* nll_scale,
+                        const float* kl_scale, const int64_t* target_indptr, const int32_t* target_indices, const rtx_step* step, float* loss_out,
+                        float* loss_accum, void* stream);
 
 /* measurement knobs of one engine (the defaults are the shipped configuration): key "fuse_adam" (0/1, bf16 step:
  * Adam inside the weight-gradient kernels), "two_stream" (0/1: the two big ones on a second stream beside the

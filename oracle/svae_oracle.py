@@ -145,6 +145,27 @@ class SvaeOracle:
         self.last_grads = g
         return loss
 
+    def train_pack(self, users, beta1=0.9, beta2=0.999, adam_eps=1e-8):
+        """NOT in the reference: one Adam step for the MEAN over ``users`` (list of (items, y, eps)) of the per-user loss --
+        the gradients of the reference's per-user objective accumulated over the pack, then the reference's optimizer."""
+        beta = self.anneal_beta()
+        loss, g = 0.0, None
+        for items, y, eps in users:
+            d = float(np.asarray(y)[0].sum())
+            l, gu, _, _, _ = self.loss_and_grads(items, y, eps, beta, d)
+            loss += l / len(users)
+            g = {k: gu[k] / len(users) for k in self.keys} if g is None else {k: g[k] + gu[k] / len(users) for k in self.keys}
+        self.step += 1
+        bc1, bc2 = 1 - beta1 ** self.step, 1 - beta2 ** self.step
+        for k in self.keys:
+            gk = g[k] + self.wd * self.p[k]
+            self.m[k] = beta1 * self.m[k] + (1 - beta1) * gk
+            self.v[k] = beta2 * self.v[k] + (1 - beta2) * gk * gk
+            self.p[k] = self.p[k] - (self.lr / bc1) * self.m[k] / (np.sqrt(self.v[k]) / np.sqrt(bc2) + adam_eps)
+        self.gradient_updates += 1.0
+        self.last_grads = g
+        return loss
+
     # models.py:1628-1635
     def predict(self, items, eps, remove_train=True):
         logits, mu, lv, _ = self.forward(items, eps)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rtx_svae_bind": (C.c_int, [_P, _P, _P, _P, _P]),
     "rtx_svae_forward": (C.c_int, [_P, _P, C.c_int32, _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P, _P, _P, _P]),
     "rtx_svae_train_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(Step), _P, _P, _P]),
+    "rtx_svae_train_pack": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.POINTER(Step), _P, _P, _P]),
     "rtx_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rtx_engine_set_timing": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rtx_engine_get_timings": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),

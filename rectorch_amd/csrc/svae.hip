@@ -1,4 +1,5 @@
-// svae.hip -- Sequential VAE (BASELINE.json configs[4]) on MI355X: one user sequence per optimizer step.
+// svae.hip -- Sequential VAE (BASELINE.json configs[4]) on MI355X: one user sequence per optimizer step (the reference's
+// semantics), or a pack of users per step.
 //
 // Reference: rectorch/nets.py:624-693 (SVAE_net: Embedding -> 1-layer GRU (batch_first) -> VAE head that ALWAYS samples
 // (VAE_net._reparameterize, nets.py:316-319) -> tanh MLP decoder), rectorch/models.py:1609-1635 (SVAE: loss =
@@ -8,13 +9,14 @@
 // The reference trains one user (T ~ 100 time steps) per Adam step, so every contraction is a [T, small] x [small, *]
 // product: the step is bound by launch latency and by the strictly sequential GRU recurrence, not by MFMA throughput.
 // Design for that regime (all float32, so parity with the reference is ~1e-6):
-//   * one generic strided GEMM kernel (64x64 tile, 4x4 per thread, bias / tanh / tanh'-mask epilogues) serves every
+//   * one generic strided GEMM kernel (64x64 tile on the exact-float32 MFMA, bias / tanh / tanh'-mask epilogues) serves every
 //     forward, backward-data and weight-gradient product -- operands are read in place with strides, no padded copies;
 //   * the GRU recurrence (forward and BPTT) runs as ONE persistent workgroup of 1024 threads per direction: h_t lives
 //     in LDS, W_hh streams from L2 (it is re-read every step), the input projections x_t W_ih^T for all t are one GEMM
 //     before the loop, and the weight gradients are two GEMMs over all t after it;
 //   * Adam over the 5 + 2(n_enc + n_dec) tensors is the one fused multi-tensor kernel of the Mult-VAE path (k_adam).
-// User packing (several sequences per launch, MFMA tiles) needs an API change in the sampler and is left for later.
+// rtx_svae_train_pack (round 2) takes several users per optimizer step: concatenated rows, one recurrence workgroup per user
+// side by side, [sum T, .] products -- 440 -> 5 400+ users/s at the ml-1m shape with packs of 32 (SVAE_Sampler(pack=N)).
 #include "../../include/rectorch_hip.h"
 #include "rtx_kernels.h"
 
@@ -39,7 +41,7 @@ struct rtx_svae {
     std::vector<float*> params, grads, m, v;
     bool bound = false, can_train = false;
     // activations / scratch (device)
-    float *X = nullptr, *GI = nullptr, *H = nullptr, *Gr = nullptr, *Gz = nullptr, *Gn = nullptr, *Ghn = nullptr;
+    float *X = nullptr, *GI = nullptr, *Hout = nullptr, *Hprev = nullptr, *Gr = nullptr, *Gz = nullptr, *Gn = nullptr, *Ghn = nullptr;
     float *mu = nullptr, *lv = nullptr, *eps = nullptr, *zl = nullptr, *dz = nullptr;
     float *dH = nullptr, *dGI = nullptr, *dGH = nullptr, *dX = nullptr;
     float *row_loss = nullptr, *kl_rows = nullptr;
@@ -69,58 +71,70 @@ struct SvGemm {
     float* part;         //          sums to part[z][M][N]; k_sv_splitk_reduce then applies the epilogue (0 / NULL = off)
 };
 
+typedef __attribute__((ext_vector_type(16))) float sv_f32x16;
+
+// 64 x 64 tile per workgroup, 4 waves, each a 32 x 32 block on the exact-float32 MFMA (v_mfma_f32_32x32x2_f32: lane l feeds
+// A[l & 31][k = l >> 5] and B[k = l >> 5][l & 31], products and sums in float32).  Round 1 computed the tile with scalar FMAs
+// (8 LDS floats per 16 FMAs per thread: LDS-bound); with several users packed per step these products are [sum T, .] GEMMs of
+// tens of GFLOP and the matrix pipes carry them.  The operands are still read in place with two strides.
 __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
 {
     __shared__ float sA[16][65], sB[16][65];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
-    float acc[4][4] = {};
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int li = lane & 31, lk = lane >> 5;
+    sv_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int kbeg = g.kchunk ? blockIdx.z * g.kchunk : 0;
     const int kend = g.kchunk ? min(g.K, kbeg + g.kchunk) : g.K;
+    // 64 x 16 elements per operand and K chunk, 4 per thread; the faster-varying thread index follows the unit-stride axis.
+    // The next chunk's values are requested (into registers) before this chunk's MFMAs, so their latency runs under them.
+    int amm[4], akk[4], bnn[4], bkk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * 256;
+        if (g.sak == 1) { akk[q] = e & 15; amm[q] = e >> 4; } else { amm[q] = e & 63; akk[q] = e >> 6; }
+        if (g.sbk == 1) { bkk[q] = e & 15; bnn[q] = e >> 4; } else { bnn[q] = e & 63; bkk[q] = e >> 6; }
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + amm[q], k = k0 + akk[q];
+            ra[q] = (m < g.M && k < kend) ? g.A[(size_t)m * g.sam + (size_t)k * g.sak] : 0.f;
+            const int n = n0 + bnn[q], kb = k0 + bkk[q];
+            rb[q] = (n < g.N && kb < kend) ? g.B[(size_t)n * g.sbn + (size_t)kb * g.sbk] : 0.f;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        // 64 x 16 elements per operand, 4 per thread; the faster-varying thread index follows the unit-stride axis
-        for (int e = tid; e < 1024; e += 256) {
-            int mm, kk;
-            if (g.sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
-            const int m = m0 + mm, k = k0 + kk;
-            sA[kk][mm] = (m < g.M && k < kend) ? g.A[(size_t)m * g.sam + (size_t)k * g.sak] : 0.f;
-            int nn, k2;
-            if (g.sbk == 1) { k2 = e & 15; nn = e >> 4; } else { nn = e & 63; k2 = e >> 6; }
-            const int n = n0 + nn, kb = k0 + k2;
-            sB[k2][nn] = (n < g.N && kb < kend) ? g.B[(size_t)n * g.sbn + (size_t)kb * g.sbk] : 0.f;
-        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sA[akk[q]][amm[q]] = ra[q]; sB[bkk[q]][bnn[q]] = rb[q]; }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = sA[kk][tm + i]; b[i] = sB[kk][tn + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
-        }
+        for (int kk = 0; kk < 16; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kk + lk][wm + li], sB[kk + lk][wn + li], acc, 0, 0, 0);
         __syncthreads();
     }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int n = n0 + wn + li;
+    if (n >= g.N) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + tm + i;
+    for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * lk;
         if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tn + j;
-            if (n >= g.N) continue;
-            float v = g.alpha * acc[i][j];
-            if (g.kchunk) {
-                g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
-                continue;
-            }
-            if (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH) v += g.bias[n];
-            if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
-            if (g.epi == SV_EPI_TANH_GRAD) { const float q = g.Q[(size_t)m * g.ldq + n]; v *= (1.f - q * q); }
-            g.C[(size_t)m * g.ldc + n] = v;
+        float v = g.alpha * acc[e];
+        if (g.kchunk) {
+            g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
+            continue;
         }
+        if (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH) v += g.bias[n];
+        if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
+        if (g.epi == SV_EPI_TANH_GRAD) { const float q = g.Q[(size_t)m * g.ldq + n]; v *= (1.f - q * q); }
+        g.C[(size_t)m * g.ldc + n] = v;
     }
 }
 
@@ -212,16 +226,23 @@ __device__ __forceinline__ float block_max(float v, float* red)
 // L2 per step was SLOWER (10.8 us): device-scope release/acquire between compute units costs microseconds on a
 // multi-XCD part, more than re-reading 480 KB from L2.
 __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ GI, const float* __restrict__ WhhT, const float* __restrict__ bhh,
-                                                     int T, int R, float* __restrict__ H /* [T+1][R], H[0] = 0 */, float* __restrict__ Gr,
-                                                     float* __restrict__ Gz, float* __restrict__ Gn, float* __restrict__ Ghn)
+                                                     const int32_t* __restrict__ seq_ptr, int T_one, int R,
+                                                     float* __restrict__ Hout /* [T][R]: h after step t */,
+                                                     float* __restrict__ Hprev /* [T][R]: h before step t (0 at a sequence start) */,
+                                                     float* __restrict__ Gr, float* __restrict__ Gz, float* __restrict__ Gn, float* __restrict__ Ghn)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // h [Rp] | gh [3R]   (Rp = R rounded up to 4)
     const int Rp = (R + 3) & ~3;
     float* h = sm;
     float* gh = sm + Rp;
     const int tid = threadIdx.x;
+    // packed sequences: workgroup b owns rows [seq_ptr[b], seq_ptr[b + 1]) of every [T][.] buffer; one sequence: all T_one rows
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    GI += (size_t)t0 * 3 * R;
+    Hout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
     for (int j = tid; j < Rp; j += 1024) h[j] = 0.f;
-    for (int j = tid; j < R; j += 1024) H[j] = 0.f;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         // this step's input projections are independent of h: fetch them before the mat-vec, not after its barrier
@@ -255,7 +276,8 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ G
             const float hp = h[j];
             const float hv = (1.f - z) * n + z * hp;
             Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
-            H[(size_t)(t + 1) * R + j] = hv;
+            Hprev[(size_t)t * R + j] = hp;
+            Hout[(size_t)t * R + j] = hv;
             h[j] = hv;   // element j is read and written by this thread only; the mat-vec above is behind the barrier
         }
         __syncthreads();
@@ -266,11 +288,17 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ G
 // gradients dGI [T][3R] (input side) and dGH [T][3R] (hidden side; differs in the n block by the factor r).
 // dh_{t-1} += W_hh^T dgh: thread (column k, row chunk c) sums W_hh[i][k] dgh[i] over its chunk of rows -- consecutive
 // lanes read consecutive k (coalesced rows), every load is independent -- and the chunks meet in LDS (5.5 us per step).
-__global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ dHout, const float* __restrict__ Whh, int T, int R,
-                                                     const float* __restrict__ H, const float* __restrict__ Gr, const float* __restrict__ Gz,
+__global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ dHout, const float* __restrict__ Whh,
+                                                     const int32_t* __restrict__ seq_ptr, int T_one, int R,
+                                                     const float* __restrict__ Hprev, const float* __restrict__ Gr, const float* __restrict__ Gz,
                                                      const float* __restrict__ Gn, const float* __restrict__ Ghn, float* __restrict__ dGI,
                                                      float* __restrict__ dGH)
 {
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    dHout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
+    dGI += (size_t)t0 * 3 * R; dGH += (size_t)t0 * 3 * R;
     extern __shared__ __attribute__((aligned(16))) float sm[];   // dh [R] | dgh [3R] | part [NC][R]
     float* dh = sm;
     float* dgh = sm + R;
@@ -284,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ d
         for (int j = tid; j < R; j += 1024) {
             const float d = dh[j] + dHout[(size_t)t * R + j];
             const float r = Gr[(size_t)t * R + j], z = Gz[(size_t)t * R + j], n = Gn[(size_t)t * R + j], hn = Ghn[(size_t)t * R + j];
-            const float hp = H[(size_t)t * R + j];
+            const float hp = Hprev[(size_t)t * R + j];
             const float dn = d * (1.f - z);
             const float dzp = d * (hp - n) * z * (1.f - z);
             const float dnp = dn * (1.f - n * n);
@@ -339,10 +367,12 @@ __global__ __launch_bounds__(256) void k_sv_reparam(const float* out, int T, int
 // gradient w.r.t. the encoder head output [T][2Z] from dz and the KL term  beta * mean_t(-0.5 sum_j (1 + lv - mu^2 - e^lv));
 // kl_rows[t] = -0.5 sum_j(...)
 __global__ __launch_bounds__(256) void k_sv_reparam_bwd(const float* dz, const float* mu, const float* lv, const float* eps, int T, int Z,
-                                                        float beta_over_T, float* dout, float* kl_rows)
+                                                        float beta_over_T, const float* __restrict__ kl_scale /* per row, or NULL */, float* dout,
+                                                        float* kl_rows)
 {
     __shared__ float red[4];
     const int t = blockIdx.x;
+    if (kl_scale) beta_over_T = kl_scale[t];   // packed users: beta / (T_user * n_users)
     float kl = 0.f;
     for (int j = threadIdx.x; j < Z; j += 256) {
         const int idx = t * Z + j;
@@ -361,10 +391,12 @@ __global__ __launch_bounds__(256) void k_sv_reparam_bwd(const float* dz, const f
 // per time step: log-softmax NLL against the target row (CSR, or dense [T][I]) and the logits gradient
 //   nll_t = -sum_i y_ti (x_ti - lse_t);  dlogits = (s_t softmax - y) * inv_d
 __global__ __launch_bounds__(256) void k_sv_loss(const float* logits, int T, int I, const int64_t* tptr, const int32_t* tidx,
-                                                 const float* ydense, float inv_d, float* dlogits, float* row_loss)
+                                                 const float* ydense, float inv_d, const float* __restrict__ nll_scale /* per row, or NULL */,
+                                                 float* dlogits, float* row_loss)
 {
     __shared__ float red[4];
     const int t = blockIdx.x, tid = threadIdx.x;
+    if (nll_scale) inv_d = nll_scale[t];   // packed users: 1 / (d_user * n_users)
     const float* x = logits + (size_t)t * I;
     float mx = -INFINITY;
     for (int i = tid; i < I; i += 256) mx = fmaxf(mx, x[i]);
@@ -397,11 +429,17 @@ __global__ __launch_bounds__(256) void k_sv_loss(const float* logits, int T, int
 }
 
 __global__ __launch_bounds__(256) void k_sv_final_loss(const float* row_loss, const float* kl_rows, int T, float inv_d, float beta_over_T,
-                                                       float* loss_out, float* loss_accum)
+                                                       const float* __restrict__ nll_scale, const float* __restrict__ kl_scale, float* loss_out,
+                                                       float* loss_accum)
 {
     __shared__ float red[4];
     float a = 0.f, b = 0.f;
-    for (int t = threadIdx.x; t < T; t += 256) { a += row_loss[t]; b += kl_rows[t]; }
+    if (nll_scale) {   // packed users: every row carries its user's factors
+        for (int t = threadIdx.x; t < T; t += 256) { a += row_loss[t] * nll_scale[t]; b += kl_rows[t] * kl_scale[t]; }
+        inv_d = 1.f; beta_over_T = 1.f;
+    } else {
+        for (int t = threadIdx.x; t < T; t += 256) { a += row_loss[t]; b += kl_rows[t]; }
+    }
     a = block_sum(a, red);
     b = block_sum(b, red);
     if (threadIdx.x == 0) {
@@ -436,9 +474,11 @@ static int sv_gemm(rtx_svae* s, hipStream_t st, const float* A, long sam, long s
     const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
     // few output tiles and a long K (the [T, hidden] = [T, n_items] x [n_items, hidden] backward-data product): split K
     // so that a few hundred workgroups share the reduction instead of a handful walking it end to end
+    // (with packed users K = sum T reaches tens of thousands in the weight-gradient products while their outputs are a few
+    // hundred tiles: the [n_items, 150] decoder gradient ran 162 workgroups for 1 ms until it was split as well)
     int splits = 1;
-    if (tiles < 64 && K >= 512) {
-        splits = std::min((K + 255) / 256, std::max(1, 256 / tiles));
+    if (tiles < 512 && K >= 512) {
+        splits = std::min((K + 255) / 256, std::max(1, 1024 / tiles));
         if ((size_t)splits * M * N > s->part_elems) splits = (int)(s->part_elems / ((size_t)M * N));
     }
     if (splits > 1) {
@@ -484,7 +524,9 @@ static void sv_shape(const rtx_svae* s, int t, int* rows, int* cols)
 }
 
 // embedding -> GRU -> encoder -> (sampled) z -> decoder; logits of all T steps land in L.back().A
-static int sv_forward(rtx_svae* s, const int32_t* items, int T, const float* eps_in, uint64_t seed, uint64_t offset, hipStream_t st)
+// `seq_ptr` (device, n_seq + 1 entries) cuts the T rows into independent sequences; NULL = one sequence
+static int sv_forward(rtx_svae* s, const int32_t* items, int T, const int32_t* seq_ptr, int n_seq, const float* eps_in, uint64_t seed, uint64_t offset,
+                      hipStream_t st)
 {
     const int E = s->E, R = s->R, Z = s->Z;
     hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
@@ -492,9 +534,9 @@ static int sv_forward(rtx_svae* s, const int32_t* items, int T, const float* eps
                     s->params[sv_tail(s, SV_T_BIH)]));
     hipLaunchKernelGGL(k_sv_transpose, dim3((R + 63) / 64, (3 * R + 63) / 64), dim3(256), 0, st, s->params[sv_tail(s, SV_T_WHH)], 3 * R, R,
                        s->WhhT);
-    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->WhhT, s->params[sv_tail(s, SV_T_BHH)], T, R,
-                       s->H, s->Gr, s->Gz, s->Gn, s->Ghn);
-    const float* in = s->H + R;   // rnn_out[t] = h_{t+1}
+    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->WhhT,
+                       s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
+    const float* in = s->Hout;   // rnn_out[t] = h after step t
     long ld_in = R;
     for (int li = 0; li < s->NL; ++li) {
         SvLayer& l = s->L[li];
@@ -563,7 +605,7 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
     const size_t T = s->Tmax, R = s->R, E = s->E, Z = s->Z;
     int rc = RTX_OK;
 #define SV_ALLOC(p, n) do { rc = sv_alloc(s, &(p), (n)); if (rc) { rtx_svae_destroy(s); return rc; } } while (0)
-    SV_ALLOC(s->X, T * E); SV_ALLOC(s->GI, T * 3 * R); SV_ALLOC(s->H, (T + 1) * R);
+    SV_ALLOC(s->X, T * E); SV_ALLOC(s->GI, T * 3 * R); SV_ALLOC(s->Hout, T * R); SV_ALLOC(s->Hprev, T * R);
     SV_ALLOC(s->Gr, T * R); SV_ALLOC(s->Gz, T * R); SV_ALLOC(s->Gn, T * R); SV_ALLOC(s->Ghn, T * R);
     SV_ALLOC(s->mu, T * Z); SV_ALLOC(s->lv, T * Z); SV_ALLOC(s->eps, T * Z); SV_ALLOC(s->zl, T * Z); SV_ALLOC(s->dz, T * Z);
     SV_ALLOC(s->dH, T * R); SV_ALLOC(s->dGI, T * 3 * R); SV_ALLOC(s->dGH, T * 3 * R); SV_ALLOC(s->dX, T * E);
@@ -638,7 +680,7 @@ int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* 
 {
     RTX_TRY(sv_check(s, items, T, false));
     hipStream_t st = (hipStream_t)stream;
-    RTX_TRY(sv_forward(s, items, T, eps_noise, seed, offset, st));
+    RTX_TRY(sv_forward(s, items, T, nullptr, 1, eps_noise, seed, offset, st));
     const float* Y = s->L.back().A;
     const size_t I = s->I;
     if (logits_all) RTX_HIP(hipMemcpyAsync(logits_all, Y, sizeof(float) * T * I, hipMemcpyDeviceToDevice, st));
@@ -652,20 +694,19 @@ int rtx_svae_forward(rtx_svae* s, const int32_t* items, int32_t T, const float* 
     return RTX_OK;
 }
 
-int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
-                        const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream)
+// One optimizer step on T rows: one sequence (seq_ptr NULL; the reference's step) or n_seq packed sequences whose rows carry
+// their own loss factors (nll_scale / kl_scale, device arrays of T floats).
+static int sv_train(rtx_svae* s, const int32_t* items, int T, const int32_t* seq_ptr, int n_seq, const float* nll_scale, const float* kl_scale,
+                    const int64_t* target_indptr, const int32_t* target_indices, const float* target_dense, const rtx_step* step, float* loss_out,
+                    float* loss_accum, hipStream_t st)
 {
-    RTX_TRY(sv_check(s, items, T, true));
-    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "svae_train_step: step count must be >= 1");
-    RTX_CHECK((target_indptr && target_indices) || target_dense, RTX_EINVAL, "svae_train_step: no target");
-    hipStream_t st = (hipStream_t)stream;
     const int E = s->E, R = s->R, Z = s->Z, I = s->I, NL = s->NL;
     const float inv_d = step->inv_batch;                 // 1 / (number of ones in the target), models.py:1623
     const float beta_over_T = step->beta / (float)T;     // beta * mean over the time steps, models.py:1624-1625
-    RTX_TRY(sv_forward(s, items, T, step->eps_noise, step->seed, step->offset, st));
+    RTX_TRY(sv_forward(s, items, T, seq_ptr, n_seq, step->eps_noise, step->seed, step->offset, st));
     // ---- loss and dlogits
     SvLayer& last = s->L[NL - 1];
-    hipLaunchKernelGGL(k_sv_loss, dim3(T), dim3(256), 0, st, last.A, T, I, target_indptr, target_indices, target_dense, inv_d, last.D,
+    hipLaunchKernelGGL(k_sv_loss, dim3(T), dim3(256), 0, st, last.A, T, I, target_indptr, target_indices, target_dense, inv_d, nll_scale, last.D,
                        s->row_loss);
     // ---- backward through decoder and encoder.  D of layer l = gradient w.r.t. its pre-activation.  Only the chain of
     //      input gradients is on the critical path (it feeds the GRU's backward pass) ...
@@ -676,8 +717,8 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
             RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[0], 1, l.in, s->dH, R, T, R, l.out));
         } else if (li == s->n_enc) {
             RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[2 * li], 1, l.in, s->dz, Z, T, Z, l.out));
-            hipLaunchKernelGGL(k_sv_reparam_bwd, dim3(T), dim3(256), 0, st, s->dz, s->mu, s->lv, s->eps, T, Z, beta_over_T, s->L[li - 1].D,
-                               s->kl_rows);
+            hipLaunchKernelGGL(k_sv_reparam_bwd, dim3(T), dim3(256), 0, st, s->dz, s->mu, s->lv, s->eps, T, Z, beta_over_T, kl_scale,
+                               s->L[li - 1].D, s->kl_rows);
         } else {
             SvLayer& p = s->L[li - 1];   // tanh layer: D_prev = (D W) * (1 - A_prev^2)
             RTX_TRY(sv_gemm(s, st, l.D, l.out, 1, s->params[2 * li], 1, l.in, p.D, p.out, T, p.out, l.out, SV_EPI_TANH_GRAD, nullptr, p.A, p.out));
@@ -691,7 +732,7 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
         SvLayer& l = s->L[li];
         const float* in;
         long ld_in;
-        if (li == 0) { in = s->H + R; ld_in = R; }
+        if (li == 0) { in = s->Hout; ld_in = R; }
         else if (li == s->n_enc) { in = s->zl; ld_in = Z; }
         else { in = s->L[li - 1].A; ld_in = s->L[li - 1].out; }
         // dW[out][in] = sum_t D[t][out] * in[t][in];  db = column sums
@@ -699,11 +740,12 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
         RTX_TRY(sv_colsum(s->side, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]));
     }
     RTX_HIP(hipEventRecord(s->ev_join, s->side));
-    hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, loss_out, loss_accum);
+    hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, nll_scale, kl_scale, loss_out,
+                       loss_accum);
     // ---- GRU backward through time, then its weight gradients over all steps at once
-    hipLaunchKernelGGL(k_sv_gru_bwd, dim3(1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], T, R, s->H, s->Gr,
-                       s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
-    RTX_TRY(sv_gemm(s, st, s->dGH, 1, 3 * R, s->H, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));          // dW_hh = dGH^T H_prev
+    hipLaunchKernelGGL(k_sv_gru_bwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], seq_ptr, T,
+                       R, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
+    RTX_TRY(sv_gemm(s, st, s->dGH, 1, 3 * R, s->Hprev, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));      // dW_hh = dGH^T H_prev
     RTX_TRY(sv_colsum(st, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]));
     RTX_TRY(sv_gemm(s, st, s->dGI, 1, 3 * R, s->X, 1, E, s->grads[sv_tail(s, SV_T_WIH)], E, 3 * R, E, T));          // dW_ih = dGI^T X
     RTX_TRY(sv_colsum(st, s->dGI, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BIH)]));
@@ -731,6 +773,34 @@ int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int6
     a.beta1 = step->beta1; a.beta2 = step->beta2; a.eps = step->eps; a.weight_decay = step->weight_decay;
     a.grad_scale = 1.f; a.lam = 0.f;
     return rtx_launch_adam(a, 0, st);
+}
+
+int rtx_svae_train_step(rtx_svae* s, const int32_t* items, int32_t T, const int64_t* target_indptr, const int32_t* target_indices,
+                        const float* target_dense, const rtx_step* step, float* loss_out, float* loss_accum, void* stream)
+{
+    RTX_TRY(sv_check(s, items, T, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "svae_train_step: step count must be >= 1");
+    RTX_CHECK((target_indptr && target_indices) || target_dense, RTX_EINVAL, "svae_train_step: no target");
+    return sv_train(s, items, T, nullptr, 1, nullptr, nullptr, target_indptr, target_indices, target_dense, step, loss_out, loss_accum,
+                    (hipStream_t)stream);
+}
+
+// Several users per optimizer step (NOT in the reference, which takes one Adam step per user): the sequences are concatenated,
+// row t belongs to the sequence whose [seq_ptr[u], seq_ptr[u + 1]) contains it, and the step minimises
+//     sum_t nll_scale[t] * NLL_t + sum_t kl_scale[t] * KL_t
+// -- with nll_scale = 1 / (d_user * n_seq) and kl_scale = beta / (T_user * n_seq) the mean over the pack of the reference's
+// per-user loss, i.e. gradient accumulation over the pack followed by ONE Adam step.  Every product becomes a [sum T, .] GEMM;
+// the recurrences run one workgroup per sequence, side by side.
+int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, const int32_t* seq_ptr, int32_t n_seq, const float* nll_scale,
+                        const float* kl_scale, const int64_t* target_indptr, const int32_t* target_indices, const rtx_step* step, float* loss_out,
+                        float* loss_accum, void* stream)
+{
+    RTX_TRY(sv_check(s, items, total_steps, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "svae_train_pack: step count must be >= 1");
+    RTX_CHECK(seq_ptr && n_seq >= 1 && n_seq <= total_steps, RTX_EINVAL, "svae_train_pack: %d sequences over %d steps", n_seq, total_steps);
+    RTX_CHECK(nll_scale && kl_scale && target_indptr && target_indices, RTX_EINVAL, "svae_train_pack: NULL argument");
+    return sv_train(s, items, total_steps, seq_ptr, n_seq, nll_scale, kl_scale, target_indptr, target_indices, nullptr, step, loss_out, loss_accum,
+                    (hipStream_t)stream);
 }
 
 }  // extern "C"

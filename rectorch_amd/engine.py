@@ -432,6 +432,47 @@ class SvaeTarget:
         self.n_steps = len(rows)
 
 
+class SvaePack:
+    """Several user sequences for ONE optimizer step (``SVAE_Sampler(pack=N)``; not in the reference): the input items of all
+    users concatenated on the device, the row range of every user, and the targets of all time steps as one CSR.
+
+    ``seqs``: list of item-id lists (the model inputs, i.e. all but each user's last item); ``target_rows``: per user the list
+    (one entry per time step) of distinct target items.  ``d`` keeps, per user, the likelihood normaliser the reference's
+    training path uses (the ones of the user's FIRST step, see :class:`SvaeTarget`)."""
+    __slots__ = ("items", "seq_ptr", "lens", "indptr", "indices", "d", "n_steps", "users")
+
+    def __init__(self, seqs, target_rows, users=None, device="cuda"):
+        assert len(seqs) == len(target_rows) and len(seqs) >= 1
+        self.lens = [len(q) for q in seqs]
+        for q, rows in zip(seqs, target_rows):
+            assert len(q) == len(rows) and len(q) >= 1, "every sequence needs one target row per time step"
+        sp = np.zeros(len(seqs) + 1, dtype=np.int32)
+        sp[1:] = np.cumsum(self.lens)
+        self.n_steps = int(sp[-1])
+        self.items = torch.from_numpy(np.fromiter((i for q in seqs for i in q), dtype=np.int32, count=self.n_steps)).to(device)
+        self.seq_ptr = torch.from_numpy(sp).to(device)
+        ptr = np.zeros(self.n_steps + 1, dtype=np.int64)
+        ptr[1:] = np.cumsum(np.fromiter((len(r) for rows in target_rows for r in rows), dtype=np.int64, count=self.n_steps))
+        self.indptr = torch.from_numpy(ptr).to(device)
+        self.indices = torch.from_numpy(np.fromiter((i for rows in target_rows for r in rows for i in r), dtype=np.int32,
+                                                    count=int(ptr[-1]))).to(device)
+        self.d = [float(len(rows[0])) for rows in target_rows]
+        self.users = list(users) if users is not None else None
+
+    def __len__(self):
+        return len(self.lens)
+
+    def row_scales(self, beta):
+        """per-row loss factors of the pack's step: (1 / (d_u N), beta / (T_u N)) repeated over each user's rows, as ONE device
+        tensor [2, n_steps] (numpy on the host: torch.repeat_interleave on CPU tensors costs milliseconds)"""
+        n = len(self.lens)
+        lens = np.asarray(self.lens)
+        nll = np.array([1.0 / (d * n) if d != 0 else np.inf for d in self.d], dtype=np.float32)
+        kl = (np.float32(beta) / (lens * n)).astype(np.float32)
+        both = np.stack([np.repeat(nll, lens), np.repeat(kl, lens)])
+        return torch.from_numpy(both).to(self.items.device)
+
+
 class SvaeEngine:
     """One ``rtx_svae``: the SVAE network's compute state (embedding -> GRU -> VAE head -> decoder, float32), bound to
     the network's parameters and, for training, to gradient buffers and the Adam moments (see :class:`Engine`)."""
@@ -505,6 +546,14 @@ class SvaeEngine:
             ptr = idx = None
         check(lib().rtx_svae_train_step(self.handle, _ptr(items), T, _ptr(ptr), _ptr(idx), _ptr(dense), C.byref(step), _ptr(loss_out),
                                         _ptr(loss_accum), stream_ptr()))
+
+    def train_pack(self, pack, step, beta, loss_out, loss_accum=None):
+        """one optimizer step on the users of ``pack`` (:class:`SvaePack`): mean over the pack of the per-user SVAE loss"""
+        if pack.n_steps > self.max_len:
+            raise _lib.RtxError("the pack holds %d time steps, the engine was sized for %d" % (pack.n_steps, self.max_len))
+        sc = pack.row_scales(beta)
+        check(lib().rtx_svae_train_pack(self.handle, _ptr(pack.items), pack.n_steps, _ptr(pack.seq_ptr), len(pack), _ptr(sc[0]), _ptr(sc[1]),
+                                        _ptr(pack.indptr), _ptr(pack.indices), C.byref(step), _ptr(loss_out), _ptr(loss_accum), stream_ptr()))
 
     def __del__(self):
         h = getattr(self, "handle", None)

@@ -19,7 +19,7 @@ import torch
 import torch.optim as optim
 
 from . import _lib
-from .engine import CsrMatrix, EaseSolver, RowBatch, SvaeTarget, multinomial_loss, tagged_rows
+from .engine import CsrMatrix, EaseSolver, RowBatch, SvaePack, SvaeTarget, multinomial_loss, tagged_rows
 from .evaluation import ValidFunc, evaluate
 from .samplers import DataSampler
 
@@ -696,7 +696,8 @@ class EASE(RecSysModel):
 class SVAE(MultiVAE):
     r"""Sequential Variational Autoencoders for Collaborative Filtering (reference models.py:1581-1635).
 
-    One user sequence per optimizer step, as in the reference: ``train_batch(x, y)`` with ``x`` the LongTensor
+    One user sequence per optimizer step, as in the reference (several with ``SVAE_Sampler(pack=N)``, which is not: one
+    Adam step for the mean loss of a pack of users): ``train_batch(x, y)`` with ``x`` the LongTensor
     ``[1, T]`` of the user's items and ``y`` the multi-hot targets ``[1, T, n_items]`` yielded by
     :class:`rectorch_amd.samplers.SVAE_Sampler` (or its compact :class:`rectorch_amd.engine.SvaeTarget`).  The whole
     step -- embedding, GRU, VAE head, decoder, loss, back-propagation through time, Adam with ``weight_decay=5e-3`` --
@@ -740,9 +741,12 @@ class SVAE(MultiVAE):
         if te_batch is None:
             raise ValueError("SVAE.train_batch needs the target sequence (SVAE_Sampler yields it)")
         st, params, m, v = self._ensure_train_state()
-        T = int(tr_batch.numel())
+        pack = tr_batch if isinstance(tr_batch, SvaePack) else None
+        T = pack.n_steps if pack is not None else int(tr_batch.numel())
         eng = self.network.svae_engine(T, train_buffers=(st.grads, m, v))
-        if isinstance(te_batch, SvaeTarget):
+        if pack is not None:
+            d = 1.0           # every user's own normaliser travels with the pack's rows
+        elif isinstance(te_batch, SvaeTarget):
             d = te_batch.d
         else:
             # the reference flattens the target to [1, T * n_items] before loss_function reads x[0, :n_items]
@@ -764,7 +768,11 @@ class SVAE(MultiVAE):
         step.seed, step.offset = draw_seed() & (2 ** 64 - 1), 0
         step.dropout_mask = None
         step.eps_noise = None if noise is None else noise.data_ptr()
-        eng.train_step(tr_batch, te_batch, step, st.loss_buf[0:1], st.loss_buf[1:2])
+        if pack is not None:
+            # SVAE_Sampler(pack=N): ONE optimizer step for the mean of the pack's per-user losses (not in the reference)
+            eng.train_pack(pack, step, anneal_beta, st.loss_buf[0:1], st.loss_buf[1:2])
+        else:
+            eng.train_step(tr_batch, te_batch, step, st.loss_buf[0:1], st.loss_buf[1:2])
         self.gradient_updates += 1.
         return st.loss_buf[0].item()
 

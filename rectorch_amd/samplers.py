@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from scipy.sparse import csr_matrix, hstack
 
-from .engine import CsrMatrix, RowBatch, SvaeTarget, tag_rows
+from .engine import CsrMatrix, RowBatch, SvaePack, SvaeTarget, tag_rows
 
 __all__ = ['Sampler', 'DataSampler', 'ConditionedDataSampler', 'BalancedConditionedDataSampler',
            'EmptyConditionedDataSampler', 'SVAE_Sampler']
@@ -331,7 +331,12 @@ class SVAE_Sampler(Sampler):
     0); ``dict_data_te`` (dict user -> test items; required when ``is_training`` is off); ``pred_type`` (``'next_k'``
     -- the default -- ``'next'`` or ``'postfix'``); ``k`` (items to predict for ``'next_k'``, at least 1); ``shuffle``
     (visit the users in a random order drawn from numpy's global generator, default on); ``is_training`` (default on);
-    ``sparse`` (see above).
+    ``sparse`` (see above); ``pack`` (not in the reference, default 1 = one user per batch and per optimizer step, as the
+    reference): with ``pack = N > 1`` a training batch is a :class:`rectorch_amd.engine.SvaePack` of up to ``N`` users --
+    yielded as ``(pack, pack)`` -- on which :meth:`rectorch_amd.models.SVAE.train_batch` takes ONE Adam step for the mean of the
+    users' losses (gradient accumulation over the pack).  A pack costs its LONGEST recurrence, so the (shuffled) users are
+    grouped by length inside windows of ``16 * N`` users and the packs of a window visited in random order; ``pack_tokens``
+    bounds the time steps of one pack (default 16 384).
     """
     def __init__(self,
                  num_items,
@@ -341,7 +346,9 @@ class SVAE_Sampler(Sampler):
                  k=1,
                  shuffle=True,
                  is_training=True,
-                 sparse=False):
+                 sparse=False,
+                 pack=1,
+                 pack_tokens=16384):
         super(SVAE_Sampler, self).__init__()
         if pred_type == "next_k":
             assert k >= 1, "If pred_type == 'next_k' then 'k' must be a positive integer."
@@ -353,9 +360,36 @@ class SVAE_Sampler(Sampler):
         self.k = k
         self.is_training = is_training
         self.sparse = sparse
+        assert pack >= 1 and pack_tokens >= 1
+        self.pack = int(pack)
+        self.pack_tokens = int(pack_tokens)
 
     def __len__(self):
+        if self.pack > 1 and self.is_training:
+            # packs of the unshuffled order; a shuffled epoch may differ by a pack or two (the token bound cuts differently)
+            return sum(len(w) for w in self._pack_windows(list(range(len(self.dict_data_tr)))))
         return len(self.dict_data_tr)
+
+    def _pack_windows(self, idxlist):
+        """the users of ``idxlist`` cut into windows of 16 * pack, each sorted by length and cut into packs (lists of users)
+        of at most ``pack`` users and ``pack_tokens`` time steps; users without a time step (fewer than 2 items) are skipped"""
+        window = 16 * self.pack
+        out = []
+        for w0 in range(0, len(idxlist), window):
+            win = [u for u in idxlist[w0:w0 + window] if len(self.dict_data_tr[u]) >= 2]
+            win.sort(key=lambda u: len(self.dict_data_tr[u]))
+            packs, cur, tok = [], [], 0
+            for u in win:
+                t = len(self.dict_data_tr[u]) - 1
+                if cur and (len(cur) == self.pack or tok + t > self.pack_tokens):
+                    packs.append(cur)
+                    cur, tok = [], 0
+                cur.append(u)
+                tok += t
+            if cur:
+                packs.append(cur)
+            out.append(packs)
+        return out
 
     def _target_rows(self, user):
         """the distinct target items of every time step of ``user`` (list of lists)"""
@@ -379,6 +413,14 @@ class SVAE_Sampler(Sampler):
         idxlist = list(range(len(self.dict_data_tr)))
         if self.shuffle:
             np.random.shuffle(idxlist)
+        if self.pack > 1 and self.is_training:
+            for packs in self._pack_windows(idxlist):
+                order = np.random.permutation(len(packs)) if self.shuffle else range(len(packs))
+                for pi in order:
+                    users = packs[pi]
+                    p = SvaePack([self.dict_data_tr[u][:-1] for u in users], [self._target_rows(u) for u in users], users)
+                    yield p, p
+            return
         for user in idxlist:
             rows = self._target_rows(user)
             x = torch.LongTensor([self.dict_data_tr[user][:-1]])

@@ -956,6 +956,64 @@ def test_svae_vs_oracle_longer_sequences():
             assert float(dlt.max()) < 1e-3 and float(np.mean(dlt > 2e-5)) < 1e-4, (T, k, float(dlt.max()))
 
 
+def test_svae_pack_of_users_vs_oracle():
+    """SVAE_Sampler(pack=N) (not in the reference): ONE Adam step for the mean of the per-user losses of a pack of users with
+    different lengths -- concatenated rows, one recurrence workgroup per user, per-row loss factors -- against the numpy
+    oracle's gradient accumulation (loss, every gradient, parameters after two packs); a pack of ONE user computes what the
+    reference's per-user step computes."""
+    from oracle.svae_oracle import SvaeOracle
+    from rectorch_amd.nets import SVAE_net
+    from rectorch_amd.models import SVAE
+    from rectorch_amd.engine import SvaePack
+    from rectorch_amd.samplers import SVAE_Sampler
+    torch.manual_seed(5)
+    I, E, R, H, L, D = 300, 48, 40, 36, 16, 28
+    net = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
+    sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    model = SVAE(net.to("cuda"), beta=0.3, anneal_steps=0)
+    orc = SvaeOracle(sd, n_enc=2, n_dec=2, beta=0.3)
+    rng = np.random.RandomState(11)
+    data = {u: rng.randint(0, I, size=n).tolist() for u, n in enumerate((2, 9, 41, 17, 130, 3, 66))}
+    smp = SVAE_Sampler(I, data, None, pred_type="next_k", k=3, shuffle=False, sparse=True, pack=4)
+    packs = [p for p, _ in smp]
+    assert len(packs) == len(smp) == 2 and sorted(u for p in packs for u in p.users) == list(range(7))
+    assert [len(data[u]) for u in packs[0].users] == sorted(len(data[u]) for u in packs[0].users)     # grouped by length
+    for p in packs:
+        eps = rng.randn(p.n_steps, L).astype(np.float32)
+        model._rtx.inject = (None, dev(eps))
+        loss = model.train_batch(p, p)
+        users, o = [], 0
+        for u, n in zip(p.users, p.lens):
+            rows = smp._target_rows(u)
+            y = np.zeros((n, I))
+            for t, r in enumerate(rows):
+                y[t, r] = 1.0
+            users.append((np.array(data[u][:-1]), y, eps[o:o + n].astype(np.float64)))
+            o += n
+        lo = orc.train_pack(users)
+        assert abs(loss - lo) < 2e-5 * abs(lo), (loss, lo)
+        for k, prm in zip(orc.keys, net._param_list()):
+            assert rel(prm.grad.cpu(), orc.last_grads[k]) < 5e-4, k
+            dlt = np.abs(prm.detach().cpu().numpy() - orc.p[k])
+            assert float(dlt.max()) < 1e-3 and float(np.mean(dlt > 2e-5)) < 1e-4, (k, float(dlt.max()))
+    # a pack of one user == the per-user step (same objective, same kernels; only the loss factors travel per row)
+    net1 = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
+    net2 = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
+    net1.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m1, m2 = SVAE(net1.to("cuda"), beta=0.3, anneal_steps=0), SVAE(net2.to("cuda"), beta=0.3, anneal_steps=0)
+    one = SVAE_Sampler(I, {0: data[4]}, None, pred_type="next_k", k=3, shuffle=False, sparse=True)
+    (x, y), = list(one)
+    eps = dev(rng.randn(x.numel(), L).astype(np.float32))
+    m1._rtx.inject = m2._rtx.inject = (None, eps)
+    l1 = m1.train_batch(x, y)
+    pk = SvaePack([data[4][:-1]], [one._target_rows(0)])
+    l2 = m2.train_batch(pk, pk)
+    assert abs(l1 - l2) < 1e-6 * abs(l1)
+    for a, b in zip(net1.parameters(), net2.parameters()):
+        assert float((a - b).abs().max()) < 1e-6
+
+
 def test_dp_world2_on_one_gpu():
     """two data-parallel ranks (gloo over device tensors) on the one GPU of the box: row sharding, bucketed exchange
     (float32 and bf16), per-bucket Adam -- three steps must land on the reference's parameters on both ranks"""

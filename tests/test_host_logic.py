@@ -414,3 +414,31 @@ def test_data_reader_dicts_match_reference_g13():
         d1, d2 = r.load_data_as_dict(dt)
         check(d1, "dict_%s_tr" % dt)
         check(d2, "dict_%s_te" % dt)
+
+
+def test_svae_sampler_pack_plan():
+    """SVAE_Sampler(pack=N): the packing plan is host bookkeeping -- every user with at least one time step lands in exactly
+    one pack, a pack holds at most N users and pack_tokens time steps, users of a window are grouped by length, and len()
+    counts the packs; pack=1 leaves the reference's one-user-per-batch iteration untouched"""
+    from rectorch_amd.samplers import SVAE_Sampler
+    rng = np.random.RandomState(2)
+    data = {u: list(range(int(n))) for u, n in enumerate(rng.randint(1, 200, size=333))}
+    smp = SVAE_Sampler(500, data, None, pred_type="next", shuffle=True, sparse=True, pack=8, pack_tokens=600)
+    order = list(range(len(data)))
+    np.random.seed(0)
+    np.random.shuffle(order)
+    wins = smp._pack_windows(order)
+    packs = [p for w in wins for p in w]
+    seen = sorted(u for p in packs for u in p)
+    assert seen == sorted(u for u in data if len(data[u]) >= 2)
+    # len() plans the unshuffled order (the count varies by a pack or two with the order: the token bound cuts differently)
+    assert len(smp) == sum(len(w) for w in smp._pack_windows(list(range(len(data))))) and abs(len(smp) - len(packs)) <= 3
+    for w, win_users in zip(wins, (order[i:i + 128] for i in range(0, len(order), 128))):
+        flat = [u for p in w for u in p]
+        assert set(flat) == {u for u in win_users if len(data[u]) >= 2}
+        lens = [len(data[u]) for u in flat]
+        assert lens == sorted(lens)
+        for p in w:
+            assert 1 <= len(p) <= 8
+            assert sum(len(data[u]) - 1 for u in p) <= 600 or len(p) == 1
+    assert len(SVAE_Sampler(500, data, None, pred_type="next", sparse=True)) == len(data)

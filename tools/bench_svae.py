@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--pack", type=int, default=1, help="users per optimizer step (SVAE_Sampler(pack=N); 1 = the reference's per-user step)")
     a = ap.parse_args()
     rng = np.random.RandomState(1)
     lens = np.clip(rng.lognormal(np.log(a.mean_len) - 0.5, 1.0, size=a.users).astype(int), 5, a.max_len)
@@ -48,43 +49,54 @@ def main():
     sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
     model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=20000)
     np.random.seed(0)
-    smp = SVAE_Sampler(a.items, seqs, None, pred_type="next_k", k=a.k, shuffle=True, sparse=True)
+    smp = SVAE_Sampler(a.items, seqs, None, pred_type="next_k", k=a.k, shuffle=True, sparse=True, pack=a.pack)
     batches = []
     for i, (x, y) in enumerate(smp):
-        batches.append((x.to("cuda"), y))
+        batches.append((x if a.pack > 1 else x.to("cuda"), y))
         if i + 1 >= a.steps + a.warmup:
             break
     n = len(batches)
     w = min(a.warmup, n // 2)
+    n_users = lambda b: len(b[0]) if a.pack > 1 else 1                       # noqa: E731
+    n_steps = lambda b: b[0].n_steps if a.pack > 1 else b[0].numel()         # noqa: E731
     for x, y in batches[:w]:
         model.train_batch(x, y)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps_t = 0
-    for x, y in batches[w:]:
-        model.train_batch(x, y)          # returns loss.item(): one host sync per user, as in the reference
-        steps_t += x.numel()
+    steps_t = users_t = longest = 0
+    for b in batches[w:]:
+        model.train_batch(*b)            # returns loss.item(): one host sync per optimizer step, as in the reference
+        steps_t += n_steps(b)
+        users_t += n_users(b)
+        longest += max(b[0].lens) if a.pack > 1 else n_steps(b)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"workload": "SVAE train, synthetic ml-1m shape: %d items, embed 256, GRU 200, enc [200,150,64], dec [64,150,I], "
-                       "next_k k=%d, one user per Adam step" % (a.items, a.k),
-           "users_per_s": (n - w) / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / (n - w) * 1e3,
-           "mean_len": steps_t / (n - w), "users_timed": n - w, "dtype": "f32"}
-    # the dominant kernels are the two GRU recurrences: ONE workgroup each, a chain of T dependent mat-vecs that re-read
-    # W_hh (3R x R floats) from L2 every step.  Against the HBM roofline that is a tiny fraction by construction (one CU of
-    # 256, latency-bound); the figure that matters is microseconds per time step.
-    eng = net._svae_engine
+                       "next_k k=%d, %s" % (a.items, a.k, "one user per Adam step (the reference's semantics)" if a.pack == 1 else
+                                            "packs of up to %d users per Adam step (mean of the users' losses; not in the reference)" % a.pack),
+           "pack": a.pack, "users_per_s": users_t / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / users_t * 1e3,
+           "ms_per_optimizer_step": dt / (n - w) * 1e3, "mean_len": steps_t / users_t, "users_timed": users_t,
+           "optimizer_steps_timed": n - w, "dtype": "f32"}
+    # the recurrences (k_sv_gru_fwd / k_sv_gru_bwd: one persistent workgroup per sequence) re-read W_hh (3R x R floats) from L2
+    # on every time step: their roof is one compute unit's L2 path (64 B/clk at 2.4 GHz = 154 GB/s) per sequence in flight.
+    # `achieved` prices the W_hh bytes of the LONGEST sequence of every step (the recurrences of a pack run side by side) against
+    # the WHOLE step time -- a lower bound for the recurrence kernels themselves, since the step also holds the GEMMs and Adam.
     whh_bytes = 3 * 200 * 200 * 4
-    out["roofline"] = {"kernel": "k_sv_gru_fwd + k_sv_gru_bwd (persistent single-workgroup recurrences)", "bound": "hbm",
-                       "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+    ach = 2.0 * whh_bytes * longest / dt / 1e9
+    out["roofline"] = {"kernel": "k_sv_gru_fwd + k_sv_gru_bwd (one persistent workgroup per sequence)", "bound": "l2_to_cu_path",
+                       "achieved": ach, "peak": 153.6, "unit": "GB/s per sequence in flight", "frac": ach / 153.6, "traffic": None,
                        "algorithmic_bytes_per_time_step": 2 * whh_bytes,
-                       "note": "per-step latency bound on one CU; see profiles/r1_svae_kernel_stats.txt for us per launch"}
+                       "note": "lower bound (whole-step time); per-kernel times in profiles/r2_svae_kernel_stats.txt"}
     if a.cpu_seconds > 0:
         from oracle.svae_oracle import SvaeOracle
         orc = SvaeOracle(sd, n_enc=2, n_dec=2, beta=0.2, anneal_steps=20000)
         t0 = time.perf_counter()
         done = ts = 0
-        for x, y in batches[w:]:
+        cpu_batches = batches[w:]
+        if a.pack > 1:       # the baseline is the reference's algorithm: one user per step
+            np.random.seed(0)
+            cpu_batches = [(x.to("cuda"), y) for x, y in SVAE_Sampler(a.items, seqs, None, pred_type="next_k", k=a.k, shuffle=True, sparse=True)]
+        for x, y in cpu_batches:
             items = x.cpu().numpy().reshape(-1)
             T = len(items)
             yd = np.zeros((T, a.items))
