@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--items", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-parity", action="store_true")
+    ap.add_argument("--kernel-timing-every", type=int, default=8, help="bracket every N-th launch of the dominant kernel with HIP events")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="no HIP events around the dominant kernel (roofline.achieved becomes null): measures what the events cost")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="engine measurement knob for an A/B run (include/rectorch_hip.h, rtx_engine_set_option)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -238,8 +241,10 @@ def main():
     _flush_c_stdio()
     eng = net._rtx_engines[args.numerics]
     sites = ("adam",) if (dp or args.numerics != "bf16") else ("dW_adam_out", "dW_adam_in")
-    for sname in sites:
-        eng.set_timing(sname, True)         # HIP events around the dominant kernel, on the stream it runs on
+    for sname in (() if args.no_kernel_timing else sites):
+        # HIP events around the dominant kernel, on the stream it runs on, inside the timed region; every 8th launch is
+        # bracketed (the two records of a timed launch cost the step ~5 us each on its critical stream: 322 vs 313 us measured)
+        eng.set_timing(sname, args.kernel_timing_every)
     wins = timed_windows(run, args.steps, args.windows, world, args.warmup)
     timings = eng.get_timings()
     eng.set_timing(None, False)
@@ -258,7 +263,7 @@ def main():
     if dp or args.numerics != "bf16":
         # one multi-tensor Adam launch per step (single GPU, float32) or one per gradient bucket (data parallel)
         adam_ms, adam_n = timings.get("adam", (0.0, 0))
-        launches_per_step = max(1, round(adam_n / max(1, args.steps * args.windows)))
+        launches_per_step = max(1, round(adam_n * (1 if args.no_kernel_timing else args.kernel_timing_every) / max(1, args.steps * args.windows)))
         adam_us = adam_ms * 1e3 / max(adam_n, 1) * launches_per_step
         # Adam reads p,g,m,v (16 B/param) and writes p,m,v (12 B/param); with the bf16 gradient exchange of the
         # data-parallel bf16 mode the reduced gradient is read as bf16 (2 B/param less); a sharded optimizer touches P / N
@@ -303,7 +308,8 @@ def main():
         "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_TBS * 1000.0, "unit": "GB/s",
                      "frac": (achieved / (HBM_PEAK_TBS * 1000.0)) if achieved else None,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": kbytes, "avg_us": kus, "launches": kn},
+                     "traffic": traffic, "algorithmic_bytes_per_launch": kbytes, "avg_us": kus, "launches_timed": kn,
+                     "timed_every": args.kernel_timing_every},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
                           "frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000.0),
                           "algorithmic_flops_per_step": step_flops,

@@ -266,6 +266,8 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
+/* enable: 0 = off, 1 = every launch of the site, N > 1 = every N-th launch (two event records cost a few microseconds of the
+ * stream they are recorded on: a sampled site perturbs a timed loop N times less) */
 int rtx_engine_set_timing(rtx_engine* e, const char* site /* NULL = every launch site */, int32_t enable);
 /* synchronises, returns up to `cap` entries (name, total ms, launches) and clears the counters */
 int rtx_engine_get_timings(rtx_engine* e, int32_t cap, char (*names)[48], float* total_ms, int32_t* launches,

@@ -91,7 +91,8 @@ struct rtx_engine {
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
     bool timing_all = false;
-    std::map<std::string, bool> timing_sites;
+    std::map<std::string, int> timing_sites;   // site -> sampling period (every N-th launch of the site is bracketed by events)
+    std::map<std::string, long> timing_seen;
     std::map<std::string, TimingSite> sites;
     std::vector<hipEvent_t> event_pool;
 };
@@ -155,7 +156,12 @@ struct ScopedTimer {
     ScopedTimer(rtx_engine* eng, const char* name, hipStream_t st) : e(eng), s(st)
     {
         if (!e->timing_all && e->timing_sites.empty()) return;
-        if (!e->timing_all && !e->timing_sites.count(name)) return;
+        if (!e->timing_all) {
+            auto it = e->timing_sites.find(name);
+            if (it == e->timing_sites.end()) return;
+            // an event record costs microseconds on the stream it is recorded on (two per timed launch): sample
+            if (it->second > 1 && (e->timing_seen[name]++ % it->second) != 0) return;
+        }
         site = &e->sites[name];
         auto get = [&]() {
             hipEvent_t ev;
@@ -1139,7 +1145,8 @@ int rtx_engine_set_timing(rtx_engine* e, const char* site, int32_t enable)
         e->timing_all = enable != 0;
         if (!enable) e->timing_sites.clear();
     } else if (enable) {
-        e->timing_sites[site] = true;
+        e->timing_sites[site] = enable;
+        e->timing_seen[site] = 0;
     } else {
         e->timing_sites.erase(site);
     }
