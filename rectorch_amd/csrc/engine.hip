@@ -86,7 +86,6 @@ struct rtx_engine {
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
-    int opt_layer_epilogue = 1; // bf16 hidden layers: bias / tanh / tanh' / VAE-head backward in the GEMM's epilogue (no k_post / k_vae_bwd launch)
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
@@ -239,24 +238,6 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form 
     return pl;
 }
 
-// A hidden layer's product with its element-wise tail in the GEMM's epilogue (one launch instead of split-K GEMM + k_post /
-// k_vae_bwd): bf16, LDS-DMA kernel, K short enough that one workgroup per tile walks it (<= 16 slices = 1024).
-static bool layer_epilogue_ok(const rtx_engine* e, int Mp, int Np, int Kp, int form)
-{
-    if (!e->bf16 || !e->opt_layer_epilogue) return false;
-    const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, form);
-    return !pl.regstage && (pl.cfg == RTX_DMA_128x128 || pl.cfg == RTX_DMA_128x128_S2) && pl.k_slices <= 16;
-}
-static int gemm_layer(rtx_engine* e, int form, int epi, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, RtxGemm g,
-                      hipStream_t st)
-{
-    const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, form);
-    g.form = form;
-    g.A = A; g.B = B; g.lda = lda; g.ldb = ldb;
-    g.k_slices = pl.k_slices; g.tile_shape = pl.cfg; g.m_tiles = pl.m_tiles; g.n_tiles = pl.n_tiles; g.splits = 1;
-    return rtx_gemm_dma_launch(g, epi, st);
-}
-
 static size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
 {
     size_t mx = 0;
@@ -397,21 +378,12 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             }
             break;
         }
-        Layer& nx = e->L[li + 1];
-        if (!(e->vae && li == e->cfg.n_enc - 1) && layer_epilogue_ok(e, Bp, l.outp, l.inp, RTX_FORM_NT)) {
-            // bias + tanh + the next layer's bf16 input (with its ones column) from the GEMM's epilogue
-            RtxGemm g = {};
-            g.bias = e->params[2 * li + 1]; g.M_real = B; g.N_real = l.out;
-            g.O32 = l.O32; g.R = nx.A; g.ldr = l.outp; g.tanh_act = l.tanh_act; g.ones_col = 1;
-            TIMED("gemm_fwd_hidden");
-            RTX_TRY(gemm_layer(e, RTX_FORM_NT, RTX_EPI_POST_FWD, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, g, st));
-            continue;
-        }
         int splits = 1;
         {
             TIMED(li == 0 ? "gemm_fwd_in" : "gemm_fwd_hidden");
             RTX_TRY(gemm_to_cacc(e, RTX_FORM_NT, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, &splits, st));
         }
+        Layer& nx = e->L[li + 1];
         if (e->vae && li == e->cfg.n_enc - 1) {
             RtxVaeFwdArgs a = {};
             a.C = e->Cacc; a.splits = splits; a.slab_stride = (long)Bp * l.outp; a.ldc = l.outp;
@@ -887,21 +859,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         }
         // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
         // the weight kernel of this layer, whose fused optimizer epilogue overwrites the compute copy.
-        if (li > 0 && layer_epilogue_ok(e, Bp, l.inp, l.outp, RTX_FORM_NN)) {
-            // the previous layer's delta straight from the data-gradient GEMM's epilogue
-            Layer& pv = e->L[li - 1];
-            RtxGemm g = {};
-            g.M_real = B; g.R = pv.D; g.ldr = pv.outp;
-            TIMED("gemm_dX_hidden");
-            if (e->vae && li == e->cfg.n_enc) {
-                g.N_real = e->Z; g.Z = e->Z; g.mu32 = e->mu32; g.lv32 = e->lv32; g.eps32 = e->eps32; g.training = 1;
-                g.beta = step->beta; g.inv_batch = step->inv_batch;
-                RTX_TRY(gemm_layer(e, RTX_FORM_NN, RTX_EPI_VAE_BWD, l.D, l.outp, l.Wsh, l.inp, Bp, l.inp, l.outp, g, st));
-            } else {
-                g.N_real = pv.out; g.tanh_act = pv.tanh_act; g.O32 = pv.O32;
-                RTX_TRY(gemm_layer(e, RTX_FORM_NN, RTX_EPI_POST_BWD, l.D, l.outp, l.Wsh, l.inp, Bp, l.inp, l.outp, g, st));
-            }
-        } else if (li > 0) {
+        if (li > 0) {
             int splits = 1;
             {
                 TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
@@ -1114,7 +1072,6 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
-    else if (k == "layer_epilogue") e->opt_layer_epilogue = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;
@@ -1134,7 +1091,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, layer_epilogue, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 1 ? (WM * WN) / 4 : 1)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         bj[j] = 0.f;
-        if ((EPI == RTX_EPI_BIAS_ROWS || EPI == RTX_EPI_POST_FWD) && p.bias) {
+        if (EPI == RTX_EPI_BIAS_ROWS && p.bias) {
             const int col = col0 + j * 32 + r;
             bj[j] = p.bias[col < p.N_real ? col : 0];
         }
@@ -318,54 +318,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 1 ? (WM * WN) / 4 : 1)
                 if (ehalf == 0 && row < p.M_real) p.lse_part[(size_t)row * p.lse_ld + (tn * WN + wn)] = make_float2(mm, s);
             }
         }
-        if constexpr (EPI == RTX_EPI_POST_FWD || EPI == RTX_EPI_POST_BWD) {
-            // k_post on the tile (every element of the padded tile is written: zeros outside the real rows / columns)
-            const bool rowv = row < p.M_real;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int c = colh + q * 4;
-                float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-                if (EPI == RTX_EPI_POST_BWD && p.tanh_act) {
-                    const gd_f32x4 o = *(const gd_f32x4*)(p.O32 + (size_t)row * p.ldr + c);
-                    x[0] *= (1.f - o.x * o.x); x[1] *= (1.f - o.y * o.y); x[2] *= (1.f - o.z * o.z); x[3] *= (1.f - o.w * o.w);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool valid = rowv && (c + k < p.N_real);
-                    float y = x[k];
-                    if (EPI == RTX_EPI_POST_FWD && valid && p.tanh_act) y = tanhf(y);
-                    x[k] = valid ? y : 0.f;
-                }
-                if (EPI == RTX_EPI_POST_FWD && p.O32) {
-                    gd_f32x4 o;
-                    o.x = x[0]; o.y = x[1]; o.z = x[2]; o.w = x[3];
-                    *(gd_f32x4*)(p.O32 + (size_t)row * p.ldr + c) = o;
-                }
-                if (EPI == RTX_EPI_POST_FWD && p.ones_col && rowv && p.N_real >= c && p.N_real < c + 4) x[p.N_real - c] = 1.f;
-                store4<bf16_t>((bf16_t*)p.R + (size_t)row * p.ldr + c, x[0], x[1], x[2], x[3]);
-            }
-        } else if constexpr (EPI == RTX_EPI_VAE_BWD) {
-            // k_vae_bwd on the tile: column j of the product is dz_j; the delta of the encoder head has mu at [0, Z), logvar at [Z, 2Z)
-            const bool rowv = row < p.M_real;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int j = colh + q * 4 + k;
-                    if (j >= p.Z) continue;
-                    float dmu = 0.f, dlv = 0.f;
-                    if (rowv) {
-                        const size_t o = (size_t)row * p.Z + j;
-                        const float dz = v[q][k], lv = p.lv32[o];
-                        dmu = dz + p.beta * p.mu32[o] * p.inv_batch;
-                        dlv = p.beta * 0.5f * (expf(lv) - 1.f) * p.inv_batch;
-                        if (p.training) dlv += dz * p.eps32[o] * 0.5f * expf(0.5f * lv);
-                    }
-                    bf16_t* d = (bf16_t*)p.R + (size_t)row * p.ldr;
-                    d[j] = f32_to_bf16(dmu);
-                    d[p.Z + j] = f32_to_bf16(dlv);
-                }
-        } else {
         const bool row_ok = (EPI == RTX_EPI_STORE) || row < p.M_real;
         if (row_ok) {
             float* dst = cbase + (size_t)row * ld + colh;
@@ -381,7 +333,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 1 ? (WM * WN) / 4 : 1)
                     if (c + 3 < p.N_real) dst[q * 4 + 3] = v[q].w;
                 }
             }
-        }
         }
     }
 }
@@ -420,43 +371,22 @@ template <int FORM, int EPI> static int gd_launch_cfg(const RtxGemm& g, dim3 gri
     }
 }
 
-// the layer epilogues exist for the two 128x128 configurations only (what hidden layers use)
-template <int FORM, int EPI> static int gd_launch_small(const RtxGemm& g, dim3 grid, hipStream_t stream)
-{
-    if (g.tile_shape == RTX_DMA_128x128_S2) return gd_launch<FORM, EPI, 2, 2, 2, 2, 2>(g, grid, stream);
-    return gd_launch<FORM, EPI, 2, 2, 2, 2, 3>(g, grid, stream);
-}
-
-// bf16 operands only.  g.tile_shape is an RtxDmaCfg; g.form RTX_FORM_NT / RTX_FORM_NN; epilogue RTX_EPI_STORE / RTX_EPI_BIAS_ROWS, or a
-// layer epilogue (RTX_EPI_POST_FWD with NT; RTX_EPI_POST_BWD / RTX_EPI_VAE_BWD with NN; 128x128 configurations, no split-K).
+// bf16 operands only.  g.tile_shape is an RtxDmaCfg; g.form RTX_FORM_NT / RTX_FORM_NN; epilogue RTX_EPI_STORE / RTX_EPI_BIAS_ROWS.
 int rtx_gemm_dma_launch(const RtxGemm& g, int epilogue, hipStream_t stream)
 {
-    const bool layer_epi = epilogue == RTX_EPI_POST_FWD || epilogue == RTX_EPI_POST_BWD || epilogue == RTX_EPI_VAE_BWD;
     RTX_CHECK(g.form == RTX_FORM_NT || g.form == RTX_FORM_NN, RTX_EINVAL, "gemm_dma: form %d not supported", g.form);
-    RTX_CHECK(epilogue == RTX_EPI_STORE || epilogue == RTX_EPI_BIAS_ROWS || layer_epi, RTX_EINVAL, "gemm_dma: bad epilogue %d", epilogue);
+    RTX_CHECK(epilogue == RTX_EPI_STORE || epilogue == RTX_EPI_BIAS_ROWS, RTX_EINVAL, "gemm_dma: bad epilogue %d", epilogue);
     RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm_dma: empty problem");
     RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm_dma: split-K only with EPI_STORE");
     RTX_CHECK(g.tile_shape >= RTX_DMA_128x128 && g.tile_shape <= RTX_DMA_128x128_S2, RTX_EINVAL, "gemm_dma: bad tile configuration %d", g.tile_shape);
     RTX_CHECK((g.splits - 1) * ((g.k_slices + g.splits - 1) / g.splits) < g.k_slices, RTX_EINVAL, "gemm_dma: %d splits leave an empty split of %d slices",
               g.splits, g.k_slices);
-    if (layer_epi) {
-        RTX_CHECK(g.tile_shape == RTX_DMA_128x128 || g.tile_shape == RTX_DMA_128x128_S2, RTX_EINVAL, "gemm_dma: layer epilogues need a 128x128 configuration");
-        RTX_CHECK((epilogue == RTX_EPI_POST_FWD) == (g.form == RTX_FORM_NT), RTX_EINVAL, "gemm_dma: POST_FWD goes with NT, the backward epilogues with NN");
-        RTX_CHECK(g.R && (g.ldr & 3) == 0, RTX_EINVAL, "gemm_dma: layer epilogue output is NULL or its rows are not 16-byte periodic");
-        if (epilogue == RTX_EPI_VAE_BWD)
-            RTX_CHECK(g.mu32 && g.lv32 && g.eps32 && g.Z >= 1 && 2 * g.Z <= g.ldr && g.Z <= g.n_tiles * 128, RTX_EINVAL, "gemm_dma: VAE_BWD arguments");
-        else
-            RTX_CHECK(g.ldr >= (long)g.n_tiles * 128 && (epilogue != RTX_EPI_POST_BWD || !g.tanh_act || g.O32), RTX_EINVAL, "gemm_dma: POST epilogue arguments");
-    }
     const int tiles = g.m_tiles * g.n_tiles;
     int groups, gsize;
     if (g.splits > 1) { groups = g.splits; gsize = tiles; }
     else if (g.m_tiles <= g.n_tiles) { groups = g.n_tiles; gsize = g.m_tiles; }
     else { groups = g.m_tiles; gsize = g.n_tiles; }
     const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * gsize));
-    if (epilogue == RTX_EPI_POST_FWD) return gd_launch_small<RTX_FORM_NT, RTX_EPI_POST_FWD>(g, grid, stream);
-    if (epilogue == RTX_EPI_POST_BWD) return gd_launch_small<RTX_FORM_NN, RTX_EPI_POST_BWD>(g, grid, stream);
-    if (epilogue == RTX_EPI_VAE_BWD) return gd_launch_small<RTX_FORM_NN, RTX_EPI_VAE_BWD>(g, grid, stream);
     if (g.form == RTX_FORM_NT) {
         if (epilogue == RTX_EPI_STORE) return gd_launch_cfg<RTX_FORM_NT, RTX_EPI_STORE>(g, grid, stream);
         return gd_launch_cfg<RTX_FORM_NT, RTX_EPI_BIAS_ROWS>(g, grid, stream);

@@ -22,11 +22,6 @@ enum RtxEpilogue {
     RTX_EPI_STORE = 0,   // C (fp32) [M_pad][ldc] (+ split * slab_stride): raw accumulators, unguarded
     RTX_EPI_BIAS_ROWS = 1,  // C[m][n] = acc + bias[n] for m < M_real, n < N_real (ldc arbitrary): logits
     RTX_EPI_GRAD = 2,    // gW[m * N_real + n] = acc (m < M_real, n < N_real); gb[m] = acc at n == N_real
-    // layer epilogues of the LDS-DMA GEMM (gemm_dma.hip; splits == 1): what k_post / k_vae_bwd do behind a split-K product,
-    // done on the tile while it is in LDS -- a hidden layer of a B = 500 step is one launch instead of two
-    RTX_EPI_POST_FWD = 3,   // x = acc + bias[n], tanh if tanh_act -> O32 (f32) and R (bf16, + ones column); zeros outside [M_real][N_real]
-    RTX_EPI_POST_BWD = 4,   // x = acc * (1 - O32^2) if tanh_act -> R (bf16); zeros outside
-    RTX_EPI_VAE_BWD = 5,    // acc = dz [.][Z]: R[.][j] = dz + beta mu / B, R[.][Z + j] = dz eps sigma / 2 + beta (e^lv - 1) / (2 B)
 };
 
 // Adam state of the tensor a fused weight-gradient launch (RTX_DW_ADAM, dw_adam.hip) updates (all [M_real][N_real] row-major float32)
@@ -75,14 +70,6 @@ struct RtxGemm {
     int M_real, N_real;
     float2* lse_part;    // RTX_EPI_BIAS_ROWS (nullable): per row, per 64-column strip (running max, sum exp) of the
     int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
-    // RTX_EPI_POST_* / RTX_EPI_VAE_BWD
-    float* O32;          // POST_FWD: post-activation f32 [M_pad][ldr] (out, nullable); POST_BWD: the saved activation (in)
-    void* R;             // bf16 [M_pad][ldr]: the next layer's input (FWD) / the previous layer's delta (BWD)
-    long ldr;
-    int tanh_act, ones_col;
-    const float *mu32, *lv32, *eps32;   // VAE_BWD: [M_real][Z]
-    int Z, training;
-    float beta, inv_batch;
 };
 
 // operand element type.  RTX_DT_F32 = 0 and RTX_DT_BF16 = 1 keep the meaning of the former `is_bf16` flag.

@@ -483,90 +483,6 @@ static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, 
     for (int i = 0; i < sets; ++i) { hipFree(p[i]); hipFree(m[i]); hipFree(v[i]); hipFree(sh[i]); }
 }
 
-// Layer epilogues of the LDS-DMA GEMM (RTX_EPI_POST_FWD with NT; RTX_EPI_POST_BWD / RTX_EPI_VAE_BWD with NN) against host double
-// loops of GEMM + k_post / k_vae_bwd arithmetic; every element of the padded outputs is checked (zeros outside the valid block,
-// the ones column of POST_FWD).
-static int run_dma_layer_case(const char* name, int epi, int cfg, int M, int N, int K, int M_real, int N_real, int tanh_act)
-{
-    const int form = (epi == RTX_EPI_POST_FWD) ? RTX_FORM_NT : RTX_FORM_NN;
-    std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
-    std::vector<double> dA((size_t)M * K), dB((size_t)N * K);
-    for (size_t i = 0; i < hA.size(); ++i) { hA[i] = f32_to_bf16(frand() * 0.2f); dA[i] = bf16_to_f32(hA[i]); }
-    for (int n = 0; n < N; ++n)
-        for (int k = 0; k < K; ++k) {
-            const bf16_t v = f32_to_bf16(frand() * 0.3f);
-            dB[(size_t)n * K + k] = bf16_to_f32(v);
-            if (form == RTX_FORM_NT) hB[(size_t)n * K + k] = v; else hB[(size_t)k * N + n] = v;
-        }
-    const int Z = N_real;                                   // VAE_BWD: the product has Z valid columns, the output 2 Z
-    const int ldr = (epi == RTX_EPI_VAE_BWD) ? rtx_pad(2 * Z) : N;
-    std::vector<float> hbias(N), hO((size_t)M * ldr), hmu((size_t)M * Z), hlv((size_t)M * Z), hep((size_t)M * Z);
-    for (auto& x : hbias) x = frand();
-    for (auto& x : hO) x = frand() * 0.9f;
-    for (auto& x : hmu) x = frand();
-    for (auto& x : hlv) x = frand() * 0.5f;
-    for (auto& x : hep) x = frand();
-    bf16_t *A, *B, *R;
-    float *bias, *O32, *mu, *lv, *ep;
-    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&R, (size_t)M * ldr * 2));
-    CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&O32, hO.size() * 4)); CK(hipMalloc(&mu, hmu.size() * 4)); CK(hipMalloc(&lv, hmu.size() * 4));
-    CK(hipMalloc(&ep, hmu.size() * 4));
-    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
-    CK(hipMemcpy(bias, hbias.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(O32, hO.data(), hO.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(mu, hmu.data(), hmu.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(lv, hlv.data(), hmu.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(ep, hep.data(), hmu.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemset(R, epi == RTX_EPI_VAE_BWD ? 0 : 0xff, (size_t)M * ldr * 2));   // (VAE_BWD leaves the pad columns [2Z, ldr) alone: zero since allocation)
-    RtxGemm g = {};
-    g.form = form; g.A = A; g.B = B; g.lda = K; g.ldb = (form == RTX_FORM_NT) ? K : N;
-    g.tile_shape = cfg; g.m_tiles = M / 128; g.n_tiles = N / 128; g.k_slices = K / 64; g.splits = 1;
-    g.bias = bias; g.M_real = M_real; g.N_real = N_real; g.O32 = O32; g.R = R; g.ldr = ldr; g.tanh_act = tanh_act; g.ones_col = 1;
-    g.mu32 = mu; g.lv32 = lv; g.eps32 = ep; g.Z = Z; g.training = 1; g.beta = 0.3f; g.inv_batch = 1.f / M_real;
-    int rc = rtx_gemm_dma_launch(g, epi, 0);
-    if (rc) { printf("[dma-layer %s] launch failed rc=%d: %s\n", name, rc, rtx_last_error_str()); return 1; }
-    CK(hipDeviceSynchronize());
-    std::vector<bf16_t> gR((size_t)M * ldr);
-    std::vector<float> gO(hO.size());
-    CK(hipMemcpy(gR.data(), R, gR.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(gO.data(), O32, gO.size() * 4, hipMemcpyDeviceToHost));
-    long bad = 0;
-    int printed = 0;
-    double max_err = 0;
-    auto chk = [&](double got, double ref, double tol, int m, int n, const char* what) {
-        const double err = fabs(got - ref);
-        max_err = std::max(max_err, err);
-        if (!(err <= tol)) { ++bad; if (printed++ < 5) printf("   %s mismatch (%d,%d): got %.6f ref %.6f\n", what, m, n, got, ref); }
-    };
-    for (int m = 0; m < M; ++m)
-        for (int n = 0; n < N; ++n) {
-            double acc = 0;
-            for (int k = 0; k < K; ++k) acc += dA[(size_t)m * K + k] * dB[(size_t)n * K + k];
-            const bool valid = m < M_real && n < N_real;
-            if (epi == RTX_EPI_POST_FWD) {
-                double y = valid ? acc + hbias[n] : 0.0;
-                if (valid && tanh_act) y = tanh(y);
-                chk(gO[(size_t)m * ldr + n], y, 2e-5, m, n, "O32");
-                const double r = (m < M_real && n == N_real) ? 1.0 : y;
-                chk(bf16_to_f32(gR[(size_t)m * ldr + n]), r, 4e-3 * std::max(1.0, fabs(r)), m, n, "R");
-            } else if (epi == RTX_EPI_POST_BWD) {
-                const double o = hO[(size_t)m * ldr + n];
-                const double y = valid ? (tanh_act ? acc * (1.0 - o * o) : acc) : 0.0;
-                chk(bf16_to_f32(gR[(size_t)m * ldr + n]), y, 4e-3 * std::max(1.0, fabs(y)) + 1e-4, m, n, "R");
-            } else if (n < Z) {
-                double dmu = 0, dlv = 0;
-                if (m < M_real) {
-                    const size_t o = (size_t)m * Z + n;
-                    dmu = acc + 0.3 * hmu[o] / M_real;
-                    dlv = 0.3 * 0.5 * (exp((double)hlv[o]) - 1.0) / M_real + acc * hep[o] * 0.5 * exp(0.5 * hlv[o]);
-                }
-                chk(bf16_to_f32(gR[(size_t)m * ldr + n]), dmu, 4e-3 * std::max(1.0, fabs(dmu)) + 1e-4, m, n, "dmu");
-                chk(bf16_to_f32(gR[(size_t)m * ldr + Z + n]), dlv, 4e-3 * std::max(1.0, fabs(dlv)) + 1e-4, m, Z + n, "dlv");
-            }
-        }
-    printf("[dma-layer %s] epi=%d cfg%d M=%d N=%d K=%d valid %dx%d tanh=%d  max_err=%.3e bad=%ld -> %s\n", name, epi, cfg, M, N, K, M_real, N_real,
-           tanh_act, max_err, bad, bad ? "FAIL" : "ok");
-    hipFree(A); hipFree(B); hipFree(R); hipFree(bias); hipFree(O32); hipFree(mu); hipFree(lv); hipFree(ep);
-    return bad != 0;
-}
-
 // Several matrices in one launch (rtx_dw_launch_group) must produce, bit for bit, what one launch per matrix produces.
 static int run_dw_group_case(int cfg)
 {
@@ -717,14 +633,6 @@ int main(int argc, char** argv)
             fails += run_dma_case("bias-oddld", form, cfg, 512, 768, 128, 1, RTX_EPI_BIAS_ROWS, 500, 703, 1);
         }
         fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
-    }
-    for (int cfg : {RTX_DMA_128x128, RTX_DMA_128x128_S2}) {
-        fails += run_dma_layer_case("post-fwd-tanh", RTX_EPI_POST_FWD, cfg, 512, 640, 256, 500, 600, 1);
-        fails += run_dma_layer_case("post-fwd-linear", RTX_EPI_POST_FWD, cfg, 128, 128, 640, 33, 127, 0);
-        fails += run_dma_layer_case("post-bwd-tanh", RTX_EPI_POST_BWD, cfg, 512, 640, 512, 500, 600, 1);
-        fails += run_dma_layer_case("post-bwd-linear", RTX_EPI_POST_BWD, cfg, 128, 256, 128, 100, 200, 0);
-        fails += run_dma_layer_case("vae-bwd", RTX_EPI_VAE_BWD, cfg, 512, 256, 640, 500, 200, 0);
-        fails += run_dma_layer_case("vae-bwd-small", RTX_EPI_VAE_BWD, cfg, 128, 128, 128, 9, 8, 0);
     }
     for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
