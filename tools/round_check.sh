@@ -8,7 +8,7 @@ if [ "$2" != "quick" ]; then
 fi
 timeout 500 build/native/test_engine perf > $OUT/engine.log 2>&1; echo "engine rc=$?"; grep -E "FAIL|TESTS" $OUT/engine.log; grep -A1 "^\[perf\]" $OUT/engine.log | grep -v "^--"
 timeout 300 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?"; tail -1 $OUT/bench.log | cut -c1-330
-timeout 200 python bench.py --opt in_on_main=0 --no-cpu-baseline --no-fp32-parity > $OUT/bench_ab.log 2>&1; tail -1 $OUT/bench_ab.log | cut -c1-330
+timeout 200 python bench.py --opt two_stream=0 --no-cpu-baseline --no-fp32-parity > $OUT/bench_ab.log 2>&1; tail -1 $OUT/bench_ab.log | cut -c1-330
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_rc
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_rc -o p -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-fp32-parity > $R/$OUT/bench_prof.log 2>&1
@@ -16,3 +16,5 @@ DB=$(find /tmp/prof_rc -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py stats $DB > $R/$OUT/kernel_stats.txt
 python $R/tools/rocprof_summary.py timeline $DB > $R/$OUT/timeline.txt
 head -16 $R/$OUT/kernel_stats.txt
+cd $R
+timeout 300 bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; echo "pmc rc=$?"
