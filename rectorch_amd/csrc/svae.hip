@@ -25,6 +25,8 @@
 #include <vector>
 
 #define SV_MAX_LAYERS RTX_MAX_LAYERS
+#define SV_GRU_KR 80   // weights of a half-row the forward recurrence keeps in registers
+#define SV_GRU_KRB 88  // weights of a row chunk the backward recurrence keeps in registers
 
 struct SvLayer {
     int in = 0, out = 0;
@@ -50,6 +52,10 @@ struct rtx_svae {
     hipStream_t side = nullptr;      // weight-gradient GEMMs of the MLPs: they overlap the single-workgroup GRU backward
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
+    size_t gru_fwd_lds = 0;          // > 0: the weight-resident forward recurrence runs, with this much dynamic LDS
+    int gru_kh = 0;                  //      K of the first half of a row
+    size_t gru_bwd_lds = 0;          // > 0: the weight-resident backward recurrence runs
+    int gru_nc = 0, gru_rp = 0;      //      its row chunks and rows per chunk
     size_t part_elems = 0;
     std::vector<void*> allocs;
 };
@@ -72,6 +78,9 @@ struct SvGemm {
 };
 
 typedef __attribute__((ext_vector_type(16))) float sv_f32x16;
+typedef __attribute__((ext_vector_type(4))) float sv_f32x4;
+// LDS read with a compile-time byte offset (the GEMM kernels' idiom: an asm read is issued where it is written)
+#define sv_lds_rd128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
 
 // 64 x 64 tile per workgroup, 4 waves, each a 32 x 32 block on the exact-float32 MFMA (v_mfma_f32_32x32x2_f32: lane l feeds
 // A[l & 31][k = l >> 5] and B[k = l >> 5][l & 31], products and sums in float32).  Round 1 computed the tile with scalar FMAs
@@ -284,6 +293,139 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ G
     }
 }
 
+// The same recurrence with ALL of W_hh resident in the compute unit.  The streaming kernel above re-reads W_hh (480 KB at
+// R = 200) through one CU's 64-B/clk L1 path on every time step: 3.3 us of its 5.2 us.  Here the 3R rows are cut in two halves
+// of K (6R half-rows; thread t owns half-row t): the first KR = 80 weights of a half-row live in the thread's REGISTERS for the
+// whole sequence, the rest of it in LDS, and the half-rows beyond the 1024th live in LDS entirely (their owners are threads
+// 0 .. 6R - 1025, which sum a second half-row per step) -- 1024 x 80 registers + 150 KB of LDS hold the 120 000 weights of
+// R = 200 exactly.  A time step reads nothing from outside the CU but its own input projection, requested one step ahead.  The two
+// halves of a row meet in LDS behind the barrier the gates need anyway.  LDS images are [chunk of 4 k][owner][4]: consecutive
+// lanes read consecutive 16 bytes.  The barriers are raw s_barriers behind an LDS-only wait: __syncthreads() also waits for the
+// six global stores of the step before (a write acknowledgement from L2 per time step).
+// Measured 3.6 us per step (5.2 streaming).  What holds it there is the register file: 80 weights + the step's working set do not
+// fit the 128 VGPRs of a 1024-thread workgroup, hipcc keeps ~17 weights in scratch and reloads them one by one every step.  Tried:
+// whole rows in registers (round 1: spills in the 200-FMA loop); 48 registers + 64 LDS + 88 streamed weights per row (4.0 us: 230
+// scalar LDS reads per wave); the thread-less half-rows spread over all threads as fragments (4.6 us: more spills); a (unit,
+// K-chunk) split with 88 / 64 registers per thread like the backward kernel's (4.2 us / 288 B of spills: the gate arithmetic's
+// working set comes on top).  The backward kernel (no transcendental gate phase) fits and runs at 2.2 us.
+__host__ __device__ inline int sv_gru_fwd_hs(int R, int Kh, int KR)
+{
+    const int CA = Kh > KR ? (Kh - KR + 3) / 4 : 0, CB = (Kh + 3) / 4;
+    const int reach = Kh + (KR + 4 * CA > 4 * CB ? KR + 4 * CA : 4 * CB);
+    return ((reach > R ? reach : R) + 7) & ~3;
+}
+
+template <int KR>
+__global__ __launch_bounds__(1024) void k_sv_gru_fwd_all(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                         const int32_t* __restrict__ seq_ptr, int T_one, int R, int Kh /* K of the first half, % 4 == 0 */,
+                                                         float* __restrict__ Hout, float* __restrict__ Hprev, float* __restrict__ Gr,
+                                                         float* __restrict__ Gz, float* __restrict__ Gn, float* __restrict__ Ghn)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h [HS] | gp [6R] | wlA [CA][1024][4] | wlB [CB][NE][4]
+    const int R3 = 3 * R, HR = 2 * R3;
+    const int NE = HR > 1024 ? HR - 1024 : 0;                     // half-rows without a thread of their own
+    const int KLA = Kh > KR ? Kh - KR : 0, CA = (KLA + 3) / 4, CB = (Kh + 3) / 4;
+    // h is read up to KR + 4 CA (or 4 CB) floats past a half's start whatever R is (the weights there are zero, but zero times
+    // an uninitialised LDS word may be NaN): the vector's area covers every such read and is zeroed once
+    const int HS = sv_gru_fwd_hs(R, Kh, KR);
+    float* h = sm;
+    float* gp = sm + HS;
+    float* wlA = gp + ((HR + 3) & ~3);
+    float* wlB = wlA + (size_t)CA * 1024 * 4;
+    const int tid = threadIdx.x;
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    GI += (size_t)t0 * R3;
+    Hout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
+    // half-row hr = half * 3R + row covers k in [half * Kh, half ? R : Kh)
+    const bool own = tid < HR;
+    const int half = own ? tid / R3 : 0, row = own ? tid % R3 : 0;
+    const int k0 = half * Kh, len = own ? (half ? R - Kh : Kh) : 0;
+    const int last = R3 * R - 1;
+    float wr[KR];
+    {
+        // unconditional loads (index clamped to the matrix), then the tail beyond the half-row is zeroed
+        const int base = row * R + k0;
+#pragma unroll
+        for (int q = 0; q < KR; ++q) {
+            const float v = Whh[min(base + q, last)];
+            wr[q] = q < len ? v : 0.f;
+        }
+        for (int q = 0; q < CA * 4; ++q) {
+            const float v = Whh[min(base + KR + q, last)];
+            wlA[((size_t)(q >> 2) * 1024 + tid) * 4 + (q & 3)] = (KR + q < len) ? v : 0.f;
+        }
+    }
+    const bool extra = tid < NE;
+    const int xrow = extra ? (1024 + tid) % R3 : 0;               // half-row 1024 + tid: always a second half (3R <= 1024)
+    const int xlen = extra ? R - Kh : 0;
+    if (extra)
+        for (int q = 0; q < CB * 4; ++q) {
+            const float v = Whh[min(xrow * R + Kh + q, last)];
+            wlB[((size_t)(q >> 2) * NE + tid) * 4 + (q & 3)] = q < xlen ? v : 0.f;
+        }
+    for (int j = tid; j < HS; j += 1024) h[j] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float4* hv0 = (const float4*)(h + k0);
+    const float4* hvx = (const float4*)(h + Kh);
+    float gir = 0.f, giz = 0.f, gin = 0.f;
+    if (tid < R && T > 0) { gir = GI[tid]; giz = GI[R + tid]; gin = GI[2 * R + tid]; }
+    for (int t = 0; t < T; ++t) {
+        float nir = 0.f, niz = 0.f, nin = 0.f;
+        if (tid < R && t + 1 < T) {
+            const float* gi = GI + (size_t)(t + 1) * R3;
+            nir = gi[tid]; niz = gi[R + tid]; nin = gi[2 * R + tid];
+        }
+        {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int q = 0; q < KR; q += 4) {
+                const float4 x = hv0[q >> 2];
+                s0 += wr[q] * x.x; s1 += wr[q + 1] * x.y; s2 += wr[q + 2] * x.z; s3 += wr[q + 3] * x.w;
+            }
+#pragma nounroll
+            for (int c = 0; c < CA; ++c) {
+                const float4 w = *(const float4*)(wlA + ((size_t)c * 1024 + tid) * 4);
+                const float4 x = hv0[(KR >> 2) + c];
+                s0 += w.x * x.x; s1 += w.y * x.y; s2 += w.z * x.z; s3 += w.w * x.w;
+            }
+            if (own) gp[tid] = (s0 + s1) + (s2 + s3);
+            if (extra) {
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+#pragma nounroll
+                for (int c = 0; c < CB; ++c) {
+                    const float4 w = *(const float4*)(wlB + ((size_t)c * NE + tid) * 4);
+                    const float4 x = hvx[c];
+                    e0 += w.x * x.x; e1 += w.y * x.y; e2 += w.z * x.z; e3 += w.w * x.w;
+                }
+                gp[1024 + tid] = (e0 + e1) + (e2 + e3);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < R) {
+            const int j = tid;
+            const float ghr = gp[j] + gp[R3 + j] + bhh[j];
+            const float ghz = gp[R + j] + gp[R3 + R + j] + bhh[R + j];
+            const float hn = gp[2 * R + j] + gp[R3 + 2 * R + j] + bhh[2 * R + j];
+            const float r = sv_sigmoid(gir + ghr);
+            const float z = sv_sigmoid(giz + ghz);
+            const float n = tanhf(gin + r * hn);
+            const float hp = h[j];
+            const float hv = (1.f - z) * n + z * hp;
+            Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
+            Hprev[(size_t)t * R + j] = hp;
+            Hout[(size_t)t * R + j] = hv;
+            h[j] = hv;
+        }
+        gir = nir; giz = niz; gin = nin;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // GRU backward through time.  dHout[t] = gradient w.r.t. the GRU output at step t.  Writes the gate pre-activation
 // gradients dGI [T][3R] (input side) and dGH [T][3R] (hidden side; differs in the n block by the factor r).
 // dh_{t-1} += W_hh^T dgh: thread (column k, row chunk c) sums W_hh[i][k] dgh[i] over its chunk of rows -- consecutive
@@ -348,6 +490,110 @@ __global__ __launch_bounds__(1024) void k_sv_gru_bwd(const float* __restrict__ d
             dh[j] = s;
         }
         __syncthreads();
+    }
+}
+
+// Backward recurrence with ALL of W_hh resident (see k_sv_gru_fwd_all): thread (row chunk c, column k) keeps the first KRB
+// weights W[c * RP + i][k] of its chunk in registers and the rest in LDS ([chunk of 4 i][thread][4]); a time step reads from
+// outside the CU only its six saved gate values, requested one step ahead.  Raw s_barriers behind LDS-only waits.
+template <int KRB>
+__global__ __launch_bounds__(1024) void k_sv_gru_bwd_all(const float* __restrict__ dHout, const float* __restrict__ Whh,
+                                                         const int32_t* __restrict__ seq_ptr, int T_one, int R, int NC, int RP /* rows per chunk, % 4 == 0 */,
+                                                         const float* __restrict__ Hprev, const float* __restrict__ Gr, const float* __restrict__ Gz,
+                                                         const float* __restrict__ Gn, const float* __restrict__ Ghn, float* __restrict__ dGI,
+                                                         float* __restrict__ dGH)
+{
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    const int R3 = 3 * R;
+    dHout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
+    dGI += (size_t)t0 * R3; dGH += (size_t)t0 * R3;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dh [Rp] | dgh [NC * RP + KRB + 4] | part [NC * R] | wl [CL][1024][4]
+    const int Rp = (R + 3) & ~3;
+    // dgh is read up to KRB + 4 CL floats past a chunk's start whatever R is (zero weights there, but zero times an uninitialised
+    // LDS word may be NaN): its area covers every such read and is zeroed once
+    const int DGS = NC * RP + KRB + 4;
+    float* dh = sm;
+    float* dgh = sm + Rp;
+    float* part = dgh + DGS;
+    float* wl = part + ((NC * R + 3) & ~3);
+    const int tid = threadIdx.x;
+    const bool own = tid < NC * R;
+    const int c = own ? tid / R : 0, k = own ? tid - c * R : 0;
+    const int i0 = c * RP;
+    const int CL = RP > KRB ? (RP - KRB + 3) / 4 : 0;
+    float wr[KRB];
+    {
+        const int last = R3 * R - 1;
+#pragma unroll
+        for (int i = 0; i < KRB; ++i) {
+            const float v = Whh[min((i0 + i) * R + k, last)];
+            wr[i] = (own && i < RP && i0 + i < R3) ? v : 0.f;
+        }
+        for (int i = 0; i < CL * 4; ++i) {
+            const float v = Whh[min((i0 + KRB + i) * R + k, last)];
+            wl[((size_t)(i >> 2) * 1024 + tid) * 4 + (i & 3)] = (own && KRB + i < RP && i0 + KRB + i < R3) ? v : 0.f;
+        }
+    }
+    for (int j = tid; j < Rp; j += 1024) dh[j] = 0.f;
+    for (int j = tid; j < DGS; j += 1024) dgh[j] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool gate = tid < R;
+    float vd = 0.f, vr = 0.f, vz = 0.f, vn = 0.f, vhn = 0.f, vhp = 0.f;
+    if (gate && T > 0) {
+        const size_t o = (size_t)(T - 1) * R + tid;
+        vd = dHout[o]; vr = Gr[o]; vz = Gz[o]; vn = Gn[o]; vhn = Ghn[o]; vhp = Hprev[o];
+    }
+    const float4* dv = (const float4*)(dgh + i0);
+    for (int t = T - 1; t >= 0; --t) {
+        float nd = 0.f, nr = 0.f, nz = 0.f, nn = 0.f, nhn = 0.f, nhp = 0.f;
+        if (gate && t > 0) {
+            const size_t o = (size_t)(t - 1) * R + tid;
+            nd = dHout[o]; nr = Gr[o]; nz = Gz[o]; nn = Gn[o]; nhn = Ghn[o]; nhp = Hprev[o];
+        }
+        if (gate) {
+            const int j = tid;
+            const float d = dh[j] + vd;
+            const float dn = d * (1.f - vz);
+            const float dzp = d * (vhp - vn) * vz * (1.f - vz);
+            const float dnp = dn * (1.f - vn * vn);
+            const float drp = dnp * vhn * vr * (1.f - vr);
+            float* gi = dGI + (size_t)t * R3;
+            float* gh = dGH + (size_t)t * R3;
+            gi[j] = drp; gi[R + j] = dzp; gi[2 * R + j] = dnp;
+            gh[j] = drp; gh[R + j] = dzp; gh[2 * R + j] = dnp * vr;
+            dgh[j] = drp; dgh[R + j] = dzp; dgh[2 * R + j] = dnp * vr;
+            dh[j] = d * vz;   // the direct path h_{t-1} -> h_t; the path through the gates is added below
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < KRB; i += 4) {
+                const float4 x = dv[i >> 2];
+                a0 += wr[i] * x.x; a1 += wr[i + 1] * x.y; a2 += wr[i + 2] * x.z; a3 += wr[i + 3] * x.w;
+            }
+#pragma nounroll
+            for (int q = 0; q < CL; ++q) {
+                const float4 w = *(const float4*)(wl + ((size_t)q * 1024 + tid) * 4);
+                const float4 x = dv[(KRB >> 2) + q];
+                a0 += w.x * x.x; a1 += w.y * x.y; a2 += w.z * x.z; a3 += w.w * x.w;
+            }
+            if (own) part[tid] = (a0 + a1) + (a2 + a3);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (gate) {
+            float sacc = dh[tid];
+            for (int q = 0; q < NC; ++q) sacc += part[q * R + tid];
+            dh[tid] = sacc;
+        }
+        vd = nd; vr = nr; vz = nz; vn = nn; vhn = nhn; vhp = nhp;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 }
 
@@ -532,10 +778,15 @@ static int sv_forward(rtx_svae* s, const int32_t* items, int T, const int32_t* s
     hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
     RTX_TRY(sv_gemm(s, st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
                     s->params[sv_tail(s, SV_T_BIH)]));
-    hipLaunchKernelGGL(k_sv_transpose, dim3((R + 63) / 64, (3 * R + 63) / 64), dim3(256), 0, st, s->params[sv_tail(s, SV_T_WHH)], 3 * R, R,
-                       s->WhhT);
-    hipLaunchKernelGGL(k_sv_gru_fwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->WhhT,
-                       s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
+    if (s->gru_fwd_lds > 0) {   // all of W_hh resident in registers + LDS
+        hipLaunchKernelGGL(k_sv_gru_fwd_all<SV_GRU_KR>, dim3(seq_ptr ? n_seq : 1), dim3(1024), s->gru_fwd_lds, st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
+                           s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->gru_kh, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
+    } else {
+        hipLaunchKernelGGL(k_sv_transpose, dim3((R + 63) / 64, (3 * R + 63) / 64), dim3(256), 0, st, s->params[sv_tail(s, SV_T_WHH)], 3 * R, R,
+                           s->WhhT);
+        hipLaunchKernelGGL(k_sv_gru_fwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * (4 * R + 4), st, s->GI, s->WhhT,
+                           s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
+    }
     const float* in = s->Hout;   // rnn_out[t] = h after step t
     long ld_in = R;
     for (int li = 0; li < s->NL; ++li) {
@@ -620,6 +871,29 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
     }
     for (auto& l : s->L) { SV_ALLOC(l.A, T * l.out); SV_ALLOC(l.D, T * l.out); }
 #undef SV_ALLOC
+    if (3 * R <= 1024) {
+        // LDS of the weight-resident forward recurrence: h [Rp + 4] | gp [6R] | wlA [CA][1024][4] | wlB [CB][NE][4]
+        const size_t Kh = (((R + 1) / 2) + 3) & ~(size_t)3, HR = 6 * R, NE = HR > 1024 ? HR - 1024 : 0;
+        const size_t CA = Kh > SV_GRU_KR ? (Kh - SV_GRU_KR + 3) / 4 : 0, CB = (Kh + 3) / 4;
+        const size_t lds = sizeof(float) * ((size_t)sv_gru_fwd_hs((int)R, (int)Kh, SV_GRU_KR) + ((HR + 3) & ~(size_t)3) + CA * 1024 * 4 + CB * NE * 4);
+        if (Kh <= R && lds <= 160 * 1024 &&
+            hipFuncSetAttribute((const void*)k_sv_gru_fwd_all<SV_GRU_KR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+            s->gru_fwd_lds = lds;
+            s->gru_kh = (int)Kh;
+        }
+    }
+    if (R <= 1024) {
+        // LDS of the weight-resident backward recurrence: dh [Rp] | dgh [NC * RP] | part [NC * R] | wl [CL][1024][4]
+        const size_t NC = std::max<size_t>(1, std::min<size_t>(16, 1024 / R)), RP = (((3 * R + NC - 1) / NC) + 3) & ~(size_t)3;
+        const size_t CL = RP > SV_GRU_KRB ? (RP - SV_GRU_KRB + 3) / 4 : 0;
+        const size_t lds = sizeof(float) * (((R + 3) & ~(size_t)3) + NC * RP + SV_GRU_KRB + 4 + ((NC * R + 3) & ~(size_t)3) + CL * 1024 * 4);
+        if (lds <= 160 * 1024 &&
+            hipFuncSetAttribute((const void*)k_sv_gru_bwd_all<SV_GRU_KRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+            s->gru_bwd_lds = lds;
+            s->gru_nc = (int)NC;
+            s->gru_rp = (int)RP;
+        }
+    }
     const size_t lds_bwd = sizeof(float) * (4 * R + 16 * R);
     if (hipFuncSetAttribute((const void*)k_sv_gru_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd) != hipSuccess) {
         rtx_set_error("svae_create: cannot reserve %zu bytes of LDS for the GRU backward kernel", lds_bwd);
@@ -743,8 +1017,12 @@ static int sv_train(rtx_svae* s, const int32_t* items, int T, const int32_t* seq
     hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, nll_scale, kl_scale, loss_out,
                        loss_accum);
     // ---- GRU backward through time, then its weight gradients over all steps at once
-    hipLaunchKernelGGL(k_sv_gru_bwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], seq_ptr, T,
-                       R, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
+    if (s->gru_bwd_lds > 0)
+        hipLaunchKernelGGL(k_sv_gru_bwd_all<SV_GRU_KRB>, dim3(seq_ptr ? n_seq : 1), dim3(1024), s->gru_bwd_lds, st, s->dH, s->params[sv_tail(s, SV_T_WHH)],
+                           seq_ptr, T, R, s->gru_nc, s->gru_rp, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
+    else
+        hipLaunchKernelGGL(k_sv_gru_bwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], seq_ptr,
+                           T, R, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
     RTX_TRY(sv_gemm(s, st, s->dGH, 1, 3 * R, s->Hprev, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));      // dW_hh = dGH^T H_prev
     RTX_TRY(sv_colsum(st, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]));
     RTX_TRY(sv_gemm(s, st, s->dGI, 1, 3 * R, s->X, 1, E, s->grads[sv_tail(s, SV_T_WIH)], E, 3 * R, E, T));          // dW_ih = dGI^T X
