@@ -16,7 +16,8 @@
 //     before the loop, and the weight gradients are two GEMMs over all t after it;
 //   * Adam over the 5 + 2(n_enc + n_dec) tensors is the one fused multi-tensor kernel of the Mult-VAE path (k_adam).
 // rtx_svae_train_pack (round 2) takes several users per optimizer step: concatenated rows, one recurrence workgroup per user
-// side by side, [sum T, .] products -- 440 -> 5 400+ users/s at the ml-1m shape with packs of 32 (SVAE_Sampler(pack=N)).
+// side by side, [sum T, .] products on the float32 MFMA, the recurrences with W_hh resident in registers + LDS -- 440 -> 806 users/s
+// per user, 21 600 users/s with packs of 128 at the ml-1m shape (SVAE_Sampler(pack=N)).
 #include "../../include/rectorch_hip.h"
 #include "rtx_kernels.h"
 

@@ -77,16 +77,18 @@ def main():
            "pack": a.pack, "users_per_s": users_t / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / users_t * 1e3,
            "ms_per_optimizer_step": dt / (n - w) * 1e3, "mean_len": steps_t / users_t, "users_timed": users_t,
            "optimizer_steps_timed": n - w, "dtype": "f32"}
-    # the recurrences (k_sv_gru_fwd / k_sv_gru_bwd: one persistent workgroup per sequence) re-read W_hh (3R x R floats) from L2
-    # on every time step: their roof is one compute unit's L2 path (64 B/clk at 2.4 GHz = 154 GB/s) per sequence in flight.
-    # `achieved` prices the W_hh bytes of the LONGEST sequence of every step (the recurrences of a pack run side by side) against
-    # the WHOLE step time -- a lower bound for the recurrence kernels themselves, since the step also holds the GEMMs and Adam.
-    whh_bytes = 3 * 200 * 200 * 4
-    ach = 2.0 * whh_bytes * longest / dt / 1e9
-    out["roofline"] = {"kernel": "k_sv_gru_fwd + k_sv_gru_bwd (one persistent workgroup per sequence)", "bound": "l2_to_cu_path",
-                       "achieved": ach, "peak": 153.6, "unit": "GB/s per sequence in flight", "frac": ach / 153.6, "traffic": None,
-                       "algorithmic_bytes_per_time_step": 2 * whh_bytes,
-                       "note": "lower bound (whole-step time); per-kernel times in profiles/r2_svae_kernel_stats.txt"}
+    # the recurrences (k_sv_gru_fwd_all / k_sv_gru_bwd_all: one persistent workgroup per sequence) keep W_hh resident -- 80 / 88
+    # weights per thread in registers, the rest in LDS -- so what a time step moves is the LDS-resident part of the weights
+    # (150 KB forward + 128 KB backward at R = 200) through one CU's LDS port (128 B/clk at 2.4 GHz = 307 GB/s per sequence in
+    # flight).  `achieved` prices those bytes for the LONGEST sequence of every step (the recurrences of a pack run side by side)
+    # against the WHOLE step time -- a lower bound for the recurrence kernels themselves, since the step also holds the GEMMs and
+    # Adam; the kernels' own 3.6 + 2.2 us per time step are in profiles/r2_svae_pack64_kernel_stats.txt.
+    lds_bytes = (150 + 128) * 1024
+    ach = lds_bytes * longest / dt / 1e9
+    out["roofline"] = {"kernel": "k_sv_gru_fwd_all + k_sv_gru_bwd_all (weights resident in registers + LDS, one workgroup per sequence)",
+                       "bound": "lds_port_of_one_cu", "achieved": ach, "peak": 307.2, "unit": "GB/s per sequence in flight", "frac": ach / 307.2,
+                       "traffic": None, "algorithmic_bytes_per_time_step": lds_bytes,
+                       "note": "lower bound (whole-step time); the recurrences are latency-bound: two / three barriers and an LDS round trip per step"}
     if a.cpu_seconds > 0:
         from oracle.svae_oracle import SvaeOracle
         orc = SvaeOracle(sd, n_enc=2, n_dec=2, beta=0.2, anneal_steps=20000)
