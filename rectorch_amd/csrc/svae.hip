@@ -301,8 +301,7 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd(const float* __restrict__ G
 // 0 .. 6R - 1025, which sum a second half-row per step) -- 1024 x 80 registers + 150 KB of LDS hold the 120 000 weights of
 // R = 200 exactly.  A time step reads nothing from outside the CU but its own input projection, requested one step ahead.  The two
 // halves of a row meet in LDS behind the barrier the gates need anyway.  LDS images are [chunk of 4 k][owner][4]: consecutive
-// lanes read consecutive 16 bytes.  The barriers are raw s_barriers behind an LDS-only wait: __syncthreads() also waits for the
-// six global stores of the step before (a write acknowledgement from L2 per time step).
+// lanes read consecutive 16 bytes.  The barriers are raw s_barriers behind an LDS-only wait.
 // Measured 3.6 us per step (5.2 streaming).  What holds it there is the register file: 80 weights + the step's working set do not
 // fit the 128 VGPRs of a 1024-thread workgroup, hipcc keeps ~17 weights in scratch and reloads them one by one every step.  Tried:
 // whole rows in registers (round 1: spills in the 200-FMA loop); 48 registers + 64 LDS + 88 streamed weights per row (4.0 us: 230
