@@ -85,6 +85,10 @@ typedef struct {
 /* Mult-DAE under data parallelism: the regulariser lam * sum ||W||_2 is the same on every rank, so only ONE rank may add
  * it to the loss it reports before the ranks' losses are summed; the others set this bit (the update itself is unchanged) */
 #define RTX_STEP_NO_REG_IN_LOSS 2
+/* rtx_engine_loss_grads in bf16 numerics with rtx_engine_bind_grads16 done: every gradient is written ONLY as the bf16 image the
+ * data-parallel exchange sends (the float32 gradient buffers are not touched, no cast pass follows); the optimizer then reads
+ * the reduced bf16 gradients (rtx_engine_apply_adam_layers / _rows with their grads_bf16 arguments) */
+#define RTX_STEP_GRADS_BF16 8
 
 /* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
  * have been enqueued; layers complete in reverse order (last decoder layer first).  A data-parallel
@@ -116,6 +120,9 @@ int rtx_engine_bind(rtx_engine* e, float* const* params, float* const* grads, fl
                     float* const* exp_avg_sq);
 /* refresh the compute-precision copies after the master parameters were changed from outside
  * (load_state_dict, reference models.py:513) */
+/* bf16 gradient images, one per tensor in parameter order, same shapes as the float32 gradients (weights [out][in] row-major);
+ * NULL unbinds.  Used by steps flagged RTX_STEP_GRADS_BF16. */
+int rtx_engine_bind_grads16(rtx_engine* e, uint16_t* const* grads_bf16);
 int rtx_engine_sync_shadows(rtx_engine* e, void* stream);
 
 /* VAE_net.forward / AE_net.forward (nets.py:322-339, 82-91) and VAE.predict / AETrainer.predict

@@ -17,6 +17,7 @@ RTX_VAE, RTX_DAE = 0, 1
 RTX_FP32, RTX_BF16 = 0, 1
 RTX_STEP_KEEP_GRADS = 1
 RTX_STEP_NO_REG_IN_LOSS = 2
+RTX_STEP_GRADS_BF16 = 8
 NUMERICS = {"fp32": RTX_FP32, "bf16": RTX_BF16}
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "rtx_engine_encode": (C.c_int, [_P, C.POINTER(Batch), C.c_int32, C.POINTER(Step), _P, _P, _P]),
     "rtx_engine_decode": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rtx_engine_loss_grads": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, LAYER_CB, _P, _P]),
+    "rtx_engine_bind_grads16": (C.c_int, [_P, _P]),
     "rtx_engine_apply_adam": (C.c_int, [_P, C.POINTER(Step), _P]),
     "rtx_engine_apply_adam_layers": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, _P, _P]),
     "rtx_engine_apply_adam_rows": (C.c_int, [_P, C.POINTER(Step), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),

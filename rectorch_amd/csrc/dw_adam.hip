@@ -73,6 +73,7 @@ __device__ __forceinline__ void dw_finish4(const RtxDw& p, int row, int col, con
     if (p.N_real >= col && p.N_real < col + 4) {
         const float gb = g4[p.N_real - col];
         if (p.gbias) p.gbias[row] = gb;
+        if (p.gbias16) p.gbias16[row] = f32_to_bf16(gb);
         if constexpr (EPI == RTX_DW_ADAM) {
             if (p.bias_p) {   // the layer's bias takes its Adam step here too: no separate small-tensor launch
                 const RtxAdamEpi& A = p.adam;

@@ -74,6 +74,7 @@ struct rtx_engine {
     float *tsum = nullptr, *lse = nullptr, *row_loss = nullptr, *sumsq = nullptr, *scratch_loss = nullptr;
     // bound tensors
     std::vector<float*> params, grads, m, v;
+    std::vector<uint16_t*> grads16;   // optional bf16 gradient images (rtx_engine_bind_grads16; RTX_STEP_GRADS_BF16)
     bool bound = false, can_train = false, shadows_valid = false;
     TempCsr tmp_in, tmp_tg;
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
@@ -665,6 +666,19 @@ int rtx_engine_bind(rtx_engine* e, float* const* params, float* const* grads, fl
     return RTX_OK;
 }
 
+int rtx_engine_bind_grads16(rtx_engine* e, uint16_t* const* grads_bf16)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    if (!grads_bf16) { e->grads16.clear(); return RTX_OK; }
+    const int n = 2 * e->NL;
+    for (int t = 0; t < n; ++t) {
+        RTX_CHECK(grads_bf16[t], RTX_EINVAL, "bind_grads16: tensor %d is NULL", t);
+        RTX_CHECK(((uintptr_t)grads_bf16[t] & 7) == 0, RTX_EINVAL, "bind_grads16: tensor %d is not 8-byte aligned", t);
+    }
+    e->grads16.assign(grads_bf16, grads_bf16 + n);
+    return RTX_OK;
+}
+
 int rtx_engine_sync_shadows(rtx_engine* e, void* stream)
 {
     RTX_TRY(check_ready(e, false));
@@ -826,6 +840,10 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
             d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
             d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
+        } else if ((step->flags & RTX_STEP_GRADS_BF16) && !e->grads16.empty()) {
+            // data-parallel bf16 exchange: the gradient leaves the kernel as the bf16 image the all-reduce sends (no float32
+            // store, no cast pass)
+            d.g16 = (bf16_t*)e->grads16[2 * li]; d.gbias16 = (bf16_t*)e->grads16[2 * li + 1];
         } else {
             d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1];
         }

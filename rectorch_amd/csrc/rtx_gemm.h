@@ -96,6 +96,7 @@ struct RtxDw {
     float* gW;           // RTX_DW_GRAD: float32 [M_real][N_real] (nullable)
     bf16_t* g16;         // RTX_DW_GRAD: bf16 image of the same (nullable): staged for a bf16 gradient exchange
     float* gbias;        // [M_real] = column N_real of the product (nullable)
+    bf16_t* gbias16;     // RTX_DW_GRAD: the same as bf16 (nullable)
     RtxAdamEpi adam;     // RTX_DW_ADAM
     float* bias_p;       // RTX_DW_ADAM (nullable): the layer's bias [M_real] and its Adam moments, updated in the same launch
     float* bias_m;       //   with the scalars of `adam`

@@ -237,6 +237,18 @@ class Engine:
         check(lib().rtx_engine_loss_grads(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           cb, None, stream_ptr()))
 
+    def bind_grads16(self, ptrs):
+        """device addresses of the bf16 gradient images, one per tensor (None unbinds): steps flagged RTX_STEP_GRADS_BF16 write
+        their gradients there instead of into the float32 buffers"""
+        if ptrs is None:
+            check(lib().rtx_engine_bind_grads16(self.handle, None))
+            self._g16_key = None
+            return
+        key = tuple(int(p) for p in ptrs)
+        if getattr(self, "_g16_key", None) != key:
+            check(lib().rtx_engine_bind_grads16(self.handle, (C.c_void_p * len(key))(*key)))
+            self._g16_key = key
+
     def apply_adam(self, step):
         check(lib().rtx_engine_apply_adam(self.handle, C.byref(step), stream_ptr()))
 

@@ -280,6 +280,13 @@ class AETrainer(TorchNNTrainer):
         st.adam_step += 1
         from .nets import draw_seed
         red = st.reducer
+        # data parallel, bf16 numerics and bf16 exchange with the optimizer behind each bucket: the weight-gradient kernels write
+        # the bf16 images the all-reduce sends directly (no float32 gradient store, no cast pass); p.grad is not filled then
+        direct16 = (red is not None and self.numerics == "bf16" and red.flat16 is not None and red.on_device and
+                    getattr(red, "bucket_adam", False) and getattr(red, "allow_direct16", True) and not self.keep_grads)
+        if red is not None:
+            red.direct16 = direct16
+            eng.bind_grads16(red.grads16_ptrs() if direct16 else None)
         inj = self._rtx.inject or (None, None)     # (keep-mask uint8 [B, n_items], eps [B, latent]) for parity tests
         step = eng._step(seed=draw_seed(), offset=0 if red is None else red.rank, mask=inj[0], noise=inj[1],
                          beta=float(beta), lam=float(lam),
@@ -287,6 +294,7 @@ class AETrainer(TorchNNTrainer):
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
                          eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
                          flags=(_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0) |
+                               (_lib.RTX_STEP_GRADS_BF16 if direct16 else 0) |
                                # data parallel: the (rank-independent) DAE regulariser enters the summed loss once
                                (_lib.RTX_STEP_NO_REG_IN_LOSS if red is not None and red.rank != 0 else 0))
         loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]

@@ -69,6 +69,7 @@ class GradAllReducer:
         self.side = torch.cuda.Stream() if self.on_device else None     # RCCL
         self.opt = torch.cuda.Stream() if self.on_device else None      # per-bucket Adam
         self.comm_dtype = comm_dtype
+        self.direct16 = False     # set per step by the trainer when the engine writes the bf16 gradient images itself
         self.flat16 = torch.zeros(flat.numel(), dtype=torch.bfloat16, device=flat.device) \
             if comm_dtype == torch.bfloat16 else None
         self.tensor_offsets = None if tensor_offsets is None else list(tensor_offsets)
@@ -141,7 +142,9 @@ class GradAllReducer:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             return
         v16 = self.flat16[rng[0]:rng[1]]
-        if self.on_device:
+        if self.direct16:
+            pass                  # the engine wrote the bf16 images itself (RTX_STEP_GRADS_BF16): nothing to cast
+        elif self.on_device:
             from .engine import cast_f32_bf16
             cast_f32_bf16(view, v16)
         else:
@@ -184,6 +187,8 @@ class GradAllReducer:
             dist.all_reduce(self.flat[breg[0]:breg[1]], op=dist.ReduceOp.SUM, group=self.group)
             return
         for a, b in (wreg, breg):
+            if self.direct16:
+                break             # the engine wrote the bf16 images itself (RTX_STEP_GRADS_BF16)
             if self.on_device:
                 from .engine import cast_f32_bf16
                 cast_f32_bf16(self.flat[a:b], self.flat16[a:b])

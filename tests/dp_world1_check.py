@@ -23,15 +23,16 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
-def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False):
+def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False, numerics="fp32", direct16=True):
     enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
     beta, anneal, p, lr = [float(v) for v in g["meta"]]
     net = MultiVAE_net(dec, enc, dropout=p)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd_from(g, "sd0__").items()})
     net.to("cuda")
-    model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
+    model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics=numerics)
     if comm_dtype is not None:
         red = parallel.attach(model, min_bucket_bytes=min_bucket, comm_dtype=comm_dtype, bucket_adam=bucket_adam, sharded=sharded)
+        red.allow_direct16 = direct16
         assert len(red.buckets()) >= 2 and bool(red.shard_layers) == sharded
     losses = []
     for t in range(g["xs"].shape[0]):
@@ -67,6 +68,18 @@ def main():
         for k, a, b in zip(keys, params, ref_params):
             # Adam normalises the step: a gradient rounded to 8 bits moves a parameter by at most ~lr per step
             assert float(np.max(np.abs(a - b))) < 3 * 1e-3 * 0.02 + 1e-6, (bucket_adam, k, float(np.max(np.abs(a - b))))
+    # bf16 numerics (what bench.py --gpus N runs): the weight-gradient kernels write the bf16 images of the exchange directly
+    # (RTX_STEP_GRADS_BF16) -- bit-identical to storing float32 gradients and casting them, replicated and sharded optimizer;
+    # and close to the single-GPU bf16 step (whose Adam sees the unrounded gradient)
+    one_losses, one_params = run(g, None, False, 0, numerics="bf16")
+    for sharded in (False, True):
+        l_cast, p_cast = run(g, torch.bfloat16, True, 256, sharded=sharded, numerics="bf16", direct16=False)
+        l_dir, p_dir = run(g, torch.bfloat16, True, 256, sharded=sharded, numerics="bf16", direct16=True)
+        assert l_cast == l_dir, (sharded, l_cast, l_dir)
+        for k, a, b in zip(keys, p_cast, p_dir):
+            assert np.array_equal(a, b), ("direct bf16 gradients must equal cast float32 gradients", sharded, k)
+        for k, a, b in zip(keys, p_dir, one_params):
+            assert float(np.max(np.abs(a - b))) < 3 * 1e-3 * 0.02 + 1e-6, (sharded, k, float(np.max(np.abs(a - b))))
     dist.destroy_process_group()
     print("DP_WORLD1_OK")
 
