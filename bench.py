@@ -207,7 +207,11 @@ def main():
         Xin, Xtg = X, None
     net, model = build_model(args, I, H, L, args.numerics)
     if world == 1 and args.force_dp:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+        # a file store: under torch.distributed.run a tcp:// init would wait for the elastic agent's store
+        # (TORCHELASTIC_USE_AGENT_STORE makes every rank a client) on a port nobody serves
+        import tempfile
+        store = os.path.join(tempfile.mkdtemp(prefix="rtx_dp1_"), "store")
+        dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1)
     rccl_ranks = None
     dp = world > 1 or args.force_dp
     if dp:
