@@ -268,8 +268,10 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * Adam inside the weight-gradient kernels), "two_stream" (0/1: the two big ones on a second stream beside the
  * data-gradient chain), "side_low_prio" (0/1: that stream at the lowest priority; before the first step), "lse_fuse" (0/1:
  * log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the big NT contractions on the register-staged GEMM
- * instead of the LDS-DMA one), "dw_cfg" (0..3: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic).  Replaces round 1's
- * RTX_* environment switches. */
+ * instead of the LDS-DMA one), "dw_cfg" (0..3: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic), "in_on_main" (0/1: the encoder matrix's weight kernel on
+ * the caller's stream behind the chain), "sparse_in" (0/1, bf16: the first encoder layer as a sparse product over the batch's
+ * stored entries -- spmm_in.hip -- instead of the dense split-K GEMM; needs a CSR batch and n_items + cond_dim <= 20 480).
+ * Replaces round 1's RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */

@@ -77,6 +77,10 @@ struct rtx_engine {
     std::vector<uint16_t*> grads16;   // optional bf16 gradient images (rtx_engine_bind_grads16; RTX_STEP_GRADS_BF16)
     bool bound = false, can_train = false, shadows_valid = false;
     TempCsr tmp_in, tmp_tg;
+    // chunk stream of the batch's stored entries for the sparse first layer (spmm_in.hip)
+    uint32_t* in_ent = nullptr;
+    int32_t *in_desc = nullptr, *in_wsplit = nullptr;
+    int64_t in_cap_chunks = 0;
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
@@ -88,6 +92,7 @@ struct rtx_engine {
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
+    int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -314,6 +319,7 @@ static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxC
                   e->Iin);
         RTX_CHECK(b->row_ids || b->batch <= b->csr->n_rows, RTX_EINVAL, "batch larger than the matrix");
         in->indptr = b->csr->indptr; in->indices = b->csr->indices; in->values = b->csr->values; in->row_ids = b->row_ids;
+        in->max_row_len = b->csr->max_row_len;
     } else {
         RTX_CHECK(b->x_dense, RTX_EINVAL, "batch has neither csr nor x_dense");
         RTX_TRY(dense_to_view(e, e->tmp_in, b->x_dense, b->batch, e->Iin, in, st));
@@ -336,13 +342,42 @@ static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxC
 // ---- forward ---------------------------------------------------------------------------------------
 // Runs layers [l0, l1).  If l0 == 0 the gather kernel builds A[0] from `in`.  The last network layer
 // writes logits to `logits` (ld = ldlog); with want_lse it also leaves the log-sum-exp partials (training).
+// The first layer as a sparse product (spmm_in.hip): bf16 numerics, a batch that names rows of a resident CSR matrix (its
+// longest row bounds the chunk stream), a first layer followed by an ordinary activation, weight rows that fit the LDS.
+static bool sparse_in_ok(const rtx_engine* e, const RtxCsrView* in, int Bp, int64_t* chunks)
+{
+    if (!e->bf16 || !e->opt_sparse_in || e->NL < 2 || (e->vae && e->cfg.n_enc == 1)) return false;
+    if (in->max_row_len <= 0 || e->Iin > 65536 || rtx_spmm_in_lds_bytes(e->Iin) > 160 * 1024) return false;
+    *chunks = (int64_t)Bp * std::max(1, (in->max_row_len + 63) / 64) + 64;   // + the read-ahead of the last wave
+    return *chunks * 256 <= ((int64_t)512 << 20);
+}
+static int ensure_in_chunks(rtx_engine* e, int64_t chunks, hipStream_t st)
+{
+    if (chunks <= e->in_cap_chunks) return RTX_OK;
+    if (e->in_ent) {   // a matrix with longer rows than the last one: rare, so simply wait and regrow
+        RTX_HIP(hipStreamSynchronize(st));
+        for (void* p : {(void*)e->in_ent, (void*)e->in_desc}) {
+            e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), p));
+            (void)hipFree(p);
+        }
+        e->in_ent = nullptr; e->in_desc = nullptr;
+    }
+    RTX_TRY(dev_alloc(e, (void**)&e->in_ent, (size_t)chunks * 256));
+    RTX_TRY(dev_alloc(e, (void**)&e->in_desc, (size_t)(chunks + 128) * sizeof(int32_t)));
+    if (!e->in_wsplit) RTX_TRY(dev_alloc(e, (void**)&e->in_wsplit, (RTX_SPMM_WAVES + 1) * sizeof(int32_t)));
+    e->in_cap_chunks = chunks;
+    return RTX_OK;
+}
+
 static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg, int B, int training, const rtx_step* step,
                        int want_lse, int l0, int l1, float* logits, long ldlog, float* mu_out, float* lv_out, hipStream_t st)
 {
     const int Bp = rtx_pad_batch(B);
     static const rtx_step zero_step = {};
     if (!step) step = &zero_step;
-    if (l0 == 0) {
+    int64_t in_chunks = 0;
+    const bool sparse_in = l0 == 0 && l1 > 1 && sparse_in_ok(e, in, Bp, &in_chunks);
+    if (l0 == 0 && !sparse_in) {
         Layer& l = e->L[0];
         RtxGatherArgs a = {};
         a.in = *in; a.target = *tg;
@@ -378,6 +413,30 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
                 RTX_TRY(rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_BIAS_ROWS, st));
             }
             break;
+        }
+        if (li == 0 && sparse_in) {
+            // the batch's stored entries as a chunk stream; in a training step the same launch also leaves what the gather
+            // kernel would (the dense image the weight-gradient kernel reads, the target row sums)
+            RTX_TRY(ensure_in_chunks(e, in_chunks, st));
+            RtxInChunksArgs c = {};
+            c.in = *in; c.B = B; c.I = e->I; c.Iin = e->Iin;
+            c.training = training; c.dropout_p = e->cfg.dropout_p;
+            c.mask = step->dropout_mask; c.seed = step->seed; c.offset = step->offset;
+            c.ent = e->in_ent; c.desc = e->in_desc; c.wsplit = e->in_wsplit;
+            if (training) { c.target = *tg; c.tsum = e->tsum; c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
+            {
+                TIMED("in_chunks");
+                RTX_TRY(rtx_launch_in_chunks(c, st));
+            }
+            RtxSpmmInArgs a = {};
+            a.ent = e->in_ent; a.desc = e->in_desc; a.wsplit = e->in_wsplit;
+            a.B = B; a.Bp = Bp;
+            a.W = (const bf16_t*)l.Wsh; a.ldw = l.inp; a.Kin = e->Iin;
+            a.bias = e->params[2 * li + 1]; a.N_real = l.out; a.Np = l.outp; a.tanh_act = l.tanh_act;
+            a.O32 = l.O32; a.R = (bf16_t*)e->L[li + 1].A; a.ones_col = 1;
+            TIMED("spmm_in");
+            RTX_TRY(rtx_launch_spmm_in(a, st));
+            continue;
         }
         int splits = 1;
         {
@@ -509,6 +568,9 @@ int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, cons
     RTX_CHECK(nnz == 0 || indices_host, RTX_EINVAL, "csr_upload: indices is NULL");
     rtx_csr* m = new rtx_csr();
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
+    int64_t longest = 0;
+    for (int64_t r = 0; r < n_rows; ++r) longest = std::max<int64_t>(longest, indptr_host[r + 1] - indptr_host[r]);
+    m->max_row_len = (int32_t)std::min<int64_t>(longest, INT32_MAX);
     int rc = dev_alloc(nullptr, (void**)&m->indptr, sizeof(int64_t) * (n_rows + 1), false);
     if (!rc) rc = dev_alloc(nullptr, (void**)&m->indices, sizeof(int32_t) * (nnz > 0 ? nnz : 1), false);
     if (!rc && values_host) rc = dev_alloc(nullptr, (void**)&m->values, sizeof(float) * (nnz > 0 ? nnz : 1), false);
@@ -1090,6 +1152,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
+    else if (k == "sparse_in") e->opt_sparse_in = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;

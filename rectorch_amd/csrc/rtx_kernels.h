@@ -10,6 +10,7 @@ struct RtxCsrView {
     const int32_t* indices;
     const float* values;
     const int32_t* row_ids;
+    int32_t max_row_len;   // longest row of the matrix the view comes from (0 = unknown: a densified batch)
 };
 
 // the opaque rtx_csr of include/rectorch_hip.h: a scipy-style CSR matrix resident in HBM
@@ -19,6 +20,7 @@ struct rtx_csr {
     float* values = nullptr;  // nullptr -> all ones
     int64_t n_rows = 0, nnz = 0;
     int32_t n_cols = 0;
+    int32_t max_row_len = 0;
 };
 
 // ---- K1: sparse user rows -> dense normalised (+dropout) input ---------------------------------------
@@ -38,6 +40,46 @@ struct RtxGatherArgs {
     uint64_t seed, offset;
 };
 int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream);
+
+// ---- first encoder layer as a sparse product (spmm_in.hip; bf16 numerics) -----------------------------------------
+// k_in_chunks: the batch's stored entries, normalised / dropped out exactly as k_gather does, as ONE stream of 64-entry
+// chunks (item | bf16 value << 16), users back to back; desc[chunk] = user (desc[n_chunks] = -1); wsplit[0..16] = a split
+// of the stream at user boundaries.  Capacity: sum_b max(1, ceil(len_b / 64)) chunks + 64 chunks of read-ahead slack.
+#define RTX_SPMM_WAVES 16
+struct RtxInChunksArgs {
+    RtxCsrView in;
+    int B, I, Iin;
+    int training;
+    float dropout_p;
+    const uint8_t* mask;
+    uint64_t seed, offset;
+    uint32_t* ent;
+    int32_t* desc;
+    int32_t* wsplit;
+    // optional: what k_gather<bf16> writes, from the same pass over the entries (training step)
+    RtxCsrView target;   // rows whose sums go to tsum (read only if tsum != NULL)
+    float* tsum;         // [Bp] nullable
+    bf16_t* X;           // [Bp][ldx] nullable: dense image, rows >= B zero, column Iin = 1 for b < B
+    int ldx, Bp;
+};
+int rtx_launch_in_chunks(const RtxInChunksArgs& a, hipStream_t stream);
+// k_spmm_in: O32 / R [Bp][Np] = act(chunks x W^T + bias) with the padding and ones-column conventions of k_post (forward)
+struct RtxSpmmInArgs {
+    const uint32_t* ent;
+    const int32_t* desc;
+    const int32_t* wsplit;
+    int B, Bp;
+    const bf16_t* W;   // [>= N_real][ldw] compute copy of the first layer's weight matrix
+    int ldw, Kin;      // Kin = input columns an entry may name (n_items + cond_dim)
+    const float* bias;
+    int N_real, Np, tanh_act;
+    float* O32;        // nullable
+    bf16_t* R;         // nullable
+    int ones_col;
+    uint64_t* stamps;  // nullable measurement hook: [workgroups][2 waves][4] shader-clock stamps (start, staged, summed, end)
+};
+size_t rtx_spmm_in_lds_bytes(int Kin);   // <= 160 KB or the launch is refused
+int rtx_launch_spmm_in(const RtxSpmmInArgs& a, hipStream_t stream);
 
 // DataSampler densify: rows -> float32 [B][I] (ld = I), optional second matrix
 int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipStream_t stream);

@@ -172,7 +172,7 @@ static std::vector<float> d2h(const float* d, size_t n)
 }
 
 static int g_fail = 0;
-static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
+static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1, g_opt_sparse = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
 static void apply_options(rtx_engine* eng)
 {
     rtx_engine_set_option(eng, "fuse_adam", g_opt_fuse);
@@ -182,6 +182,7 @@ static void apply_options(rtx_engine* eng)
     rtx_engine_set_option(eng, "nt_regstage", g_opt_ntreg);
     rtx_engine_set_option(eng, "side_low_prio", g_opt_lowprio);
     rtx_engine_set_option(eng, "in_on_main", g_opt_inmain);
+    rtx_engine_set_option(eng, "sparse_in", g_opt_sparse);
 }
 static void check(const char* what, double err, double tol)
 {
@@ -428,7 +429,7 @@ static void philox_case()
 
 static void perf_case(int numerics, int B, int steps, int splitk)
 {
-    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d nt_regstage=%d dw_cfg=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_ntreg, g_opt_dw_cfg);
+    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d nt_regstage=%d dw_cfg=%d sparse_in=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_ntreg, g_opt_dw_cfg, g_opt_sparse);
     Net net = make_net({20108, 600, 200}, {200, 600, 20108}, ORC_VAE, 0.5f, 0.1f);
     const int I = 20108, U = 4096;
     Csr tr;
@@ -499,8 +500,10 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s CUs=%d arch=%s | abi v%d\n", prop.name, prop.multiProcessorCount, prop.gcnArchName, rtx_abi_version());
+    const bool perf_only = argc > 1 && !strcmp(argv[1], "perfonly");   // the perf table without the (CPU-oracle-bound) parity cases
     // parity cases run rtx_engine_train_step (step 3): in bf16 numerics that is the fused dW + Adam path (the default)
-    for (int numerics = 0; numerics < 2; ++numerics) {
+    const bool quick = argc > 1 && !strcmp(argv[1], "quick");   // bf16 numerics only, without the widest case and the variants
+    for (int numerics = quick ? 1 : 0; numerics < 2 && !perf_only; ++numerics) {
         parity_case("small-vae", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), numerics, 5, 9, 0.2f, false, false, false, 0.2f, 0.f);
         parity_case("small-vae-te-weighted", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), numerics, 6, 9, 0.2f, true, true, false, 1.0f, 0.f);
         parity_case("deep-odd-vae", make_net({77, 21, 13, 5}, {5, 9, 77}, ORC_VAE, 0.3f, 1.0f), numerics, 7, 11, 0.15f, true, false, false, 0.3f, 0.f);
@@ -509,10 +512,10 @@ int main(int argc, char** argv)
         parity_case("dense-api-vae-te", make_net({130, 40, 12}, {12, 40, 130}, ORC_VAE, 0.5f, 0.5f), numerics, 33, 40, 0.1f, true, true, true, 0.5f, 0.f);
         parity_case("mid-vae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_VAE, 0.5f, 0.3f), numerics, 300, 400, 0.02f, false, false, false, 0.2f, 0.f);
         // wide enough that the engine picks the 8-wave tiles (256x128 / 128x256) and split-K in multiples of 8
-        parity_case("wide-vae", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), numerics, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+        if (!quick) parity_case("wide-vae", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), numerics, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
     }
-    philox_case();
-    {   // the two-kernel train_step (gradients stored, one multi-tensor Adam launch) and the other tile configurations of the
+    if (!perf_only) philox_case();
+    if (!perf_only && !quick) {   // the two-kernel train_step (gradients stored, one multi-tensor Adam launch) and the other tile configurations of the
         // weight-gradient kernel, on a shape with big layers, against the same oracle
         g_opt_fuse = 0;
         parity_case("wide-vae-unfused-step", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
@@ -537,7 +540,17 @@ int main(int argc, char** argv)
         g_opt_ntreg = 0;     // every NT contraction on the LDS-DMA kernel (log-sum-exp partials from its epilogue)
         parity_case("wide-vae-nt-dma", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
         g_opt_ntreg = 1;
+        g_opt_sparse = 0;    // the first layer as the dense split-K product (what float32 numerics and densified batches use)
+        parity_case("wide-vae-dense-in", make_net({8100, 600, 200}, {200, 600, 8100}, ORC_VAE, 0.5f, 0.3f), RTX_BF16, 512, 600, 0.01f, false, false, false, 0.2f, 0.f);
+        parity_case("mid-dae-dense-in", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
+        g_opt_sparse = 1;
         parity_case("mid-dae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
+    }
+    if (perf_only || quick) {
+        const int B = argc > 2 ? atoi(argv[2]) : 500;
+        perf_case(RTX_BF16, B, 50, 0);
+        g_opt_sparse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_sparse = 1;
+        perf_case(RTX_BF16, B, 50, 0);
     }
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
@@ -545,6 +558,7 @@ int main(int argc, char** argv)
         perf_case(RTX_BF16, B, 50, 0);                                  // shipped configuration again (box drift)
         g_opt_inmain = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_inmain = 1;   // encoder matrix's kernel on the side stream
         g_opt_two = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_two = 1;          // one stream
+        g_opt_sparse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_sparse = 1;    // dense first layer
         if (argc > 3) {
             g_opt_fuse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_fuse = 1;
             perf_case(RTX_FP32, B, 20, 0);
