@@ -79,8 +79,13 @@ struct rtx_engine {
     TempCsr tmp_in, tmp_tg;
     // chunk stream of the batch's stored entries for the sparse first layer (spmm_in.hip)
     uint32_t* in_ent = nullptr;
-    int32_t *in_desc = nullptr, *in_wsplit = nullptr;
+    int32_t *in_desc = nullptr, *in_wsplit = nullptr, *in_ustart = nullptr;
     int64_t in_cap_chunks = 0;
+    int opt_defer_image = 1;    // fused two-stream step: the dense image of the batch rows (only the encoder matrix's weight kernel reads it)
+                                //   is built from the chunk stream on the side stream, behind the event that stream waits for anyway
+    bool in_defer = false;      // set by the step around run_forward: leave the dense image to the side stream ...
+    bool in_image_pending = false;   // ... set by run_forward when it did
+    hipEvent_t ev_img = nullptr;
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
@@ -364,7 +369,10 @@ static int ensure_in_chunks(rtx_engine* e, int64_t chunks, hipStream_t st)
     }
     RTX_TRY(dev_alloc(e, (void**)&e->in_ent, (size_t)chunks * 256));
     RTX_TRY(dev_alloc(e, (void**)&e->in_desc, (size_t)(chunks + 128) * sizeof(int32_t)));
-    if (!e->in_wsplit) RTX_TRY(dev_alloc(e, (void**)&e->in_wsplit, (RTX_SPMM_WAVES + 1) * sizeof(int32_t)));
+    if (!e->in_wsplit) {
+        RTX_TRY(dev_alloc(e, (void**)&e->in_wsplit, (RTX_SPMM_WAVES + 1) * sizeof(int32_t)));
+        RTX_TRY(dev_alloc(e, (void**)&e->in_ustart, (size_t)(rtx_pad_batch(e->cfg.max_batch) + 1) * sizeof(int32_t)));
+    }
     e->in_cap_chunks = chunks;
     return RTX_OK;
 }
@@ -423,7 +431,11 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             c.training = training; c.dropout_p = e->cfg.dropout_p;
             c.mask = step->dropout_mask; c.seed = step->seed; c.offset = step->offset;
             c.ent = e->in_ent; c.desc = e->in_desc; c.wsplit = e->in_wsplit;
-            if (training) { c.target = *tg; c.tsum = e->tsum; c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
+            if (training) {
+                c.target = *tg; c.tsum = e->tsum;
+                if (e->in_defer) { c.ustart = e->in_ustart; e->in_image_pending = true; }
+                else { c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
+            }
             {
                 TIMED("in_chunks");
                 RTX_TRY(rtx_launch_in_chunks(c, st));
@@ -687,6 +699,7 @@ int rtx_engine_destroy(rtx_engine* e)
     for (hipEvent_t ev : e->ev_d)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+    if (e->ev_img) (void)hipEventDestroy(e->ev_img);
     if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
@@ -829,7 +842,26 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     RtxCsrView in, tg;
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
     const int B = batch->batch, Bp = rtx_pad_batch(B), NL = e->NL;
-    RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
+    // (see below for what the two streams do)
+    const bool two = fuse && e->opt_two_stream;
+    if (two && !e->side) {
+        // lowest priority: the long streaming kernels take the workgroup slots the short launches of the chain leave free,
+        // not the other way round (with equal priorities the chain's kernels waited for slots: k_reduce_loss 17 us, k_post
+        // 16 us under contention against 5 and 8 us alone)
+        int prio_least = 0, prio_greatest = 0;
+        RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
+        // (events created with hipEventReleaseToDevice -- a device-scope release at the record -- measure the same: 328.0 vs 327.7 us)
+        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&e->ev_img, hipEventDisableTiming));
+    }
+    const int main_li = (two && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
+    e->in_defer = main_li == 0 && e->opt_defer_image;
+    e->in_image_pending = false;
+    const int fwd_rc = run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st);
+    e->in_defer = false;
+    RTX_TRY(fwd_rc);
     if (dae_reg) {
         TIMED("sumsq");
         RTX_TRY(launch_sumsq(e, st));
@@ -854,24 +886,11 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     // beside the whole chain, the encoder matrix as soon as the chain has produced D[0]; the small layers' kernels follow
     // the chain on the caller's stream, beside the encoder matrix.  A big layer's fused optimizer writes the NEXT step's
     // compute copy (Wsh_alt; swapped at the end), because the chain still reads this step's.
-    const bool two = fuse && e->opt_two_stream;
-    if (two && !e->side) {
-        // lowest priority: the long streaming kernels take the workgroup slots the short launches of the chain leave free,
-        // not the other way round (with equal priorities the chain's kernels waited for slots: k_reduce_loss 17 us, k_post
-        // 16 us under contention against 5 and 8 us alone)
-        int prio_least = 0, prio_greatest = 0;
-        RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
-        // (events created with hipEventReleaseToDevice -- a device-scope release at the record -- measure the same: 328.0 vs 327.7 us)
-        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
-    }
     // The encoder matrix's kernel is the END of the step's critical path (it needs D[0], the last thing the chain produces, and
     // the next step's first product needs its result).  A cross-stream dependency costs about 18 us from the event's record to
     // the first workgroup of the waiting stream and a record about 7 us on the recording stream (profiles/r2_step_timeline.txt),
     // so that kernel stays on the CALLER's stream right behind the chain -- no hop before it, none after it -- and takes the small
     // layers' weight kernels with it in the same launch (as launches of their own beside it they crawl: 53 + 33 us).
-    const int main_li = (two && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
     auto on_side = [&](int li) { return two && layer_is_big(e->L[li]) && li != main_li; };
     auto reduce_loss = [&](hipStream_t ws) -> int {
         ScopedTimer tm(e, "reduce_loss", ws);
@@ -935,6 +954,13 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (on_side(li)) {   // the long kernel first: it only needs D[li], which exists now
             RTX_HIP(hipEventRecord(e->ev_d[li], st));
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[li], 0));
+            if (e->in_image_pending && li == NL - 1) {
+                // the chunk stream (written on the caller's stream before this event) -> the dense image the encoder matrix's
+                // weight kernel reads at the end of the step; that kernel waits for ev_img, recorded ~100 us before it is needed
+                ScopedTimer tm(e, "dense_image", e->side);
+                RTX_TRY(rtx_launch_chunks_to_dense(e->in_ent, e->in_ustart, B, Bp, e->Iin, (bf16_t*)e->L[0].A, e->L[0].inp, e->side));
+            }
+            if (e->in_image_pending && li == NL - 1) RTX_HIP(hipEventRecord(e->ev_img, e->side));
             RTX_TRY(weight_grad(li, e->side));
         }
         // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
@@ -987,6 +1013,10 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             else RTX_TRY(weight_grad(li, st));
         }
         make_dw(main_li, grp[ng++]);
+        if (e->in_image_pending) {
+            RTX_HIP(hipStreamWaitEvent(st, e->ev_img, 0));
+            e->in_image_pending = false;
+        }
         {
             ScopedTimer tm(e, "dW_adam_in", st);
             RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, e->opt_dw_cfg, st));
@@ -1153,6 +1183,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
     else if (k == "sparse_in") e->opt_sparse_in = value != 0;
+    else if (k == "defer_image") e->opt_defer_image = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;

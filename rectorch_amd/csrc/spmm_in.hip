@@ -55,6 +55,13 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
         if (tid == 0 && a.tsum) a.tsum[b] = 0.f;
         return;
     }
+    // this user's row first: its loads (row id -> row bounds -> first entries) are on their way while the chunk offsets of
+    // all users are summed below -- five dependent HBM round trips folded into three
+    const int64_t u = a.in.row_ids ? (int64_t)a.in.row_ids[b] : (int64_t)b;
+    const int64_t beg = a.in.indptr[u];
+    const int len = (int)(a.in.indptr[u + 1] - beg);
+    const int nch = max(1, (len + 63) >> 6);
+    const int first_item = tid < len ? a.in.indices[beg + tid] : 0;
     // chunks of the users before this one, and of all users
     int before = 0, total = 0;
     for (int j = tid; j < a.B; j += 512) {
@@ -72,11 +79,6 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
     before = 0; total = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { before += red_i[0][w]; total += red_i[1][w]; }
-
-    const int64_t u = a.in.row_ids ? (int64_t)a.in.row_ids[b] : (int64_t)b;
-    const int64_t beg = a.in.indptr[u];
-    const int len = (int)(a.in.indptr[u + 1] - beg);
-    const int nch = max(1, (len + 63) >> 6);
     // 1 / max(||x||, 1e-12) over the item columns (condition columns stay raw), as k_gather
     const bool cond = a.Iin > a.I;
     float ss;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
     };
     if (!a.X) {
         for (int t = tid; t < len; t += 512) {
-            const int i = a.in.indices[beg + t];
+            const int i = t == tid ? first_item : a.in.indices[beg + t];
             ent[t] = (uint32_t)i | ((uint32_t)entry(t, i) << 16);
         }
     } else {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
             for (int i = tid * 8; i < cn; i += 512 * 8) *(uint4*)(img + i) = make_uint4(0, 0, 0, 0);
             __syncthreads();
             for (int t = tid; t < len; t += 512) {
-                const int i = a.in.indices[beg + t];
+                const int i = t == tid ? first_item : a.in.indices[beg + t];
                 if (i >= c0 && i < c0 + cn) {
                     const bf16_t v = entry(t, i);
                     img[i - c0] = v;
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
     for (int t = len + tid; t < nch * 64; t += 512) ent[t] = 0;   // zero padding of the user's last chunk
     for (int c = tid; c < nch; c += 512) a.desc[before + c] = b;
     if (b == a.B - 1 && tid == 0) a.desc[total] = -1;
+    if (a.ustart && tid == 0) {
+        a.ustart[b] = before;
+        if (b == a.B - 1) a.ustart[a.B] = total;
+    }
     // the 16-way split: part w starts at the first user whose chunk offset reaches total * w / 16
     if (tid <= SPMM_WAVES) {
         const int w = tid;
@@ -184,6 +190,50 @@ int rtx_launch_in_chunks(const RtxInChunksArgs& a, hipStream_t stream)
     RTX_CHECK(a.B >= 1 && a.Iin >= a.I && a.Iin <= 65536, RTX_EINVAL, "in_chunks: bad shape");
     RTX_CHECK(!a.X || (a.ldx % 8 == 0 && a.Bp >= a.B), RTX_EINVAL, "in_chunks: bad dense image");
     hipLaunchKernelGGL(k_in_chunks, dim3(a.X ? a.Bp : a.B), dim3(512), 0, stream, a);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_chunks_to_dense: the dense bf16 image of the batch rows from the chunk stream (what k_in_chunks writes itself when it is
+// given X).  The fused step launches it on its side stream, off the critical path: no row ids, no Philox, no dependent loads
+// beyond ustart -> entries.  One workgroup per (padded) batch row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_chunks_to_dense(const uint32_t* __restrict__ ent, const int32_t* __restrict__ ustart, int B, int Iin,
+                                                         bf16_t* __restrict__ X, int ldx)
+{
+    constexpr int CH = 8192;
+    __shared__ __attribute__((aligned(16))) bf16_t img[CH];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    bf16_t* row = X + (size_t)b * ldx;
+    if (b >= B) {
+        for (int i = tid * 8; i < ldx; i += 512 * 8) *(uint4*)(row + i) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int c0 = ustart[b], n = (ustart[b + 1] - c0) * 64;
+    const uint32_t* __restrict__ e = ent + (size_t)c0 * 64;
+    const uint32_t first = tid < n ? e[tid] : 0u;
+    for (int x0 = 0; x0 < ldx; x0 += CH) {
+        const int xn = min(CH, ldx - x0);
+        for (int i = tid * 8; i < xn; i += 512 * 8) *(uint4*)(img + i) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        for (int t = tid; t < n; t += 512) {
+            const uint32_t w = t == tid ? first : e[t];
+            const int i = (int)(w & 0xffffu) - x0;
+            // the zero padding of a user's last chunk names item 0 with value 0: it must not overwrite a stored item 0
+            if (i >= 0 && i < xn && (w >> 16) != 0) img[i] = (bf16_t)(w >> 16);
+        }
+        if (tid == 0 && Iin >= x0 && Iin < x0 + xn) img[Iin - x0] = f32_to_bf16(1.f);   // ones column -> bias gradient
+        __syncthreads();
+        for (int i = tid * 8; i < xn; i += 512 * 8) *(uint4*)(row + x0 + i) = *(const uint4*)(img + i);
+        __syncthreads();
+    }
+}
+
+int rtx_launch_chunks_to_dense(const uint32_t* ent, const int32_t* ustart, int B, int Bp, int Iin, bf16_t* X, int ldx, hipStream_t stream)
+{
+    RTX_CHECK(ldx % 8 == 0 && Bp >= B && Iin < ldx, RTX_EINVAL, "chunks_to_dense: bad dense image");
+    hipLaunchKernelGGL(k_chunks_to_dense, dim3(Bp), dim3(512), 0, stream, ent, ustart, B, Iin, X, ldx);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

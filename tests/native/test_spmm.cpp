@@ -119,6 +119,7 @@ static int run_case(const Case& c, int perf_iters)
         CK(hipMalloc(&X, (size_t)Bp * ldw * 2)); CK(hipMemset(X, 0xff, (size_t)Bp * ldw * 2));
         CK(hipMalloc(&tsum, Bp * 4)); CK(hipMemset(tsum, 0xff, Bp * 4));
         ca.target = v; ca.tsum = tsum; ca.X = X; ca.ldx = ldw; ca.Bp = Bp;
+        CK(hipMalloc(&ca.ustart, (Bp + 1) * 4));
     }
     RT(rtx_launch_in_chunks(ca, 0));
     RT(rtx_launch_spmm_in(sa, 0));
@@ -131,12 +132,12 @@ static int run_case(const Case& c, int perf_iters)
     CK(hipMemcpy(r.data(), R, r.size() * 2, hipMemcpyDeviceToHost));
     CK(hipMemcpy(ws.data(), wsplit, 17 * 4, hipMemcpyDeviceToHost));
     // the split: monotone, from 0 to the number of chunks
+    int bad = 0;
     int total = 0;
     for (int b = 0; b < c.B; ++b) {
         const int64_t u = v.row_ids ? ids[b] : b;
         total += std::max(1, (int)((indptr[u + 1] - indptr[u] + 63) / 64));
     }
-    int bad = 0;
     if (ws[0] != 0 || ws[16] != total) { printf("  split ends %d..%d, expected 0..%d\n", ws[0], ws[16], total); ++bad; }
     for (int w = 0; w < 16; ++w) if (ws[w] > ws[w + 1]) { printf("  split not monotone at %d\n", w); ++bad; }
     std::vector<bf16_t> hx;
@@ -145,6 +146,16 @@ static int run_case(const Case& c, int perf_iters)
         hx.resize((size_t)Bp * ldw); hts.resize(Bp);
         CK(hipMemcpy(hx.data(), X, hx.size() * 2, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hts.data(), tsum, Bp * 4, hipMemcpyDeviceToHost));
+        // the same image rebuilt from the chunk stream (what the fused step's side stream does)
+        bf16_t* X2;
+        CK(hipMalloc(&X2, (size_t)Bp * ldw * 2)); CK(hipMemset(X2, 0xff, (size_t)Bp * ldw * 2));
+        RT(rtx_launch_chunks_to_dense(ent, ca.ustart, c.B, Bp, Iin, X2, ldw, 0));
+        std::vector<bf16_t> hx2((size_t)Bp * ldw);
+        CK(hipMemcpy(hx2.data(), X2, hx2.size() * 2, hipMemcpyDeviceToHost));
+        size_t diff = 0;
+        for (size_t k = 0; k < hx.size(); ++k) diff += hx[k] != hx2[k];
+        if (diff) { printf("  chunks_to_dense differs from the direct image in %zu elements\n", diff); ++bad; }
+        CK(hipFree(X2));
     }
     // host reference
     double worst = 0;
