@@ -79,13 +79,8 @@ struct rtx_engine {
     TempCsr tmp_in, tmp_tg;
     // chunk stream of the batch's stored entries for the sparse first layer (spmm_in.hip)
     uint32_t* in_ent = nullptr;
-    int32_t *in_desc = nullptr, *in_wsplit = nullptr, *in_ustart = nullptr;
+    int32_t *in_desc = nullptr, *in_wsplit = nullptr;
     int64_t in_cap_chunks = 0;
-    int opt_defer_image = 1;    // fused two-stream step: the dense image of the batch rows (only the encoder matrix's weight kernel reads it)
-                                //   is built from the chunk stream on the side stream, behind the event that stream waits for anyway
-    bool in_defer = false;      // set by the step around run_forward: leave the dense image to the side stream ...
-    bool in_image_pending = false;   // ... set by run_forward when it did
-    hipEvent_t ev_img = nullptr;
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
@@ -369,10 +364,7 @@ static int ensure_in_chunks(rtx_engine* e, int64_t chunks, hipStream_t st)
     }
     RTX_TRY(dev_alloc(e, (void**)&e->in_ent, (size_t)chunks * 256));
     RTX_TRY(dev_alloc(e, (void**)&e->in_desc, (size_t)(chunks + 128) * sizeof(int32_t)));
-    if (!e->in_wsplit) {
-        RTX_TRY(dev_alloc(e, (void**)&e->in_wsplit, (RTX_SPMM_WAVES + 1) * sizeof(int32_t)));
-        RTX_TRY(dev_alloc(e, (void**)&e->in_ustart, (size_t)(rtx_pad_batch(e->cfg.max_batch) + 1) * sizeof(int32_t)));
-    }
+    if (!e->in_wsplit) RTX_TRY(dev_alloc(e, (void**)&e->in_wsplit, (RTX_SPMM_WAVES + 1) * sizeof(int32_t)));
     e->in_cap_chunks = chunks;
     return RTX_OK;
 }
@@ -431,11 +423,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             c.training = training; c.dropout_p = e->cfg.dropout_p;
             c.mask = step->dropout_mask; c.seed = step->seed; c.offset = step->offset;
             c.ent = e->in_ent; c.desc = e->in_desc; c.wsplit = e->in_wsplit;
-            if (training) {
-                c.target = *tg; c.tsum = e->tsum;
-                if (e->in_defer) { c.ustart = e->in_ustart; e->in_image_pending = true; }
-                else { c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
-            }
+            if (training) { c.target = *tg; c.tsum = e->tsum; c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
             {
                 TIMED("in_chunks");
                 RTX_TRY(rtx_launch_in_chunks(c, st));
@@ -699,7 +687,6 @@ int rtx_engine_destroy(rtx_engine* e)
     for (hipEvent_t ev : e->ev_d)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
-    if (e->ev_img) (void)hipEventDestroy(e->ev_img);
     if (e->side) (void)hipStreamDestroy(e->side);
     delete e;
     return RTX_OK;
@@ -854,14 +841,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         // (events created with hipEventReleaseToDevice -- a device-scope release at the record -- measure the same: 328.0 vs 327.7 us)
         for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&e->ev_img, hipEventDisableTiming));
     }
     const int main_li = (two && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
-    e->in_defer = main_li == 0 && e->opt_defer_image;
-    e->in_image_pending = false;
-    const int fwd_rc = run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st);
-    e->in_defer = false;
-    RTX_TRY(fwd_rc);
+    RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
     if (dae_reg) {
         TIMED("sumsq");
         RTX_TRY(launch_sumsq(e, st));
@@ -954,13 +936,6 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (on_side(li)) {   // the long kernel first: it only needs D[li], which exists now
             RTX_HIP(hipEventRecord(e->ev_d[li], st));
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[li], 0));
-            if (e->in_image_pending && li == NL - 1) {
-                // the chunk stream (written on the caller's stream before this event) -> the dense image the encoder matrix's
-                // weight kernel reads at the end of the step; that kernel waits for ev_img, recorded ~100 us before it is needed
-                ScopedTimer tm(e, "dense_image", e->side);
-                RTX_TRY(rtx_launch_chunks_to_dense(e->in_ent, e->in_ustart, B, Bp, e->Iin, (bf16_t*)e->L[0].A, e->L[0].inp, e->side));
-            }
-            if (e->in_image_pending && li == NL - 1) RTX_HIP(hipEventRecord(e->ev_img, e->side));
             RTX_TRY(weight_grad(li, e->side));
         }
         // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
@@ -1013,10 +988,6 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             else RTX_TRY(weight_grad(li, st));
         }
         make_dw(main_li, grp[ng++]);
-        if (e->in_image_pending) {
-            RTX_HIP(hipStreamWaitEvent(st, e->ev_img, 0));
-            e->in_image_pending = false;
-        }
         {
             ScopedTimer tm(e, "dW_adam_in", st);
             RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, e->opt_dw_cfg, st));
@@ -1183,7 +1154,6 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
     else if (k == "sparse_in") e->opt_sparse_in = value != 0;
-    else if (k == "defer_image") e->opt_defer_image = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;

@@ -61,11 +61,8 @@ struct RtxInChunksArgs {
     float* tsum;         // [Bp] nullable
     bf16_t* X;           // [Bp][ldx] nullable: dense image, rows >= B zero, column Iin = 1 for b < B
     int ldx, Bp;
-    int32_t* ustart;     // [B + 1] nullable: first chunk of every user (rtx_launch_chunks_to_dense reads it)
 };
 int rtx_launch_in_chunks(const RtxInChunksArgs& a, hipStream_t stream);
-// the dense image from the chunk stream, for a stream that must not touch the batch's row ids (the step's side stream)
-int rtx_launch_chunks_to_dense(const uint32_t* ent, const int32_t* ustart, int B, int Bp, int Iin, bf16_t* X, int ldx, hipStream_t stream);
 // k_spmm_in: O32 / R [Bp][Np] = act(chunks x W^T + bias) with the padding and ones-column conventions of k_post (forward)
 struct RtxSpmmInArgs {
     const uint32_t* ent;

@@ -20,6 +20,12 @@
 //                 parked in one lane each; every 16 users the wave adds the bias, applies tanh and writes the float32
 //                 activation and the bf16 operand row of the next layer with all 64 lanes busy.
 //
+// Measured at the ml-20m shape (B = 500, profiles/r2_spmm_*): k_in_chunks 15 us (the gather kernel it replaces: 14), k_spmm_in
+// ~16 us (staging 5, sums 9 -- VALU-bound: 8 instructions per chunk, 13 per user end) against 23 + 9 us for the dense split-K
+// product and its post kernel: 9-13 us per step.  Tried and dropped: the dense image as zeros streamed out at kernel start +
+// 2-byte scattered stores of the values (17 us instead of 15; with an agent-scope fence 79 us: it writes the L2 back); the
+// dense image rebuilt from the chunk stream on the step's side stream (no gain: profiles/r2_defer_image_experiment.log).
+//
 // The weight matrix is read from HBM exactly once (24 MB), the chunk stream (~360 KB) from L2 by every workgroup.
 // Products are bf16 x bf16 exact in float32 like the MFMA's; only the order of the float32 additions differs from the dense
 // kernel (per lane over the user's chunks, then across the wave) -- fixed, so results are reproducible run to run.
@@ -165,10 +171,6 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
     for (int t = len + tid; t < nch * 64; t += 512) ent[t] = 0;   // zero padding of the user's last chunk
     for (int c = tid; c < nch; c += 512) a.desc[before + c] = b;
     if (b == a.B - 1 && tid == 0) a.desc[total] = -1;
-    if (a.ustart && tid == 0) {
-        a.ustart[b] = before;
-        if (b == a.B - 1) a.ustart[a.B] = total;
-    }
     // the 16-way split: part w starts at the first user whose chunk offset reaches total * w / 16
     if (tid <= SPMM_WAVES) {
         const int w = tid;
@@ -190,50 +192,6 @@ int rtx_launch_in_chunks(const RtxInChunksArgs& a, hipStream_t stream)
     RTX_CHECK(a.B >= 1 && a.Iin >= a.I && a.Iin <= 65536, RTX_EINVAL, "in_chunks: bad shape");
     RTX_CHECK(!a.X || (a.ldx % 8 == 0 && a.Bp >= a.B), RTX_EINVAL, "in_chunks: bad dense image");
     hipLaunchKernelGGL(k_in_chunks, dim3(a.X ? a.Bp : a.B), dim3(512), 0, stream, a);
-    RTX_HIP(hipGetLastError());
-    return RTX_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_chunks_to_dense: the dense bf16 image of the batch rows from the chunk stream (what k_in_chunks writes itself when it is
-// given X).  The fused step launches it on its side stream, off the critical path: no row ids, no Philox, no dependent loads
-// beyond ustart -> entries.  One workgroup per (padded) batch row.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_chunks_to_dense(const uint32_t* __restrict__ ent, const int32_t* __restrict__ ustart, int B, int Iin,
-                                                         bf16_t* __restrict__ X, int ldx)
-{
-    constexpr int CH = 8192;
-    __shared__ __attribute__((aligned(16))) bf16_t img[CH];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    bf16_t* row = X + (size_t)b * ldx;
-    if (b >= B) {
-        for (int i = tid * 8; i < ldx; i += 512 * 8) *(uint4*)(row + i) = make_uint4(0, 0, 0, 0);
-        return;
-    }
-    const int c0 = ustart[b], n = (ustart[b + 1] - c0) * 64;
-    const uint32_t* __restrict__ e = ent + (size_t)c0 * 64;
-    const uint32_t first = tid < n ? e[tid] : 0u;
-    for (int x0 = 0; x0 < ldx; x0 += CH) {
-        const int xn = min(CH, ldx - x0);
-        for (int i = tid * 8; i < xn; i += 512 * 8) *(uint4*)(img + i) = make_uint4(0, 0, 0, 0);
-        __syncthreads();
-        for (int t = tid; t < n; t += 512) {
-            const uint32_t w = t == tid ? first : e[t];
-            const int i = (int)(w & 0xffffu) - x0;
-            // the zero padding of a user's last chunk names item 0 with value 0: it must not overwrite a stored item 0
-            if (i >= 0 && i < xn && (w >> 16) != 0) img[i] = (bf16_t)(w >> 16);
-        }
-        if (tid == 0 && Iin >= x0 && Iin < x0 + xn) img[Iin - x0] = f32_to_bf16(1.f);   // ones column -> bias gradient
-        __syncthreads();
-        for (int i = tid * 8; i < xn; i += 512 * 8) *(uint4*)(row + x0 + i) = *(const uint4*)(img + i);
-        __syncthreads();
-    }
-}
-
-int rtx_launch_chunks_to_dense(const uint32_t* ent, const int32_t* ustart, int B, int Bp, int Iin, bf16_t* X, int ldx, hipStream_t stream)
-{
-    RTX_CHECK(ldx % 8 == 0 && Bp >= B && Iin < ldx, RTX_EINVAL, "chunks_to_dense: bad dense image");
-    hipLaunchKernelGGL(k_chunks_to_dense, dim3(Bp), dim3(512), 0, stream, ent, ustart, B, Iin, X, ldx);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

@@ -172,7 +172,7 @@ static std::vector<float> d2h(const float* d, size_t n)
 }
 
 static int g_fail = 0;
-static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1, g_opt_sparse = 1, g_opt_defer = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
+static int g_opt_fuse = 1, g_opt_dw_cfg = 0, g_opt_lse = 1, g_opt_two = 1, g_opt_ntreg = 1, g_opt_lowprio = 1, g_opt_inmain = 1, g_opt_sparse = 1;   // the shipped defaults   // rtx_engine_set_option values applied to every engine a case creates
 static void apply_options(rtx_engine* eng)
 {
     rtx_engine_set_option(eng, "fuse_adam", g_opt_fuse);
@@ -183,7 +183,6 @@ static void apply_options(rtx_engine* eng)
     rtx_engine_set_option(eng, "side_low_prio", g_opt_lowprio);
     rtx_engine_set_option(eng, "in_on_main", g_opt_inmain);
     rtx_engine_set_option(eng, "sparse_in", g_opt_sparse);
-    rtx_engine_set_option(eng, "defer_image", g_opt_defer);
 }
 static void check(const char* what, double err, double tol)
 {
@@ -430,7 +429,7 @@ static void philox_case()
 
 static void perf_case(int numerics, int B, int steps, int splitk)
 {
-    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d nt_regstage=%d dw_cfg=%d sparse_in=%d defer_image=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_ntreg, g_opt_dw_cfg, g_opt_sparse, g_opt_defer);
+    printf("[perf] MultiVAE [20108,600,200] %s B=%d splitk=%d fuse=%d two_stream=%d in_on_main=%d nt_regstage=%d dw_cfg=%d sparse_in=%d\n", numerics ? "bf16" : "fp32", B, splitk, g_opt_fuse, g_opt_two, g_opt_inmain, g_opt_ntreg, g_opt_dw_cfg, g_opt_sparse);
     Net net = make_net({20108, 600, 200}, {200, 600, 20108}, ORC_VAE, 0.5f, 0.1f);
     const int I = 20108, U = 4096;
     Csr tr;
@@ -550,10 +549,8 @@ int main(int argc, char** argv)
     if (perf_only || quick) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
         perf_case(RTX_BF16, B, 50, 0);
-        g_opt_defer = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_defer = 1;      // dense image written by k_in_chunks on the caller's stream
         g_opt_sparse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_sparse = 1;    // dense first layer
         perf_case(RTX_BF16, B, 50, 0);
-        g_opt_defer = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_defer = 1;
     }
     if (argc > 1 && !strcmp(argv[1], "perf")) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
