@@ -93,6 +93,7 @@ struct rtx_engine {
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
     int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
+    int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_fwd.hip)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -436,6 +437,23 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             a.O32 = l.O32; a.R = (bf16_t*)e->L[li + 1].A; a.ones_col = 1;
             TIMED("spmm_in");
             RTX_TRY(rtx_launch_spmm_in(a, st));
+            continue;
+        }
+        if (li > 0 && e->bf16 && e->opt_small_fwd && rtx_small_fwd_ok(l.inp)) {
+            // a hidden layer (or the VAE head): product + bias + activation + the next operand in one launch (small_fwd.hip)
+            Layer& nx1 = e->L[li + 1];
+            RtxSmallFwdArgs a = {};
+            a.A = (const bf16_t*)l.A; a.W = (const bf16_t*)l.Wsh; a.lda = l.inp; a.ldw = l.inp; a.w_rows = l.outp;
+            a.B = B; a.Bp = Bp; a.bias = e->params[2 * li + 1]; a.R = (bf16_t*)nx1.A;
+            if (e->vae && li == e->cfg.n_enc - 1) {
+                a.Z = e->Z; a.Np = e->Zp; a.N_real = e->Z; a.training = training;
+                a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32; a.mu_out = mu_out; a.lv_out = lv_out;
+                a.eps_in = step->eps_noise; a.seed = step->seed; a.offset = step->offset;
+            } else {
+                a.N_real = l.out; a.Np = l.outp; a.tanh_act = l.tanh_act; a.O32 = l.O32;
+            }
+            TIMED(a.Z ? "fwd_head" : "fwd_hidden");
+            RTX_TRY(rtx_launch_small_fwd(a, st));
             continue;
         }
         int splits = 1;
@@ -1154,6 +1172,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
     else if (k == "sparse_in") e->opt_sparse_in = value != 0;
+    else if (k == "small_fwd") e->opt_small_fwd = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;

@@ -81,6 +81,26 @@ struct RtxSpmmInArgs {
 size_t rtx_spmm_in_lds_bytes(int Kin);   // <= 160 KB or the launch is refused
 int rtx_launch_spmm_in(const RtxSpmmInArgs& a, hipStream_t stream);
 
+// ---- hidden layers of the forward pass in one launch each (small_fwd.hip; bf16 numerics, padded input width <= 1024) ----
+// Z == 0: R / O32 [Bp][Np] = act(A W^T + bias) with the conventions of k_post (forward).  Z > 0: the VAE head with the
+// conventions of k_vae_fwd (W rows [0, Z) = mu, [Z, 2Z) = logvar; R = the next operand [Bp][Np = Zp]).
+struct RtxSmallFwdArgs {
+    const bf16_t* A;   // [Bp][lda]
+    const bf16_t* W;   // [w_rows][ldw]
+    int lda, ldw, w_rows;
+    int B, Bp, N_real, Np, tanh_act;
+    const float* bias;
+    float* O32;        // hidden: nullable
+    bf16_t* R;
+    // VAE head
+    int Z, training;
+    float *mu32, *lv32, *eps32, *mu_out, *lv_out;
+    const float* eps_in;
+    uint64_t seed, offset;
+};
+bool rtx_small_fwd_ok(int K);
+int rtx_launch_small_fwd(const RtxSmallFwdArgs& a, hipStream_t stream);
+
 // DataSampler densify: rows -> float32 [B][I] (ld = I), optional second matrix
 int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipStream_t stream);
 

@@ -1,0 +1,137 @@
+// small_fwd.hip -- the hidden layers of the forward pass in ONE launch each (gfx950, bf16 numerics).
+//
+// Reference: the `nn.Linear` + tanh of every hidden layer and the mu / logvar head with the reparameterisation
+// (nets.py:262-265, 394-417).  At B = 500 these are [500 x 600] x [600 x 400] and [500 x 200] x [200 x 600] products: a
+// few MFLOP each, so the general GEMM + its post kernel (8-9 us per launch, almost all of it launch ramp and the latency of
+// walking K slice by slice through an LDS pipeline) cost 31 us per step for four launches.  Here a wave owns 16 batch rows
+// x 32 output features and K is a compile-time constant (the padded input width / 32): every fragment of the wave's A and B
+// operands is loaded straight from global memory into registers in one burst -- ONE round trip, no LDS, no K loop to wait
+// in -- then 2 x K/32 v_mfma_f32_16x16x32_bf16 run back to back and the epilogue (bias, tanh or the VAE head, the float32
+// activation, the next layer's bf16 operand row with its ones column) is applied from the accumulators.
+//
+// Operands: A [Bp][K] bf16 row-major (K-contiguous; column `in` = 1, beyond it 0), W [outp][K] bf16 compute copy (row n =
+// output feature n; its column `in` is zero, so the ones column adds nothing in the forward product).
+#include "rtx_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 sf_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float sf_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned sf_u32x4;
+
+// fragment s of a 16-row operand: lane (r = lane & 15, g = lane >> 4) holds elements [r][32 s + 8 g .. + 8)
+template <int KS>
+__device__ __forceinline__ void sf_load(sf_u32x4 (&f)[KS], const bf16_t* __restrict__ base, int ld, int row0, int lane)
+{
+    const bf16_t* p = base + (size_t)(row0 + (lane & 15)) * ld + (lane >> 4) * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = *(const sf_u32x4*)(p + s * 32);
+}
+template <int KS>
+__device__ __forceinline__ sf_f32x4 sf_dot(const sf_u32x4 (&a)[KS], const sf_u32x4 (&b)[KS])
+{
+    sf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sf_bf16x8, a[s]), __builtin_bit_cast(sf_bf16x8, b[s]), acc, 0, 0, 0);
+    return acc;   // element i: row (lane >> 4) * 4 + i, column lane & 15
+}
+
+// ---- hidden layer: R / O32 [Bp][Np] = act(A W^T + bias), conventions of k_post (forward) -------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void k_fwd_hidden(const RtxSmallFwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 32;
+    sf_u32x4 fa[KS], fb0[KS], fb1[KS];
+    sf_load<KS>(fa, a.A, a.lda, r0, lane);
+    sf_load<KS>(fb0, a.W, a.ldw, c0, lane);
+    sf_load<KS>(fb1, a.W, a.ldw, c0 + 16, lane);
+    __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first MFMA waits (the scheduler would interleave
+                                         // them twelve at a time to save registers: a pipeline paced by the memory latency)
+    const sf_f32x4 acc[2] = {sf_dot<KS>(fa, fb0), sf_dot<KS>(fa, fb1)};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = c0 + t * 16 + (lane & 15);
+        const float bias = n < a.N_real ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = r0 + (lane >> 4) * 4 + i;
+            float x = 0.f;
+            if (b < a.B && n < a.N_real) {
+                x = acc[t][i] + bias;
+                if (a.tanh_act) x = tanhf(x);
+            }
+            const size_t at = (size_t)b * a.Np + n;
+            if (a.O32) a.O32[at] = x;
+            a.R[at] = f32_to_bf16((b < a.B && n == a.N_real) ? 1.f : x);
+        }
+    }
+}
+
+// ---- VAE head: [mu | logvar] = A W^T + bias; z = mu + eps exp(logvar / 2) (eval: z = mu); conventions of k_vae_fwd -----
+template <int KS>
+__global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 16;
+    const int j = c0 + (lane & 15);
+    sf_f32x4 mu = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < a.Z) {   // (a tile beyond the latent width only carries the ones column / zero padding of the next operand)
+        sf_u32x4 fa[KS], fm[KS], fl[KS];
+        sf_load<KS>(fa, a.A, a.lda, r0, lane);
+        sf_load<KS>(fm, a.W, a.ldw, c0, lane);
+        sf_load<KS>(fl, a.W, a.ldw, a.Z + c0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mu = sf_dot<KS>(fa, fm);
+        lv = sf_dot<KS>(fa, fl);
+    }
+    const float bm = j < a.Z ? a.bias[j] : 0.f, bl = j < a.Z ? a.bias[a.Z + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = r0 + (lane >> 4) * 4 + i;
+        float z = 0.f;
+        if (b < a.B && j < a.Z) {
+            const float mm = mu[i] + bm, l = lv[i] + bl;
+            float eps = 0.f;
+            if (a.training) eps = a.eps_in ? a.eps_in[(size_t)b * a.Z + j] : rtx_normal(a.seed, a.offset, (uint64_t)b * a.Z + j);
+            z = a.training ? mm + eps * expf(0.5f * l) : mm;
+            const size_t o = (size_t)b * a.Z + j;
+            a.mu32[o] = mm;
+            a.lv32[o] = l;
+            a.eps32[o] = eps;
+            if (a.mu_out) a.mu_out[o] = mm;
+            if (a.lv_out) a.lv_out[o] = l;
+        }
+        if (b < a.B && j == a.Z) z = 1.f;   // ones column -> bias gradient of the first decoder layer
+        a.R[(size_t)b * a.Np + j] = f32_to_bf16(z);
+    }
+}
+
+bool rtx_small_fwd_ok(int K) { return K >= 128 && K <= 1024 && K % 128 == 0; }
+
+template <int KS>
+static void small_fwd_launch(const RtxSmallFwdArgs& a, hipStream_t stream)
+{
+    if (a.Z > 0)
+        hipLaunchKernelGGL(k_fwd_head<KS>, dim3(a.Np / 16, a.Bp / 64), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_fwd_hidden<KS>, dim3(a.Np / 32, a.Bp / 64), dim3(256), 0, stream, a);
+}
+
+int rtx_launch_small_fwd(const RtxSmallFwdArgs& a, hipStream_t stream)
+{
+    RTX_CHECK(rtx_small_fwd_ok(a.lda) && a.ldw == a.lda, RTX_EINVAL, "small_fwd: input width %d not in {128, 256, .. 1024}", a.lda);
+    RTX_CHECK(a.Bp % 64 == 0 && a.Np % 32 == 0 && a.R, RTX_EINVAL, "small_fwd: bad padding");
+    RTX_CHECK(a.Z > 0 ? a.Z + ((a.Z + 15) & ~15) <= a.w_rows : a.Np <= a.w_rows, RTX_EINVAL, "small_fwd: the weight copy has %d rows", a.w_rows);
+    switch (a.lda / 128) {
+        case 1: small_fwd_launch<4>(a, stream); break;
+        case 2: small_fwd_launch<8>(a, stream); break;
+        case 3: small_fwd_launch<12>(a, stream); break;
+        case 4: small_fwd_launch<16>(a, stream); break;
+        case 5: small_fwd_launch<20>(a, stream); break;
+        case 6: small_fwd_launch<24>(a, stream); break;
+        case 7: small_fwd_launch<28>(a, stream); break;
+        default: small_fwd_launch<32>(a, stream); break;
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}

@@ -48,6 +48,8 @@ def timeline(path, anchor="k_gather", nth=40, count=2):
     cur = sqlite3.connect(path).cursor()
     rows = cur.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if anchor in r[0]]
+    if not idx:   # the sparse first layer: the step opens with k_in_chunks instead of k_gather
+        idx = [i for i, r in enumerate(rows) if "k_in_chunks" in r[0]]
     if len(idx) < nth + count + 1:
         nth = max(0, len(idx) - count - 1)
     lo, hi = idx[nth], idx[nth + count]
