@@ -321,6 +321,7 @@ static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxC
         RTX_CHECK(b->row_ids || b->batch <= b->csr->n_rows, RTX_EINVAL, "batch larger than the matrix");
         in->indptr = b->csr->indptr; in->indices = b->csr->indices; in->values = b->csr->values; in->row_ids = b->row_ids;
         in->max_row_len = b->csr->max_row_len;
+        in->avg_row_len = (int32_t)std::min<int64_t>((b->csr->nnz + std::max<int64_t>(b->csr->n_rows, 1) - 1) / std::max<int64_t>(b->csr->n_rows, 1), INT32_MAX);
     } else {
         RTX_CHECK(b->x_dense, RTX_EINVAL, "batch has neither csr nor x_dense");
         RTX_TRY(dense_to_view(e, e->tmp_in, b->x_dense, b->batch, e->Iin, in, st));
@@ -350,7 +351,11 @@ static bool sparse_in_ok(const rtx_engine* e, const RtxCsrView* in, int Bp, int6
     if (!e->bf16 || !e->opt_sparse_in || e->NL < 2 || (e->vae && e->cfg.n_enc == 1)) return false;
     if (in->max_row_len <= 0 || e->Iin > 65536 || rtx_spmm_in_lds_bytes(e->Iin) > 160 * 1024) return false;
     *chunks = (int64_t)Bp * std::max(1, (in->max_row_len + 63) / 64) + 64;   // + the read-ahead of the last wave
-    return *chunks * 256 <= ((int64_t)512 << 20);
+    // every workgroup of k_spmm_in walks the whole chunk stream (~6 ns per chunk), the dense product re-reads the weights and
+    // the dense batch image (~25 us + 8 us per 1000 rows): beyond ~4000 expected chunks (ml-20m at B = 500: ~1500; Netflix-
+    // shaped rows at B = 4096: ~18 000) the dense product wins
+    const int64_t expected = (int64_t)Bp * ((in->avg_row_len + 63) / 64 + 1);
+    return *chunks * 256 <= ((int64_t)512 << 20) && expected <= 4096;
 }
 static int ensure_in_chunks(rtx_engine* e, int64_t chunks, hipStream_t st)
 {

@@ -11,6 +11,7 @@ struct RtxCsrView {
     const float* values;
     const int32_t* row_ids;
     int32_t max_row_len;   // longest row of the matrix the view comes from (0 = unknown: a densified batch)
+    int32_t avg_row_len;   // its mean row length, rounded up
 };
 
 // the opaque rtx_csr of include/rectorch_hip.h: a scipy-style CSR matrix resident in HBM

@@ -75,29 +75,38 @@ __global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
     const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 16;
     const int j = c0 + (lane & 15);
     sf_f32x4 mu = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
+    float eps[4] = {0.f, 0.f, 0.f, 0.f};
+    const float bm = j < a.Z ? a.bias[j] : 0.f, bl = j < a.Z ? a.bias[a.Z + j] : 0.f;
     if (c0 < a.Z) {   // (a tile beyond the latent width only carries the ones column / zero padding of the next operand)
         sf_u32x4 fa[KS], fm[KS], fl[KS];
         sf_load<KS>(fa, a.A, a.lda, r0, lane);
         sf_load<KS>(fm, a.W, a.ldw, c0, lane);
         sf_load<KS>(fl, a.W, a.ldw, a.Z + c0, lane);
+        // the noise (Philox + Box-Muller, ~200 instructions per element) is drawn while the operands are in flight
+        // (pure ALU here: a load in this stretch makes the compiler wait for ALL loads at the branch; injected noise is read below)
+        if (a.training && !a.eps_in) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = r0 + (lane >> 4) * 4 + i;
+                eps[i] = rtx_normal(a.seed, a.offset, (uint64_t)b * a.Z + j);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         mu = sf_dot<KS>(fa, fm);
         lv = sf_dot<KS>(fa, fl);
     }
-    const float bm = j < a.Z ? a.bias[j] : 0.f, bl = j < a.Z ? a.bias[a.Z + j] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int b = r0 + (lane >> 4) * 4 + i;
         float z = 0.f;
         if (b < a.B && j < a.Z) {
             const float mm = mu[i] + bm, l = lv[i] + bl;
-            float eps = 0.f;
-            if (a.training) eps = a.eps_in ? a.eps_in[(size_t)b * a.Z + j] : rtx_normal(a.seed, a.offset, (uint64_t)b * a.Z + j);
-            z = a.training ? mm + eps * expf(0.5f * l) : mm;
+            if (a.training && a.eps_in) eps[i] = a.eps_in[(size_t)b * a.Z + j];
+            z = a.training ? mm + eps[i] * expf(0.5f * l) : mm;
             const size_t o = (size_t)b * a.Z + j;
             a.mu32[o] = mm;
             a.lv32[o] = l;
-            a.eps32[o] = eps;
+            a.eps32[o] = eps[i];
             if (a.mu_out) a.mu_out[o] = mm;
             if (a.lv_out) a.lv_out[o] = l;
         }
