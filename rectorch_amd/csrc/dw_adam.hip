@@ -115,6 +115,10 @@ __device__ __forceinline__ void dw_finish4(const RtxDw& p, int row, int col, con
         dw_st_nt(A.v + off, vn);
         if (A.gkeep) *(dw_f32x4*)(A.gkeep + off) = g4;
         if (A.sh) store4<bf16_t>((bf16_t*)A.sh + (size_t)row * A.ld_sh + col, pn[0], pn[1], pn[2], pn[3]);
+        if (A.shT) {   // hidden layers only (a few hundred thousand elements): the transposed compute copy of the backward chain
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ((bf16_t*)A.shT)[(size_t)(col + k) * A.ld_shT + row] = f32_to_bf16(pn[k]);
+        }
     } else {
         const bool vec = (p.N_real & 3) == 0;
         const int nv = min(4, p.N_real - col);

@@ -37,6 +37,7 @@ struct Layer {
     void* Wsh = nullptr;      // the compute copy every reader of this step uses
     void* Wsh_alt = nullptr;  // the fused optimizer writes the NEXT step's copy here (they swap after the step), so the
                               // weight-gradient kernels may run beside the data-gradient chain that still reads Wsh
+    void* WshT = nullptr;     // hidden layers, bf16: the transposed compute copy [inp][outp] the backward chain reads (small_layers.hip)
     void* A = nullptr;
     float* O32 = nullptr;
     void* D = nullptr;
@@ -93,7 +94,8 @@ struct rtx_engine {
     int opt_side_low_prio = 1;  // ... created with the lowest stream priority
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
     int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
-    int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_fwd.hip)
+    int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_layers.hip)
+    int opt_small_bwd = 1;      // ... and of the data-gradient chain (reads the transposed compute copies of the hidden layers)
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -445,7 +447,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             continue;
         }
         if (li > 0 && e->bf16 && e->opt_small_fwd && rtx_small_fwd_ok(l.inp)) {
-            // a hidden layer (or the VAE head): product + bias + activation + the next operand in one launch (small_fwd.hip)
+            // a hidden layer (or the VAE head): product + bias + activation + the next operand in one launch (small_layers.hip)
             Layer& nx1 = e->L[li + 1];
             RtxSmallFwdArgs a = {};
             a.A = (const bf16_t*)l.A; a.W = (const bf16_t*)l.Wsh; a.lda = l.inp; a.ldw = l.inp; a.w_rows = l.outp;
@@ -517,7 +519,7 @@ static void fill_adam_tensors(rtx_engine* e, RtxAdamArgs& a, int l0 = 0, int l1 
         w.g = e->can_train ? e->grads[2 * li] : nullptr;
         w.m = e->can_train ? e->m[2 * li] : nullptr;
         w.v = e->can_train ? e->v[2 * li] : nullptr;
-        w.sh = l.Wsh; w.shT = nullptr; w.rows = l.out; w.cols = l.in; w.ld_sh = l.inp; w.ld_shT = 0;
+        w.sh = l.Wsh; w.shT = l.WshT; w.rows = l.out; w.cols = l.in; w.ld_sh = l.inp; w.ld_shT = l.WshT ? l.outp : 0;
         w.sumsq = nullptr;
         RtxAdamTensor& b = a.t[a.n++];
         b.p = e->params[2 * li + 1];
@@ -674,6 +676,7 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
         Layer& l = e->L[li];
         ALLOC(l.Wsh, (size_t)l.outp * l.inp * es);
         if (e->bf16) ALLOC(l.Wsh_alt, (size_t)l.outp * l.inp * es);
+        if (e->bf16 && li > 0 && li < e->NL - 1 && rtx_small_fwd_ok(l.outp)) ALLOC(l.WshT, (size_t)l.inp * l.outp * es);
         ALLOC(l.A, Bp * l.inp * es);
         if (li < e->NL - 1) ALLOC(l.O32, Bp * l.outp * sizeof(float));
         ALLOC(l.D, Bp * l.outp * es);
@@ -920,7 +923,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             d.adam.p = e->params[2 * li]; d.adam.m = e->m[2 * li]; d.adam.v = e->v[2 * li];
             d.adam.gkeep = keep ? e->grads[2 * li] : nullptr;
             d.gbias = keep ? e->grads[2 * li + 1] : nullptr;
-            d.adam.sh = on_side(li) ? l.Wsh_alt : l.Wsh; d.adam.shT = nullptr; d.adam.ld_sh = l.inp; d.adam.ld_shT = 0;
+            d.adam.sh = on_side(li) ? l.Wsh_alt : l.Wsh; d.adam.shT = l.WshT; d.adam.ld_sh = l.inp; d.adam.ld_shT = l.WshT ? l.outp : 0;
             d.adam.step_size = sc.step_size; d.adam.bc2_sqrt = sc.bc2_sqrt; d.adam.beta1 = sc.beta1; d.adam.beta2 = sc.beta2;
             d.adam.eps = sc.eps; d.adam.weight_decay = sc.weight_decay; d.adam.lam = sc.lam;
             d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
@@ -963,7 +966,22 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         }
         // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
         // the weight kernel of this layer, whose fused optimizer epilogue overwrites the compute copy.
-        if (li > 0) {
+        if (li > 0 && li < NL - 1 && l.WshT && e->opt_small_bwd) {
+            // a hidden layer: product with the transposed compute copy + the activation derivative (or the VAE head's
+            // backward) + the bf16 gradient of the layer below in one launch (small_layers.hip)
+            Layer& pv = e->L[li - 1];
+            RtxSmallBwdArgs a = {};
+            a.D = (const bf16_t*)l.D; a.WT = (const bf16_t*)l.WshT; a.ld = l.outp; a.wt_rows = l.inp;
+            a.B = B; a.Bp = Bp; a.Np = pv.outp; a.Dout = (bf16_t*)pv.D;
+            if (e->vae && li == e->cfg.n_enc) {
+                a.Z = e->Z; a.training = 1; a.mu32 = e->mu32; a.lv32 = e->lv32; a.eps32 = e->eps32;
+                a.beta = step->beta; a.inv_batch = step->inv_batch;
+            } else {
+                a.N_real = pv.out; a.tanh_act = pv.tanh_act; a.O32 = pv.O32;
+            }
+            TIMED(a.Z ? "bwd_head" : "bwd_hidden");
+            RTX_TRY(rtx_launch_small_bwd(a, st));
+        } else if (li > 0) {
             int splits = 1;
             {
                 TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
@@ -1178,6 +1196,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "in_on_main") e->opt_in_on_main = value != 0;
     else if (k == "sparse_in") e->opt_sparse_in = value != 0;
     else if (k == "small_fwd") e->opt_small_fwd = value != 0;
+    else if (k == "small_bwd") e->opt_small_bwd = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;

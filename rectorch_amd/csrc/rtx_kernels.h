@@ -82,7 +82,7 @@ struct RtxSpmmInArgs {
 size_t rtx_spmm_in_lds_bytes(int Kin);   // <= 160 KB or the launch is refused
 int rtx_launch_spmm_in(const RtxSpmmInArgs& a, hipStream_t stream);
 
-// ---- hidden layers of the forward pass in one launch each (small_fwd.hip; bf16 numerics, padded input width <= 1024) ----
+// ---- hidden layers of the forward pass in one launch each (small_layers.hip; bf16 numerics, padded input width <= 1024) ----
 // Z == 0: R / O32 [Bp][Np] = act(A W^T + bias) with the conventions of k_post (forward).  Z > 0: the VAE head with the
 // conventions of k_vae_fwd (W rows [0, Z) = mu, [Z, 2Z) = logvar; R = the next operand [Bp][Np = Zp]).
 struct RtxSmallFwdArgs {
@@ -101,6 +101,21 @@ struct RtxSmallFwdArgs {
 };
 bool rtx_small_fwd_ok(int K);
 int rtx_launch_small_fwd(const RtxSmallFwdArgs& a, hipStream_t stream);
+// backward through a hidden layer (Z == 0: conventions of k_post backward) or the VAE head (Z > 0: of k_vae_bwd):
+// Dout [Bp][Np] from D [Bp][ld] (the layer's output gradient) and W^T [wt_rows][ld] (row n = input feature n)
+struct RtxSmallBwdArgs {
+    const bf16_t* D;
+    const bf16_t* WT;
+    int ld, wt_rows;
+    int B, Bp, N_real, Np, tanh_act;
+    const float* O32;  // hidden: the saved activation of the layer below [Bp][Np] (read if tanh_act)
+    bf16_t* Dout;
+    // VAE head
+    int Z, training;
+    const float *mu32, *lv32, *eps32;
+    float beta, inv_batch;
+};
+int rtx_launch_small_bwd(const RtxSmallBwdArgs& a, hipStream_t stream);
 
 // DataSampler densify: rows -> float32 [B][I] (ld = I), optional second matrix
 int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipStream_t stream);

@@ -1,4 +1,4 @@
-// small_fwd.hip -- the hidden layers of the forward pass in ONE launch each (gfx950, bf16 numerics).
+// small_layers.hip -- the hidden layers of the forward AND the backward pass in ONE launch each (gfx950, bf16 numerics).
 //
 // Reference: the `nn.Linear` + tanh of every hidden layer and the mu / logvar head with the reparameterisation
 // (nets.py:262-265, 394-417).  At B = 500 these are [500 x 600] x [600 x 400] and [500 x 200] x [200 x 600] products: a
@@ -8,6 +8,11 @@
 // operands is loaded straight from global memory into registers in one burst -- ONE round trip, no LDS, no K loop to wait
 // in -- then 2 x K/32 v_mfma_f32_16x16x32_bf16 run back to back and the epilogue (bias, tanh or the VAE head, the float32
 // activation, the next layer's bf16 operand row with its ones column) is applied from the accumulators.
+//
+// Backward (the data-gradient chain between the decoder matrix's product and the encoder matrix's weight kernel): the same
+// scheme on dA = D W with the TRANSPOSED compute copy W^T [in][outp] (kept for the hidden layers only, 0.7 MB; written by the
+// optimizer wherever it writes the compute copy), so the contraction index is contiguous for both operands again; epilogues
+// of k_post (backward: x (1 - o^2)) and k_vae_bwd.  Four launches of the chain become two.
 //
 // Operands: A [Bp][K] bf16 row-major (K-contiguous; column `in` = 1, beyond it 0), W [outp][K] bf16 compute copy (row n =
 // output feature n; its column `in` is zero, so the ones column adds nothing in the forward product).
@@ -115,6 +120,72 @@ __global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
     }
 }
 
+// ---- backward through a hidden layer: Dout [Bp][Np] = (D W)[b][n] x (1 - o[b][n]^2), conventions of k_post (backward) ------
+template <int KS>
+__global__ __launch_bounds__(256) void k_bwd_hidden(const RtxSmallBwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 32;
+    sf_u32x4 fa[KS], fb0[KS], fb1[KS];
+    sf_load<KS>(fa, a.D, a.ld, r0, lane);
+    sf_load<KS>(fb0, a.WT, a.ld, c0, lane);
+    sf_load<KS>(fb1, a.WT, a.ld, c0 + 16, lane);
+    float o[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[t][i] = a.tanh_act ? a.O32[(size_t)(r0 + (lane >> 4) * 4 + i) * a.Np + c0 + t * 16 + (lane & 15)] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    const sf_f32x4 acc[2] = {sf_dot<KS>(fa, fb0), sf_dot<KS>(fa, fb1)};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = c0 + t * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = r0 + (lane >> 4) * 4 + i;
+            const float x = (b < a.B && n < a.N_real) ? acc[t][i] * (1.f - o[t][i] * o[t][i]) : 0.f;
+            a.Dout[(size_t)b * a.Np + n] = f32_to_bf16(x);
+        }
+    }
+}
+
+// ---- backward through the VAE head: dz = D W; Dout [Bp][Np] = [dmu | dlogvar | 0], conventions of k_vae_bwd ------------
+template <int KS>
+__global__ __launch_bounds__(256) void k_bwd_head(const RtxSmallBwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 16;
+    const int j = c0 + (lane & 15);
+    sf_u32x4 fa[KS], fb[KS];
+    sf_load<KS>(fa, a.D, a.ld, r0, lane);
+    sf_load<KS>(fb, a.WT, a.ld, c0, lane);
+    float mu[4], lv[4], ep[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (clamped addresses, masked below: no branch around the loads)
+        const size_t at = (size_t)min(r0 + (lane >> 4) * 4 + i, a.B - 1) * a.Z + min(j, a.Z - 1);
+        mu[i] = a.mu32[at]; lv[i] = a.lv32[at]; ep[i] = a.eps32[at];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const sf_f32x4 dz = sf_dot<KS>(fa, fb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = r0 + (lane >> 4) * 4 + i;
+        bf16_t* out = a.Dout + (size_t)b * a.Np;
+        if (j < a.Z) {
+            float dm = 0.f, dl = 0.f;
+            if (b < a.B) {
+                dm = dz[i] + a.beta * mu[i] * a.inv_batch;
+                dl = a.beta * 0.5f * (expf(lv[i]) - 1.f) * a.inv_batch;
+                if (a.training) dl += dz[i] * ep[i] * 0.5f * expf(0.5f * lv[i]);
+            }
+            out[j] = f32_to_bf16(dm);
+            out[a.Z + j] = f32_to_bf16(dl);
+        }
+        for (int n = 2 * a.Z + j; n < a.Np; n += gridDim.x * 16) out[n] = 0;   // the padding columns, shared out over the tiles
+    }
+}
+
 bool rtx_small_fwd_ok(int K) { return K >= 128 && K <= 1024 && K % 128 == 0; }
 
 template <int KS>
@@ -124,6 +195,34 @@ static void small_fwd_launch(const RtxSmallFwdArgs& a, hipStream_t stream)
         hipLaunchKernelGGL(k_fwd_head<KS>, dim3(a.Np / 16, a.Bp / 64), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(k_fwd_hidden<KS>, dim3(a.Np / 32, a.Bp / 64), dim3(256), 0, stream, a);
+}
+
+template <int KS>
+static void small_bwd_launch(const RtxSmallBwdArgs& a, hipStream_t stream)
+{
+    if (a.Z > 0)
+        hipLaunchKernelGGL(k_bwd_head<KS>, dim3((a.Z + 15) / 16, a.Bp / 64), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_bwd_hidden<KS>, dim3(a.Np / 32, a.Bp / 64), dim3(256), 0, stream, a);
+}
+
+int rtx_launch_small_bwd(const RtxSmallBwdArgs& a, hipStream_t stream)
+{
+    RTX_CHECK(rtx_small_fwd_ok(a.ld), RTX_EINVAL, "small_bwd: output width %d not in {128, 256, .. 1024}", a.ld);
+    RTX_CHECK(a.Bp % 64 == 0 && a.Np % 32 == 0 && a.Dout && a.B >= 1, RTX_EINVAL, "small_bwd: bad padding");
+    RTX_CHECK(a.Z > 0 ? ((a.Z + 15) & ~15) <= a.wt_rows : a.Np <= a.wt_rows, RTX_EINVAL, "small_bwd: the transposed weight copy has %d rows", a.wt_rows);
+    switch (a.ld / 128) {
+        case 1: small_bwd_launch<4>(a, stream); break;
+        case 2: small_bwd_launch<8>(a, stream); break;
+        case 3: small_bwd_launch<12>(a, stream); break;
+        case 4: small_bwd_launch<16>(a, stream); break;
+        case 5: small_bwd_launch<20>(a, stream); break;
+        case 6: small_bwd_launch<24>(a, stream); break;
+        case 7: small_bwd_launch<28>(a, stream); break;
+        default: small_bwd_launch<32>(a, stream); break;
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
 }
 
 int rtx_launch_small_fwd(const RtxSmallFwdArgs& a, hipStream_t stream)
