@@ -259,6 +259,6 @@ int main()
     };
     for (const Case& c : cases) bad += run_case(c, 0) != 0;
     bad += run_case(cases[0], 40) != 0;
-    printf(bad ? "FAILED (%d cases)\n" : "all spmm cases ok\n", bad);
+    printf(bad ? "SPMM TESTS FAILED (%d cases)\n" : "SPMM TESTS PASSED\n", bad);
     return bad ? 1 : 0;
 }

@@ -54,9 +54,10 @@ def make_dae(enc, dec, p, sd, **kw):
 
 
 # ---------------------------------------------------------------------------------------------- native drivers
-@pytest.mark.parametrize("exe", ["test_gemm", "test_engine"])
+@pytest.mark.parametrize("exe", ["test_gemm", "test_spmm", "test_engine"])
 def test_native_driver(exe):
-    """the no-Python drivers: MFMA GEMM vs host double loops; the whole engine vs the C oracle via the C ABI"""
+    """the no-Python drivers: MFMA GEMM vs host double loops; the sparse first layer vs a host loop over the same stored
+    entries; the whole engine vs the C oracle via the C ABI"""
     path = os.path.join(ROOT, "build", "native", exe)
     if not os.path.exists(path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native")])
@@ -1353,3 +1354,47 @@ def test_c_abi_rccl_hooks_one_rank():
     for a, b in zip(outs[0][1], outs[1][1]):
         assert np.array_equal(a, b)
     _lib.check(L_.rtx_comm_destroy(comm))
+
+
+@pytest.mark.parametrize("case", ["vae-mid", "dae-deep-odd", "vae-head-first"])
+def test_bf16_fast_paths_match_the_generic_kernels(case):
+    """bf16 numerics: the sparse first layer (spmm_in.hip) and the one-launch hidden layers of both passes (small_layers.hip)
+    against the dense split-K product and the GEMM + post-kernel chain they replace -- same batches, same Philox draws, three
+    training steps and a prediction.  Both sides multiply the same bf16 operands; only the order of the float32 additions
+    differs, so the trajectories agree far inside the bf16 tolerance of the fp32 reference."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    enc, dec, variant, p = {"vae-mid": ([3000, 600, 200], [200, 600, 3000], "vae", 0.5),
+                            "dae-deep-odd": ([777, 77, 33], [33, 50, 777], "dae", 0.3),
+                            "vae-head-first": ([500, 64], [64, 120, 500], "vae", 0.5)}[case]
+    I, B = enc[0], 130
+    X = synth_interactions(3 * B, I, mu=3.2, sigma=0.9, dmax=I // 2, seed=11)
+    sd = hash_state_dict(enc, dec, variant, 5, bias_std=0.1)
+
+    def run(opts):
+        if variant == "vae":
+            net, model = make_vae(enc, dec, p, sd, beta=0.2, anneal_steps=10, numerics="bf16")
+        else:
+            net, model = make_dae(enc, dec, p, sd, lam=0.05, numerics="bf16")
+        st, params, m, v = model._ensure_train_state()
+        eng = net.rtx_engine("bf16", B, train_buffers=(st.grads, m, v))
+        for k, val in opts.items():
+            eng.set_option(k, val)
+        smp = DataSampler(X, batch_size=B, shuffle=False)
+        rbs = list(smp.iter_rows())
+        torch.manual_seed(3)
+        losses = [model._fused_step(rbs[i % len(rbs)], None, want_loss=True) for i in range(3)]
+        pred = model.predict(smp._csr_tr.gather_dense(rbs[0].rows))[0].cpu().numpy()
+        return losses, [q.detach().cpu().numpy().copy() for q in net._param_list()], pred
+
+    fast = run({})
+    slow = run({"sparse_in": 0, "small_fwd": 0, "small_bwd": 0})
+    for a, b in zip(fast[0], slow[0]):
+        assert abs(a - b) < 2e-4 * abs(b), (case, fast[0], slow[0])
+    for a, b in zip(fast[1], slow[1]):
+        d = np.abs(a - b)
+        # three Adam steps of lr = 1e-3: an element whose tiny gradient changes sign moves by up to 2 lr per step
+        assert float(d.max()) <= 6.1e-3 and float(np.mean(d > 2e-5)) < 1e-2, (case, float(d.max()), float(np.mean(d > 2e-5)))
+    assert np.array_equal(np.isneginf(fast[2]), np.isneginf(slow[2]))
+    fin = np.isfinite(slow[2])
+    assert rel(fast[2][fin], slow[2][fin]) < 5e-3
