@@ -270,7 +270,9 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the big NT contractions on the register-staged GEMM
  * instead of the LDS-DMA one), "dw_cfg" (0..3: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic), "in_on_main" (0/1: the encoder matrix's weight kernel on
  * the caller's stream behind the chain), "sparse_in" (0/1, bf16: the first encoder layer as a sparse product over the batch's
- * stored entries -- spmm_in.hip -- instead of the dense split-K GEMM; needs a CSR batch and n_items + cond_dim <= 20 480).
+ * stored entries -- spmm_in.hip -- instead of the dense split-K GEMM; needs a CSR batch, n_items + cond_dim <= 20 480 and at most
+ * ~4000 expected 64-entry chunks per batch), "small_fwd" / "small_bwd" (0/1, bf16: hidden layers and the VAE head of the forward
+ * pass / of the data-gradient chain as one register-resident launch each -- small_layers.hip -- for padded widths <= 1024).
  * Replaces round 1's RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
 
