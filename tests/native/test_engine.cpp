@@ -502,8 +502,9 @@ int main(int argc, char** argv)
     printf("device: %s CUs=%d arch=%s | abi v%d\n", prop.name, prop.multiProcessorCount, prop.gcnArchName, rtx_abi_version());
     const bool perf_only = argc > 1 && !strcmp(argv[1], "perfonly");   // the perf table without the (CPU-oracle-bound) parity cases
     // parity cases run rtx_engine_train_step (step 3): in bf16 numerics that is the fused dW + Adam path (the default)
-    const bool quick = argc > 1 && !strcmp(argv[1], "quick");   // bf16 numerics only, without the widest case and the variants
-    for (int numerics = quick ? 1 : 0; numerics < 2 && !perf_only; ++numerics) {
+    const bool quick32 = argc > 1 && !strcmp(argv[1], "quick32");   // ... the same in float32 numerics, no perf table
+    const bool quick = quick32 || (argc > 1 && !strcmp(argv[1], "quick"));   // bf16 numerics only, without the widest case and the variants
+    for (int numerics = (quick && !quick32) ? 1 : 0; numerics < (quick32 ? 1 : 2) && !perf_only; ++numerics) {
         parity_case("small-vae", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), numerics, 5, 9, 0.2f, false, false, false, 0.2f, 0.f);
         parity_case("small-vae-te-weighted", make_net({64, 16, 8}, {8, 16, 64}, ORC_VAE, 0.5f, 1.0f), numerics, 6, 9, 0.2f, true, true, false, 1.0f, 0.f);
         parity_case("deep-odd-vae", make_net({77, 21, 13, 5}, {5, 9, 77}, ORC_VAE, 0.3f, 1.0f), numerics, 7, 11, 0.15f, true, false, false, 0.3f, 0.f);
@@ -546,7 +547,7 @@ int main(int argc, char** argv)
         g_opt_sparse = 1;
         parity_case("mid-dae", make_net({3000, 600, 200}, {200, 600, 3000}, ORC_DAE, 0.5f, 0.3f), RTX_BF16, 300, 400, 0.02f, false, false, false, 0.f, 0.2f);
     }
-    if (perf_only || quick) {
+    if (perf_only || (quick && !quick32)) {
         const int B = argc > 2 ? atoi(argv[2]) : 500;
         perf_case(RTX_BF16, B, 50, 0);
         g_opt_sparse = 0; perf_case(RTX_BF16, B, 50, 0); g_opt_sparse = 1;    // dense first layer
