@@ -12,17 +12,17 @@
 //                 gradient kernel still reads it K-major) and the target row sums -- each entry is computed once.
 //   k_spmm_in     one workgroup per FOUR output features: their four weight rows (4 x n_items bf16 = 157 KB of the
 //                 160 KB LDS at n_items = 20 108) are interleaved into LDS once -- item i -> 8 bytes (w0 w1 | w2 w3) --
-//                 then every wave streams its share of the chunk stream (coalesced 256-B loads, 16 chunks in flight
-//                 twice over); each lane gathers its entry's four weights with ONE ds_read_b64 and accumulates them with
+//                 then every wave streams its share of the chunk stream (coalesced 256-B loads, two blocks of 16
+//                 chunks in flight while a third is consumed); each lane gathers its entry's four weights with ONE ds_read_b64 and accumulates them with
 //                 four v_dot2c_f32_bf16 (the value sits in one half of the second operand, zero in the other: no
 //                 bf16 -> f32 unpacking).  At a user boundary the four per-lane sums are reduced across the wave
 //                 together (v_permlane32_swap, v_permlane16_swap, four DPP steps: 13 instructions for the four sums) and
 //                 parked in one lane each; every 16 users the wave adds the bias, applies tanh and writes the float32
 //                 activation and the bf16 operand row of the next layer with all 64 lanes busy.
 //
-// Measured at the ml-20m shape (B = 500, profiles/r2_spmm_*): k_in_chunks 15 us (the gather kernel it replaces: 14), k_spmm_in
-// ~16 us (staging 5, sums 9 -- VALU-bound: 8 instructions per chunk, 13 per user end) against 23 + 9 us for the dense split-K
-// product and its post kernel: 9-13 us per step.  Tried and dropped: the dense image as zeros streamed out at kernel start +
+// Measured at the ml-20m shape (B = 500; profiles/r2_bench_kernel_stats.txt, r2_spmm_native_test.log): k_in_chunks 12 us (the
+// gather kernel it replaces: 12-14), k_spmm_in 20 us (staging 5, sums 9 -- VALU-bound: 8 instructions per chunk, 13 per user
+// end -- the rest launch ramp and tail) against 22 + 9 us for the dense split-K product and its post kernel: 9-13 us per step.  Tried and dropped: the dense image as zeros streamed out at kernel start +
 // 2-byte scattered stores of the values (17 us instead of 15; with an agent-scope fence 79 us: it writes the L2 back); the
 // dense image rebuilt from the chunk stream on the step's side stream (no gain: profiles/r2_defer_image_experiment.log).
 //
