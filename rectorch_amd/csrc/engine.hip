@@ -312,6 +312,7 @@ static int dense_to_view(rtx_engine* e, TempCsr& t, const float* x, int B, int w
     RTX_TRY(ensure_tmp(e, t, nnz));
     RTX_TRY(rtx_launch_dense_fill(x, B, width, t.indptr, t.indices, t.values, st));
     v->indptr = t.indptr; v->indices = t.indices; v->values = t.values; v->row_ids = nullptr;
+    v->max_row_len = 0; v->avg_row_len = 0;   // a densified batch: row lengths unknown -> the dense first layer (sparse_in_ok)
     return RTX_OK;
 }
 
@@ -433,7 +434,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             c.in = *in; c.B = B; c.I = e->I; c.Iin = e->Iin;
             c.training = training; c.dropout_p = e->cfg.dropout_p;
             c.mask = step->dropout_mask; c.seed = step->seed; c.offset = step->offset;
-            c.ent = e->in_ent; c.desc = e->in_desc; c.wsplit = e->in_wsplit;
+            c.ent = e->in_ent; c.desc = e->in_desc; c.wsplit = e->in_wsplit; c.cap_chunks = e->in_cap_chunks;
             if (training) { c.target = *tg; c.tsum = e->tsum; c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
             {
                 TIMED("in_chunks");
@@ -792,7 +793,7 @@ int rtx_engine_forward(rtx_engine* e, const rtx_batch* batch, int32_t training, 
     RTX_CHECK(logits, RTX_EINVAL, "forward: logits is NULL");
     hipStream_t st = (hipStream_t)stream;
     RTX_TRY(ensure_shadows(e, st));
-    RtxCsrView in, tg;
+    RtxCsrView in = {}, tg = {};
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
     RTX_TRY(run_forward(e, &in, &in, batch->batch, training, step, 0, 0, e->NL, logits, e->I, mu, logvar, st));
     if (remove_train) {
@@ -809,7 +810,7 @@ int rtx_engine_encode(rtx_engine* e, const rtx_batch* batch, int32_t training, c
     RTX_CHECK(out0, RTX_EINVAL, "encode: out0 is NULL");
     hipStream_t st = (hipStream_t)stream;
     RTX_TRY(ensure_shadows(e, st));
-    RtxCsrView in, tg;
+    RtxCsrView in = {}, tg = {};
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st, 0));
     const int ne = e->cfg.n_enc;
     RTX_TRY(run_forward(e, &in, &in, batch->batch, training, step, 0, 0, ne, nullptr, 0, out0, out1, st));
@@ -855,7 +856,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
     const bool dae_reg = !e->vae && step->lam != 0.f;
     RTX_TRY(ensure_shadows(e, st));
-    RtxCsrView in, tg;
+    RtxCsrView in = {}, tg = {};
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
     const int B = batch->batch, Bp = rtx_pad_batch(B), NL = e->NL;
     // (see below for what the two streams do)
@@ -902,7 +903,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     // the first workgroup of the waiting stream and a record about 7 us on the recording stream (profiles/r2_step_timeline.txt),
     // so that kernel stays on the CALLER's stream right behind the chain -- no hop before it, none after it -- and takes the small
     // layers' weight kernels with it in the same launch (as launches of their own beside it they crawl: 53 + 33 us).
-    auto on_side = [&](int li) { return two && layer_is_big(e->L[li]) && li != main_li; };
+    // (a hidden layer keeps ONE transposed compute copy, WshT, which its fused optimizer epilogue overwrites and the chain's
+    // k_bwd_hidden reads: such a layer's weight kernel must stay behind the chain on the caller's stream)
+    auto on_side = [&](int li) { return two && layer_is_big(e->L[li]) && li != main_li && !e->L[li].WshT; };
     auto reduce_loss = [&](hipStream_t ws) -> int {
         ScopedTimer tm(e, "reduce_loss", ws);
         const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);

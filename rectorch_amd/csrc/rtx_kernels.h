@@ -57,6 +57,7 @@ struct RtxInChunksArgs {
     uint32_t* ent;
     int32_t* desc;
     int32_t* wsplit;
+    int64_t cap_chunks;  // capacity of ent / desc in chunks: a user whose chunks would not fit writes nothing (0 = unchecked)
     // optional: what k_gather<bf16> writes, from the same pass over the entries (training step)
     RtxCsrView target;   // rows whose sums go to tsum (read only if tsum != NULL)
     float* tsum;         // [Bp] nullable

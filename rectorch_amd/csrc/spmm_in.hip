@@ -85,6 +85,8 @@ __global__ __launch_bounds__(512) void k_in_chunks(const RtxInChunksArgs a)
     before = 0; total = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { before += red_i[0][w]; total += red_i[1][w]; }
+    // the engine sizes the stream from the matrix's longest row; a caller that hands a shorter bound must not corrupt memory
+    if (a.cap_chunks > 0 && (int64_t)total + 1 > a.cap_chunks) return;
     // 1 / max(||x||, 1e-12) over the item columns (condition columns stay raw), as k_gather
     const bool cond = a.Iin > a.I;
     float ss;

@@ -126,6 +126,7 @@ class _EpochLog:
         self.every = max(10, n_batches // 10 ** verbose)
         self.t_epoch = self.t_stretch = time.time()
         self.total = 0.0
+        self.seen = 0           # batches actually consumed (a sampler's __len__ may be approximate: SVAE packs under shuffle)
 
     def due(self, n_done):
         return n_done % self.every == 0
@@ -136,11 +137,13 @@ class _EpochLog:
         logger.info('| epoch %d | %d/%d batches | ms/batch %.2f | loss %.2f |', self.epoch, n_done, self.n_batches,
                     (now - self.t_stretch) * 1000 / self.every, loss_sum / self.every)
         self.total += loss_sum
+        self.seen = n_done
         self.t_stretch = time.time()
 
-    def finish(self, tail_loss_sum):
+    def finish(self, tail_loss_sum, n_done=None):
+        n = n_done if n_done is not None else self.n_batches
         logger.info("| epoch %d | loss %.4f | total time: %.2fs |", self.epoch,
-                    (self.total + tail_loss_sum) / self.n_batches, time.time() - self.t_epoch)
+                    (self.total + tail_loss_sum) / max(n, 1), time.time() - self.t_epoch)
 
 
 def _validate(model, epoch, valid_data, valid_metric, valid_func):
@@ -207,6 +210,7 @@ class AETrainer(TorchNNTrainer):
         log = _EpochLog(epoch, len(train_loader), verbose)
         resident = isinstance(train_loader, DataSampler) and train_loader.resident
         pending = 0.0                       # host path: losses of the current stretch
+        done = 0
         for done, item in enumerate(train_loader.iter_rows() if resident else train_loader, 1):
             if resident:
                 rows = item if self._uses_te or item.te is None else RowBatch(item.tr, None, item.rows)
@@ -217,7 +221,7 @@ class AETrainer(TorchNNTrainer):
             if log.due(done):
                 log.stretch(done, self._read_loss_sum() if resident else pending)
                 pending = 0.0
-        log.finish(self._read_loss_sum() if resident else pending)
+        log.finish(self._read_loss_sum() if resident else pending, done)
 
     def train_batch(self, tr_batch, te_batch=None):
         r"""Training of a single batch (reference models.py:424-447): the loss target is the batch itself

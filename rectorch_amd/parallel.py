@@ -66,6 +66,7 @@ class GradAllReducer:
         self.world = dist.get_world_size(group)
         self.layer_ranges = list(layer_ranges)
         self.on_device = flat.is_cuda
+        self.native_collectives = dist.get_backend(group) != "gloo"    # reduce_scatter_tensor / all_gather_into_tensor exist
         self.side = torch.cuda.Stream() if self.on_device else None     # RCCL
         self.opt = torch.cuda.Stream() if self.on_device else None      # per-bucket Adam
         self.comm_dtype = comm_dtype
@@ -157,10 +158,12 @@ class GradAllReducer:
         """in-place reduce-scatter of a buffer of world equal blocks: afterwards block `rank` holds the sum"""
         n = buf.numel() // self.world
         mine = buf[self.rank * n:(self.rank + 1) * n]
-        try:
+        if self.native_collectives:
             dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            # backends without reduce-scatter (gloo in the CPU / shared-GPU tests): same result from an all-reduce
+        else:
+            # backends without reduce-scatter (gloo in the CPU / shared-GPU tests): same result from an all-reduce.  The choice
+            # is made ONCE from the backend -- an error of a real collective on one rank must surface, not turn into a different
+            # collective than the peers issue
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
     def _all_gather_inplace(self, full):
@@ -168,9 +171,9 @@ class GradAllReducer:
         n = full.numel() // self.world
         flat = full.view(-1)
         mine = flat[self.rank * n:(self.rank + 1) * n]
-        try:
+        if self.native_collectives:
             dist.all_gather_into_tensor(flat, mine, group=self.group)
-        except (RuntimeError, NotImplementedError):
+        else:
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)
             for r, t in enumerate(parts):

@@ -1398,3 +1398,135 @@ def test_bf16_fast_paths_match_the_generic_kernels(case):
     assert np.array_equal(np.isneginf(fast[2]), np.isneginf(slow[2]))
     fin = np.isfinite(slow[2])
     assert rel(fast[2][fin], slow[2][fin]) < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------- round 3: the benchmarked shape
+@pytest.mark.parametrize("numerics", ["fp32", "bf16"])
+def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
+    """BASELINE.json configs[1] exactly as bench.py times it -- I = 20108, B = 500, the DEFAULT step configuration (bf16: sparse
+    first layer, one-launch hidden layers, the 1580 + 60-tile grouped weight-gradient + Adam launch with the encoder matrix and the
+    transposed hidden copies, the decoder matrix's kernel on the side stream; gradients never stored) -- two steps with injected
+    dropout masks / noise against oracle/mvae_oracle.c: loss, all eight parameter tensors, exp_avg and exp_avg_sq
+    (reference models.py:817-835).  Prints the achieved errors."""
+    from oracle import c_oracle
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L, B = 20108, 600, 200, 500
+    X = synth_interactions(2 * B, I, seed=23)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 41, bias_std=0.05)
+    params, keys = params_in_order(sd)
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, numerics=numerics)
+    assert model.keep_grads is False
+    ref = c_oracle.OracleTrainer([I, H, L], [L, H, I], params, "vae", 0.5, beta=0.2, anneal_steps=0, lr=1e-3)
+    gen = torch.Generator().manual_seed(11)
+    fp32 = numerics == "fp32"
+    for t, rb in enumerate(DataSampler(X, batch_size=B, shuffle=False).iter_rows()):
+        mask = (torch.rand(B, I, generator=gen) >= 0.5).to(torch.uint8)
+        eps = torch.randn(B, L, generator=gen)
+        model._rtx.inject = (mask.cuda(), eps.cuda())
+        loss = model._fused_step(rb, None, want_loss=True)
+        dense = np.asarray(X[t * B:(t + 1) * B].toarray(), dtype=np.float32)
+        ref_loss = ref.train_batch(dense, None, mask.numpy(), eps.numpy())
+        print("%s step %d: loss hip %.6f oracle %.6f (rel %.2e)" % (numerics, t, loss, ref_loss, abs(loss - ref_loss) / abs(ref_loss)))
+        assert abs(loss - ref_loss) < (2e-5 if fp32 else 2e-3) * abs(ref_loss), (t, loss, ref_loss)
+    torch.cuda.synchronize()
+    lr = 1e-3
+    for prm, r, rm, rv, k in zip(net._param_list(), ref.params, ref.m, ref.v, keys):
+        state = model.optimizer.state[prm]
+        d = np.abs(prm.detach().cpu().numpy() - r)
+        m_hip, v_hip = state['exp_avg'].cpu().numpy(), state['exp_avg_sq'].cpu().numpy()
+        em = float(np.max(np.abs(m_hip - rm))) / max(1e-30, float(np.max(np.abs(rm))))
+        ev = float(np.max(np.abs(v_hip - rv))) / max(1e-30, float(np.max(np.abs(rv))))
+        frac = float(np.mean(d > (2e-5 if fp32 else 5e-4)))
+        print("%s %-22s |dp| max %.2e mean %.2e frac>%s %.2e | exp_avg rel %.2e | exp_avg_sq rel %.2e"
+              % (numerics, k, float(d.max()), float(d.mean()), "2e-5" if fp32 else "5e-4", frac, em, ev))
+        # Adam's normalised step turns a gradient that is round-off noise around zero into a +-lr move: the bound on a single
+        # parameter is 2 steps x lr, the statistics say how rare that is
+        assert float(d.max()) <= 2 * lr * 1.05, (k, float(d.max()))
+        if fp32:
+            assert frac < 2e-4 and float(d.mean()) < 2e-7, (k, frac, float(d.mean()))
+            assert em < 3e-4 and ev < 6e-4, (k, em, ev)
+        else:
+            assert frac < 0.02 and float(d.mean()) < 4e-5, (k, frac, float(d.mean()))
+            assert em < 3e-2 and ev < 6e-2, (k, em, ev)
+    assert model._rtx.adam_step == 2
+
+
+def _grouped_interactions(n_users, n_items, n_groups, seed):
+    """ml-20m-shaped synthetic rows with structure a recommender can learn: user u belongs to group u % n_groups and every group
+    ranks the items by its own permutation of the Zipf popularity law (rectorch_amd.utils.synth_interactions draws the rows)"""
+    from rectorch_amd.utils import synth_interactions
+    X = synth_interactions(n_users, n_items, seed=seed).tocsr()
+    rng = np.random.default_rng(seed + 1)
+    perms = np.stack([rng.permutation(n_items) for _ in range(n_groups)])
+    rows = np.repeat(np.arange(n_users), np.diff(X.indptr))
+    cols = perms[rows % n_groups, X.indices]
+    Y = csr_matrix((np.ones(cols.size), (rows, cols)), shape=X.shape)
+    Y.sum_duplicates()
+    Y.sort_indices()
+    return Y
+
+
+def test_trained_model_ndcg_recall_parity_bf16_vs_cpu_port():
+    """The metric's second half ("nDCG@100 parity") for the HEADLINE mode: MultiVAE [20108, 600, 200], B = 500, bf16 training on the
+    HIP path vs the same K = 120 steps of the reference's op sequence on the CPU (oracle/rectorch_cpu.py, float32), same hash init,
+    same dropout masks and noise (the CPU port draws them from torch's generator; they are replayed from the seed and injected),
+    then evaluate() on 1000 held-out users (80/20 item split): mean nDCG@100 and Recall@50 within 1e-2 relative, the smoothed loss
+    curves within 1 %.  Reference: models.py:817-835 -> evaluation.py:100-106 -> metrics.py:136-147, 187-196."""
+    import torch.nn.functional as F
+    from oracle.rectorch_cpu import CpuNet, CpuTrainer
+    from rectorch_amd.utils import hash_state_dict
+    from rectorch_amd.utils.synth import split_heldout
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd.evaluation import evaluate
+    from rectorch_amd.metrics import Metrics
+    I, H, L, B, K = 20108, 600, 200, 500, 120
+    n_train, n_val = 8000, 1000
+    X = _grouped_interactions(n_train + n_val, I, 24, seed=77)
+    train, held = X[:n_train], X[n_train:]
+    val_tr, val_te = split_heldout(held, 0.2, seed=5)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 2024, bias_std=0.05)
+    params, _ = params_in_order(sd)
+    net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=1000, learning_rate=1e-3, numerics="bf16")
+    cnet = CpuNet([I, H, L], [L, H, I], "vae", 0.5)
+    cnet.load_numpy(params)
+    ctr = CpuTrainer(cnet, beta=0.2, anneal_steps=1000, lr=1e-3)
+    torch.set_num_threads(max(1, min(64, (os.cpu_count() or 8))))
+    np.random.seed(4242)
+    smp = DataSampler(train, batch_size=B, shuffle=True)
+    hip_losses, cpu_losses = [], []
+    t = 0
+    while t < K:
+        for rb in smp.iter_rows():
+            if t >= K or len(rb) < B:
+                break
+            seed = 5000 + t
+            rows = rb.rows.cpu().numpy()
+            x = torch.from_numpy(np.asarray(train[rows].toarray(), dtype=np.float32))
+            torch.manual_seed(seed)
+            cpu_losses.append(ctr.train_batch(x))
+            torch.manual_seed(seed)                      # replay: the draws the CPU step just consumed (dropout first, then eps)
+            mask = (F.dropout(torch.ones(B, I), 0.5, True) != 0).to(torch.uint8)
+            eps = torch.randn(B, L)
+            model._rtx.inject = (mask.cuda(), eps.cuda())
+            hip_losses.append(model._fused_step(rb, None, want_loss=True))
+            t += 1
+    model._rtx.inject = None
+    hip_losses, cpu_losses = np.array(hip_losses), np.array(cpu_losses)
+    w = 10
+    sm = lambda a: np.convolve(a, np.ones(w) / w, mode="valid")
+    curve = float(np.max(np.abs(sm(hip_losses) - sm(cpu_losses)) / np.abs(sm(cpu_losses))))
+    res = evaluate(model, DataSampler(val_tr, val_te, batch_size=500, shuffle=False), ["ndcg@100", "recall@50"])
+    xo = torch.from_numpy(np.asarray(val_tr.toarray(), dtype=np.float32))
+    lo = ctr.predict(xo, True)[0].numpy()
+    ro = Metrics.compute(lo, np.asarray(val_te.toarray(), dtype=np.float32), ["ndcg@100", "recall@50"])
+    nd_h, nd_c = float(np.mean(res["ndcg@100"])), float(np.mean(ro["ndcg@100"]))
+    rc_h, rc_c = float(np.mean(res["recall@50"])), float(np.mean(ro["recall@50"]))
+    print("trained %d steps: loss first %.4f/%.4f last-20 mean hip %.4f cpu %.4f | smoothed curve max rel diff %.2e"
+          % (K, hip_losses[0], cpu_losses[0], hip_losses[-20:].mean(), cpu_losses[-20:].mean(), curve))
+    print("nDCG@100 hip(bf16) %.5f cpu(f32) %.5f rel %.2e | Recall@50 hip %.5f cpu %.5f rel %.2e | per-user nDCG max |d| %.3f"
+          % (nd_h, nd_c, abs(nd_h - nd_c) / nd_c, rc_h, rc_c, abs(rc_h - rc_c) / rc_c,
+             float(np.max(np.abs(res["ndcg@100"] - ro["ndcg@100"])))))
+    assert nd_c > 0.15, "the CPU port must have learned the groups' rankings in %d steps (untrained: 0.05)" % K
+    assert curve < 1e-2, curve
+    assert abs(nd_h - nd_c) < 1e-2 * nd_c and abs(rc_h - rc_c) < 1e-2 * rc_c
