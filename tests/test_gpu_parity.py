@@ -1440,15 +1440,17 @@ def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
         frac = float(np.mean(d > (2e-5 if fp32 else 5e-4)))
         print("%s %-22s |dp| max %.2e mean %.2e frac>%s %.2e | exp_avg rel %.2e | exp_avg_sq rel %.2e"
               % (numerics, k, float(d.max()), float(d.mean()), "2e-5" if fp32 else "5e-4", frac, em, ev))
-        # Adam's normalised step turns a gradient that is round-off noise around zero into a +-lr move: the bound on a single
-        # parameter is 2 steps x lr, the statistics say how rare that is
-        assert float(d.max()) <= 2 * lr * 1.05, (k, float(d.max()))
+        # Adam's normalised step turns a gradient that is round-off noise around zero into a +-lr move: two trajectories can part
+        # by 2 lr per step on such a parameter; the statistics say how rare that is.  Bounds = about 4x the errors achieved on
+        # MI355X (round 3: fp32 |dp| max 4.5e-5, moments 1e-5; bf16 |dp| mean 2.6e-6, 0.1 % of the parameters off by > 5e-4,
+        # moments 5e-3)
+        assert float(d.max()) <= 2 * 2 * lr * 1.05, (k, float(d.max()))
         if fp32:
-            assert frac < 2e-4 and float(d.mean()) < 2e-7, (k, frac, float(d.mean()))
-            assert em < 3e-4 and ev < 6e-4, (k, em, ev)
+            assert float(d.max()) < 2e-4 and frac < 1e-5 and float(d.mean()) < 5e-9, (k, float(d.max()), frac, float(d.mean()))
+            assert em < 5e-5 and ev < 5e-5, (k, em, ev)
         else:
-            assert frac < 0.02 and float(d.mean()) < 4e-5, (k, frac, float(d.mean()))
-            assert em < 3e-2 and ev < 6e-2, (k, em, ev)
+            assert frac < 5e-3 and float(d.mean()) < 1.2e-5, (k, frac, float(d.mean()))
+            assert em < 2.5e-2 and ev < 2.5e-2, (k, em, ev)
     assert model._rtx.adam_step == 2
 
 
