@@ -71,7 +71,18 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="exercise the data-parallel code path (RCCL exchange + split step) even with one rank")
     ap.add_argument("--sharded", action="store_true",
-                    help="data parallel: reduce-scatter -> Adam on the local 1/N shard -> all-gather of the weights")
+                    help="data parallel: reduce-scatter -> Adam on the local 1/N shard -> all-gather of the weights "
+                         "(the default with more than one rank, real or emulated)")
+    ap.add_argument("--replicated", action="store_true", help="data parallel: all-reduce + the whole Adam update on every rank")
+    ap.add_argument("--dp-engine", default=None, choices=["native", "python"],
+                    help="who schedules the data-parallel step: the engine (one C call per step, default) or round 2's Python reducer")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="G",
+                    help="one GPU plays rank 0 of a G-rank job: the engine's data-parallel schedule with every collective replaced by "
+                         "device copies of the bytes a rank moves and Adam on 1/G of the rows (HBM cost of the per-GPU step; timing only)")
+    ap.add_argument("--pmc-json", default=None,
+                    help="JSON written by tools/pmc_bench.sh for THIS build (field hbm_bytes_per_launch): reported as roofline.traffic "
+                         "with its file name; without it traffic is null (counters need their own rocprofv3 --pmc passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the train_batch-API and dense-first-layer side measurements")
     a = ap.parse_args()
     if a.workload == "netflix":
         a.users = a.users or 480000
@@ -83,6 +94,10 @@ def parse():
         a.items = a.items or 20108
         a.scaling = a.scaling or "weak"
         a.batch = a.batch or 500
+    if a.replicated:
+        a.sharded = False
+    elif a.gpus > 1 or a.emulate_world > 1:
+        a.sharded = True
     return a
 
 
@@ -190,6 +205,8 @@ def main():
     from rectorch_amd.engine import RowBatch
 
     I, H, L = args.items, 600, 200
+    emu = args.emulate_world
+    assert not (emu and world > 1), "--emulate-world runs on ONE GPU"
     global_batch = args.batch * world if args.scaling == "weak" else args.batch
     if args.workload == "netflix":
         X = synth_interactions(args.users, I, mu=4.3, sigma=1.0, dmax=5000, seed=20240927)
@@ -213,12 +230,20 @@ def main():
         store = os.path.join(tempfile.mkdtemp(prefix="rtx_dp1_"), "store")
         dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1)
     rccl_ranks = None
-    dp = world > 1 or args.force_dp
-    if dp:
+    dp = world > 1 or args.force_dp or emu > 0
+    plan = None
+    if emu:
+        # rank 0 of an emu-rank job on this one GPU: weak scaling keeps --batch users here, strong scaling --batch / emu
+        if args.scaling == "strong":
+            global_batch, args.batch = args.batch, max(1, args.batch // emu)
+        else:
+            global_batch = args.batch * emu
+        plan = parallel.attach(model, fixed_global_batch=global_batch, sharded=args.sharded, emulate_world=emu)
+    elif dp:
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)                                 # an actual RCCL collective: the line is self-checking
         rccl_ranks = int(round(float(probe.item())))
-        parallel.attach(model, fixed_global_batch=global_batch, sharded=args.sharded)
+        plan = parallel.attach(model, fixed_global_batch=global_batch, sharded=args.sharded, engine=args.dp_engine)
     # resident sampler over the global batch; each rank takes its slice of every global batch
     np.random.seed(20240927)
     smp = DataSampler(Xin, Xtg, batch_size=global_batch, shuffle=True)
@@ -226,7 +251,7 @@ def main():
     for rb in smp.iter_rows():
         if len(rb) < global_batch:
             break
-        s, e = parallel.shard_rows(len(rb), rank, world)
+        s, e = parallel.shard_rows(len(rb), 0 if emu else rank, emu if emu else world)
         batches.append(RowBatch(rb.tr, rb.te if Cd else None, rb.rows[s:e].contiguous()))
     B = len(batches[0])                                        # users per GPU per step (this rank)
     torch.manual_seed(1000 + rank)
@@ -260,7 +285,10 @@ def main():
         return
     elapsed = float(np.median(wins))
     ms_step = elapsed / args.steps * 1e3
-    value = global_batch * args.steps / elapsed
+    # (emulation: ONE GPU's share of the job is measured; the job-level figure would be users_here * G / time only if the
+    #  exchange itself were free -- it is reported as what this GPU processed)
+    value = (B if emu else global_batch) * args.steps / elapsed
+    sparse_first = bool(eng.get_option("last_sparse_in"))
     step_bytes, step_flops = eng.step_cost(B)
     P = sum(p.numel() for p in net.parameters())
     traffic = None
@@ -272,7 +300,7 @@ def main():
         # Adam reads p,g,m,v (16 B/param) and writes p,m,v (12 B/param); with the bf16 gradient exchange of the
         # data-parallel bf16 mode the reduced gradient is read as bf16 (2 B/param less); a sharded optimizer touches P / N
         per_param = 26.0 if dp and args.numerics == "bf16" else 28.0
-        shard = world if (dp and args.sharded) else 1
+        shard = (emu or world) if (dp and args.sharded) else 1
         kbytes = per_param * P / shard
         kname = "k_adam (multi-tensor Adam + compute-copy refresh)"
         kus, kn = adam_us, adam_n
@@ -287,13 +315,19 @@ def main():
         kbytes = 24.0 * I * H
         kname = ("rtx_dw_tn / rtx_dw_tn_group <64x128, RTX_DW_ADAM> (weight gradient fused with Adam: the decoder n_items x 600 matrix on "
                  "the side stream, the encoder matrix + the hidden layers' in one launch on the caller's; 2 launches/step)")
-        pmc = os.path.join(ROOT, "profiles", "r2_pmc_dw_adam.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+    traffic_src = None
+    if args.pmc_json:
+        # HBM bytes come from PMC counters, which need rocprofv3 --pmc passes of their own (tools/pmc_bench.sh): a companion
+        # run of the same build, named here -- never a constant
+        pj = json.load(open(args.pmc_json))
+        traffic, traffic_src = pj.get("hbm_bytes_per_launch"), {"file": os.path.relpath(args.pmc_json, ROOT), "git": pj.get("git")}
     achieved = kbytes / (kus * 1e-6) / 1e9 if kus else None
+    # flops actually executed: the sparse first layer replaces the dense forward product 2 * B * I_in * H by ~2 * nnz * H
+    exec_flops = step_flops
+    if sparse_first:
+        nnz_b = float(X.nnz) / X.shape[0] * B          # stored entries of a batch (dropped ones are still walked, as zeros)
+        exec_flops = step_flops - 2.0 * B * (I + Cd) * H + 2.0 * nnz_b * H
+    mode = ("emulated rank 0 of %d" % emu) if emu else ("dp%d" % world)
     out = {
         "metric": ("CMultiVAE (cond_dim=%d) " % Cd if Cd else "MultiVAE ") + "train users/sec on %s (synthetic, %s-shaped)"
                   % (("ml-20m", "ml-20m") if args.workload == "ml20m" else ("netflix", "Netflix-prize")),
@@ -304,7 +338,10 @@ def main():
                                "beta 0.2 anneal 100000, Adam lr 1e-3 (BASELINE.json configs[%d])"
                                % (I, "ml-20m" if args.workload == "ml20m" else "Netflix", args.users, I, B,
                                   1 if args.workload == "ml20m" else 3),
-                   "global_batch": global_batch, "parallelism": "dp%d" % world + ("-sharded-adam" if dp and args.sharded else ""),
+                   "global_batch": global_batch,
+                   "parallelism": mode + (("-sharded-adam" if args.sharded else "-replicated-adam") if dp else ""),
+                   "dp_scheduler": (None if not dp else ("engine (%s)" % plan.transport if getattr(plan, "native", False) else "python reducer")),
+                   "first_layer": "sparse (k_spmm_in, VALU)" if sparse_first else "dense (MFMA split-K GEMM)",
                    "numerics": "bf16 MFMA operands, f32 accumulate, f32 master weights + Adam" if args.numerics == "bf16"
                                else "f32 MFMA (parity mode)"},
         "windows": {"n": args.windows, "steps_each": args.steps, "seconds": wins, "reported": "median"},
@@ -312,15 +349,34 @@ def main():
         "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_TBS * 1000.0, "unit": "GB/s",
                      "frac": (achieved / (HBM_PEAK_TBS * 1000.0)) if achieved else None,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": kbytes, "avg_us": kus, "launches_timed": kn,
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": kbytes, "avg_us": kus, "launches_timed": kn,
                      "timed_every": args.kernel_timing_every},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
                           "frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000.0),
-                          "algorithmic_flops_per_step": step_flops,
-                          "achieved_TFLOPs": step_flops / (ms_step * 1e-3) / 1e12,
-                          "frac_of_bf16_mfma_peak": step_flops / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF},
+                          "algorithmic_flops_per_step": step_flops, "executed_flops_per_step": exec_flops,
+                          "achieved_TFLOPs": exec_flops / (ms_step * 1e-3) / 1e12,
+                          "frac_of_bf16_mfma_peak": exec_flops / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF},
         "mean_loss": loss_mean,
     }
+    if world == 1 and not dp and args.numerics == "bf16" and not args.no_extras and not Cd:
+        # (a) the same steps through the PUBLIC train_batch (reference models.py:835: `return loss.item()` -- one host sync per step)
+        k_api = max(10, min(args.steps, 100))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k_api):
+            model.train_batch(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        e_api = time.perf_counter() - t0
+        out["train_batch_api"] = {"value": global_batch * k_api / e_api, "unit": "users/s", "ms_per_step": e_api / k_api * 1e3, "steps": k_api,
+                                  "what": "MultiVAE.train_batch(rows) per step, returning loss.item() like the reference (models.py:835)"}
+        # (b) A/B of the first layer: the dense MFMA split-K product instead of the sparse VALU product
+        if sparse_first:
+            eng.set_option("sparse_in", 0)
+            run(5, 0)
+            wd = timed_windows(run, k_api, 2, 1, 5)
+            eng.set_option("sparse_in", 1)
+            out["first_layer_dense_mfma"] = {"ms_per_step": float(np.median(wd)) / k_api * 1e3, "steps": k_api,
+                                             "frac_of_bf16_mfma_peak": step_flops / (float(np.median(wd)) / k_api) / 1e12 / MFMA_BF16_PEAK_TF}
     if world == 1 and not dp and args.numerics == "bf16" and not args.no_fp32_parity and not Cd:
         # the float32 parity mode (exact-f32 MFMA, the arithmetic the 1e-5 logits criterion is met in): same workload, a
         # shorter sample; bound by the f32 MFMA rate ("two numerics modes ... report both")

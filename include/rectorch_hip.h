@@ -180,6 +180,52 @@ int rtx_comm_reduce_scatter(rtx_comm* c, void* buf, int64_t n_total, int32_t dty
 /* bytes_total = world equal blocks; block r is replaced by rank r's block on every rank */
 int rtx_comm_allgather(rtx_comm* c, void* buf, int64_t bytes_total, void* stream);
 
+/* several collectives issued between start and end go to RCCL as one group (ncclGroupStart / ncclGroupEnd) */
+int rtx_comm_group_start(rtx_comm* c);
+int rtx_comm_group_end(rtx_comm* c);
+
+/* ---- the data-parallel step scheduled by the ENGINE (round 3; the reference has no counterpart) ----------------
+ * rtx_engine_train_step_dp is train_batch for one rank of a data-parallel job: forward + loss + backward on this rank's
+ * users (step->inv_batch = 1 / GLOBAL batch), the gradient exchange and the optimizer, all enqueued by ONE call -- no host
+ * callback, no per-bucket event created per step.  The gradients leave the weight-gradient kernels as the images the
+ * collectives send (engine-owned exchange buffer, comm_dtype), in two buckets: the decoder matrix (+ its bias) on the engine's
+ * side stream beside the data-gradient chain, everything else behind the chain on the caller's stream.
+ *   sharded = 0: all-reduce, then Adam on every rank (replicated weights stay bit-identical);
+ *   sharded = 1: a big weight matrix's region (rows padded to a multiple of 128: equal blocks) is reduce-scattered, Adam runs
+ *                on this rank's rows only -- the optimizer's 28 B/param of HBM traffic shrink by the number of ranks -- and the
+ *                compute copy is all-gathered in place; biases and small layers are all-reduced and replicated.  The float32
+ *                master rows / Adam moments of the OTHER ranks' rows go stale on this rank (rtx_engine_dp_owned_rows says which
+ *                rows are current); gather them before reading parameters from the host side.
+ * Collectives: an RCCL communicator (rtx_comm_init), or caller-supplied functions (any transport: the tests use
+ * torch.distributed/gloo), or -- emulate = 1 -- none at all: every collective is replaced by device copies of the bytes one
+ * rank of `world` would move and Adam runs on 1/world of the rows: the HBM cost of rank 0's step on ONE GPU (timing only: the
+ * other ranks' rows are never updated). */
+typedef struct {
+    /* all IN PLACE on `buf`, enqueued on `stream`; dtype RTX_FP32 | RTX_BF16; return 0 on success.
+     * reduce_scatter: n_total = world equal blocks, block `rank` receives the sum; all_gather: bytes_total = world equal
+     * blocks, block r is replaced by rank r's */
+    int (*all_reduce)(void* ctx, void* buf, int64_t n, int32_t dtype, void* stream);
+    int (*reduce_scatter)(void* ctx, void* buf, int64_t n_total, int32_t dtype, void* stream);
+    int (*all_gather)(void* ctx, void* buf, int64_t bytes_total, void* stream);
+    int (*group_start)(void* ctx); /* nullable */
+    int (*group_end)(void* ctx);   /* nullable */
+    void* ctx;
+} rtx_dp_ops;
+typedef struct {
+    int32_t rank, world;
+    int32_t sharded;       /* 0 | 1 (above) */
+    int32_t comm_dtype;    /* RTX_FP32 (exact sums: parity) | RTX_BF16 (half the bytes on xGMI) */
+    int32_t emulate;       /* 1: no communicator, device copies of the same size (timing of rank 0's step on one GPU) */
+    rtx_comm* comm;        /* RCCL communicator, or NULL when ops / emulate is given */
+    const rtx_dp_ops* ops; /* caller-supplied collectives (copied), or NULL */
+} rtx_dp_cfg;
+int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg /* NULL detaches */);
+int rtx_engine_train_step_dp(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
+                             void* stream);
+/* rows [row_lo, row_hi) of layer `layer`'s weight matrix whose float32 master / Adam state this rank keeps current
+ * (everything when the layer is not sharded); sharded_out: 1 if the layer is sharded */
+int rtx_engine_dp_owned_rows(const rtx_engine* e, int32_t layer, int32_t* row_lo, int32_t* row_hi, int32_t* sharded_out);
+
 /* float32 -> bfloat16 (round to nearest even) of n contiguous elements: stages a gradient bucket for a bf16 all-reduce */
 int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* both of the above: one full train_batch */
@@ -275,6 +321,8 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * pass / of the data-gradient chain as one register-resident launch each -- small_layers.hip -- for padded widths <= 1024).
  * Replaces round 1's RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
+/* the current value of a knob; also "last_sparse_in": 1 when the last forward pass ran the first layer as the sparse product */
+int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */
 /* enable: 0 = off, 1 = every launch of the site, N > 1 = every N-th launch (two event records cost a few microseconds of the

@@ -54,6 +54,22 @@ class Step(C.Structure):
 
 LAYER_CB = C.CFUNCTYPE(None, C.c_int32, C.c_void_p)
 
+# caller-supplied collectives of the engine-scheduled data-parallel step (rtx_dp_ops)
+DP_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)   # all_reduce / reduce_scatter
+DP_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)              # all_gather
+DP_GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class DpOps(C.Structure):
+    _fields_ = [("all_reduce", DP_REDUCE_FN), ("reduce_scatter", DP_REDUCE_FN), ("all_gather", DP_GATHER_FN),
+                ("group_start", DP_GROUP_FN), ("group_end", DP_GROUP_FN), ("ctx", C.c_void_p)]
+
+
+class DpCfg(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("sharded", C.c_int32), ("comm_dtype", C.c_int32),
+                ("emulate", C.c_int32), ("comm", C.c_void_p), ("ops", C.POINTER(DpOps))]
+
+
 # every symbol include/rectorch_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -86,6 +102,11 @@ SIGNATURES = {
     "rtx_comm_allreduce_many": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     "rtx_comm_reduce_scatter": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "rtx_comm_allgather": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "rtx_comm_group_start": (C.c_int, [_P]),
+    "rtx_comm_group_end": (C.c_int, [_P]),
+    "rtx_engine_dp_attach": (C.c_int, [_P, C.POINTER(DpCfg)]),
+    "rtx_engine_train_step_dp": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
+    "rtx_engine_dp_owned_rows": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
@@ -106,6 +127,7 @@ SIGNATURES = {
     "rtx_svae_train_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(Step), _P, _P, _P]),
     "rtx_svae_train_pack": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.POINTER(Step), _P, _P, _P]),
     "rtx_engine_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "rtx_engine_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "rtx_engine_set_timing": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "rtx_engine_get_timings": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(C.c_int32)]),
     "rtx_engine_step_cost": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

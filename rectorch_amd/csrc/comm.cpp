@@ -176,6 +176,20 @@ int rtx_comm_allreduce_many(rtx_comm* c, void* const* bufs, const int64_t* count
     return RTX_OK;
 }
 
+int rtx_comm_group_start(rtx_comm* c)
+{
+    RTX_CHECK(c, RTX_EINVAL, "comm is NULL");
+    RTX_NCCL(g_api.GroupStart());
+    return RTX_OK;
+}
+
+int rtx_comm_group_end(rtx_comm* c)
+{
+    RTX_CHECK(c, RTX_EINVAL, "comm is NULL");
+    RTX_NCCL(g_api.GroupEnd());
+    return RTX_OK;
+}
+
 int rtx_comm_rank(const rtx_comm* c, int32_t* rank, int32_t* world)
 {
     RTX_CHECK(c, RTX_EINVAL, "comm is NULL");

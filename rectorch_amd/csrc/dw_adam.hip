@@ -406,24 +406,37 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     return dw_launch_cfg<RTX_DW_GRAD>(d, cfg, stream);
 }
 
-// d[0..n): same d.k_slices; small problems first keeps the big one's tail free of stragglers
+// d[0..n): same d.k_slices; small problems first keeps the big one's tail free of stragglers.  RTX_DW_GRAD groups serve the
+// data-parallel step (gradients leave as the float32 / bf16 images the exchange sends).
+template <int EPI> static int dw_launch_group_cfg(const RtxDw* d, int n, int cfg, hipStream_t stream)
+{
+    switch (cfg) {
+    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, EPI>(d, n, stream);
+    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, EPI>(d, n, stream);
+    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, EPI>(d, n, stream);
+    default: return dw_launch_group<2, 4, 3, EPI>(d, n, stream);
+    }
+}
+
 int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_t stream)
 {
     RTX_CHECK(d && n >= 1 && n <= RTX_DW_GROUP_MAX, RTX_EINVAL, "dw group: 1..%d problems (got %d)", RTX_DW_GROUP_MAX, n);
     if (n == 1) return rtx_dw_launch(d[0], epilogue, cfg, stream);
-    RTX_CHECK(epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw group: only the fused Adam epilogue is launched in groups");
+    RTX_CHECK(epilogue == RTX_DW_ADAM || epilogue == RTX_DW_GRAD, RTX_EINVAL, "dw group: bad epilogue %d", epilogue);
     RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     for (int k = 0; k < n; ++k) {
         const RtxDw& q = d[k];
         RTX_CHECK(q.A && q.B && q.m_tiles > 0 && q.n_tiles > 0 && q.k_slices >= 2 && q.k_slices == d[0].k_slices, RTX_EINVAL, "dw group: bad problem %d", k);
-        RTX_CHECK(q.M_real >= 1 && (q.N_real & 3) == 0 && q.N_real >= 4 && q.adam.p && q.adam.m && q.adam.v, RTX_EINVAL, "dw group: problem %d is not fusable", k);
-        RTX_CHECK((((uintptr_t)q.adam.p | (uintptr_t)q.adam.m | (uintptr_t)q.adam.v | (uintptr_t)q.adam.gkeep) & 15) == 0, RTX_EINVAL,
-                  "dw: Adam buffers must be 16-byte aligned");
+        RTX_CHECK(q.M_real >= 1 && q.N_real >= 1, RTX_EINVAL, "dw group: problem %d is empty", k);
+        if (epilogue == RTX_DW_ADAM) {
+            RTX_CHECK((q.N_real & 3) == 0 && q.N_real >= 4 && q.adam.p && q.adam.m && q.adam.v, RTX_EINVAL, "dw group: problem %d is not fusable", k);
+            RTX_CHECK((((uintptr_t)q.adam.p | (uintptr_t)q.adam.m | (uintptr_t)q.adam.v | (uintptr_t)q.adam.gkeep) & 15) == 0, RTX_EINVAL,
+                      "dw: Adam buffers must be 16-byte aligned");
+        } else {
+            RTX_CHECK((q.N_real & 3) != 0 || ((((uintptr_t)q.gW) & 15) == 0 && (((uintptr_t)q.g16) & 7) == 0), RTX_EINVAL,
+                      "dw: gradient buffers must be 16-byte aligned");
+        }
     }
-    switch (cfg) {
-    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, RTX_DW_ADAM>(d, n, stream);
-    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, RTX_DW_ADAM>(d, n, stream);
-    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, RTX_DW_ADAM>(d, n, stream);
-    default: return dw_launch_group<2, 4, 3, RTX_DW_ADAM>(d, n, stream);
-    }
+    if (epilogue == RTX_DW_ADAM) return dw_launch_group_cfg<RTX_DW_ADAM>(d, n, cfg, stream);
+    return dw_launch_group_cfg<RTX_DW_GRAD>(d, n, cfg, stream);
 }

@@ -57,6 +57,24 @@ struct TempCsr {  // dense batch converted to CSR on the device
     int64_t cap = 0;
 };
 
+// data-parallel step scheduled by the engine (rtx_engine_dp_attach): the exchange buffer every gradient is produced into, in
+// comm dtype.  Layout (elements; every tensor starts at a multiple of 64): W[NL-1], b[NL-1], W[NL-2], b[NL-2], ..., W[1], b[1],
+// b[0], W[0] -- bucket A (the decoder matrix, exchanged on the side stream beside the data-gradient chain) first, bucket B
+// (everything else, behind the chain) after it, the sharded encoder matrix last so that the replicated tensors of a bucket
+// form ONE contiguous all-reduce range.  A sharded matrix's region is rows padded to P(out) = roundup(out + 1, 128) (zeros):
+// world equal row blocks.
+struct DpState {
+    bool on = false;
+    rtx_dp_cfg cfg = {};
+    rtx_dp_ops ops = {};
+    void* xg = nullptr;                       // exchange buffer, comm dtype
+    size_t xbytes = 0, xesz = 4;
+    size_t xoff[2 * 2 * RTX_MAX_LAYERS] = {};   // element offset of tensor t
+    bool shard[2 * RTX_MAX_LAYERS] = {};        // per layer: weight matrix reduce-scattered / updated by rows / all-gathered
+    void* emu_scratch = nullptr;              // emulate: where the stand-in copies go
+    size_t emu_bytes = 0;
+};
+
 struct rtx_engine {
     rtx_cfg cfg;
     int NL = 0, I = 0, Z = 0, Ip = 0, Zp = 0;
@@ -96,6 +114,7 @@ struct rtx_engine {
     int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
     int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_layers.hip)
     int opt_small_bwd = 1;      // ... and of the data-gradient chain (reads the transposed compute copies of the hidden layers)
+    int last_sparse_in = 0;     // what the last forward pass did with the first layer (rtx_engine_get_option "last_sparse_in")
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
     // timing
@@ -104,6 +123,7 @@ struct rtx_engine {
     std::map<std::string, long> timing_seen;
     std::map<std::string, TimingSite> sites;
     std::vector<hipEvent_t> event_pool;
+    DpState dp;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -389,6 +409,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     if (!step) step = &zero_step;
     int64_t in_chunks = 0;
     const bool sparse_in = l0 == 0 && l1 > 1 && sparse_in_ok(e, in, Bp, &in_chunks);
+    if (l0 == 0) e->last_sparse_in = sparse_in;
     if (l0 == 0 && !sparse_in) {
         Layer& l = e->L[0];
         RtxGatherArgs a = {};
@@ -586,7 +607,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 4; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region
+int32_t rtx_abi_version(void) { return 5; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step)
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -849,18 +870,39 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && (l.in & 3) == 0 && l.in >= 4; }
 static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
 
+// tensors of the exchange buffer in layout order (DpState): W[NL-1], b[NL-1], ..., W[1], b[1], b[0], W[0]
+static int dp_layout_order(const rtx_engine* e, int* order)
+{
+    int n = 0;
+    for (int li = e->NL - 1; li >= 1; --li) { order[n++] = 2 * li; order[n++] = 2 * li + 1; }
+    order[n++] = 1;
+    order[n++] = 0;
+    return n;
+}
+static size_t dp_region_elems(const rtx_engine* e, const DpState& d, int t)
+{
+    const Layer& l = e->L[t / 2];
+    if (t & 1) return (size_t)l.out;
+    return (size_t)(d.shard[t / 2] ? l.outp : l.out) * l.in;
+}
+
 static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
-                           rtx_layer_cb cb, void* user, hipStream_t st, bool fuse)
+                           rtx_layer_cb cb, void* user, hipStream_t st, bool fuse, DpState* dp = nullptr)
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
     const bool dae_reg = !e->vae && step->lam != 0.f;
+    if (dp && dae_reg)   // lam * W / ||W|| needs the norm of the WHOLE matrix; a rank of the sharded optimizer holds current rows of its shard only
+        for (int li = 0; li < e->NL; ++li)
+            RTX_CHECK(!dp->shard[li], RTX_EINVAL, "data parallel: Mult-DAE's norm regulariser (lam != 0) needs whole master matrices; attach with sharded = 0");
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in = {}, tg = {};
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
     const int B = batch->batch, Bp = rtx_pad_batch(B), NL = e->NL;
     // (see below for what the two streams do)
-    const bool two = fuse && e->opt_two_stream;
+    // (data parallel: the second stream carries the decoder matrix's weight kernel, its exchange and its optimizer pass; the
+    //  float32 parity mode keeps one compute copy per matrix and therefore one stream)
+    const bool two = (fuse || (dp && e->bf16)) && e->opt_two_stream;
     if (two && !e->side) {
         // lowest priority: the long streaming kernels take the workgroup slots the short launches of the chain leave free,
         // not the other way round (with equal priorities the chain's kernels waited for slots: k_reduce_loss 17 us, k_post
@@ -872,7 +914,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     }
-    const int main_li = (two && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
+    const int main_li = (two && fuse && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
     if (dae_reg) {
         TIMED("sumsq");
@@ -905,7 +947,14 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     // layers' weight kernels with it in the same launch (as launches of their own beside it they crawl: 53 + 33 us).
     // (a hidden layer keeps ONE transposed compute copy, WshT, which its fused optimizer epilogue overwrites and the chain's
     // k_bwd_hidden reads: such a layer's weight kernel must stay behind the chain on the caller's stream)
-    auto on_side = [&](int li) { return two && layer_is_big(e->L[li]) && li != main_li && !e->L[li].WshT; };
+    auto on_side = [&](int li) {
+        if (dp) return two && NL >= 2 && li == NL - 1 && layer_is_big(e->L[li]) && !e->L[li].WshT;   // bucket A of the exchange
+        return two && layer_is_big(e->L[li]) && li != main_li && !e->L[li].WshT;
+    };
+    const bool keep_grads = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
+    // data parallel: where tensor t's gradient is produced (the exchange buffer, in comm dtype)
+    auto xg16 = [&](int t) { return (bf16_t*)dp->xg + dp->xoff[t]; };
+    auto xg32 = [&](int t) { return (float*)dp->xg + dp->xoff[t]; };
     auto reduce_loss = [&](hipStream_t ws) -> int {
         ScopedTimer tm(e, "reduce_loss", ws);
         const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);
@@ -935,6 +984,15 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             d.adam.sumsq = dae_reg ? e->sumsq + 2 * li : nullptr;
             d.bias_p = e->params[2 * li + 1]; d.bias_m = e->m[2 * li + 1]; d.bias_v = e->v[2 * li + 1];
             d.bias_sumsq = dae_reg ? e->sumsq + 2 * li + 1 : nullptr;
+        } else if (dp) {
+            // the gradient leaves the kernel as the image the exchange sends; RTX_STEP_KEEP_GRADS also stores this rank's own
+            // (unreduced) float32 gradient in the bound buffers
+            if (dp->cfg.comm_dtype == RTX_BF16) {
+                d.g16 = xg16(2 * li); d.gbias16 = xg16(2 * li + 1);
+                if (keep_grads) { d.gW = e->grads[2 * li]; d.gbias = e->grads[2 * li + 1]; }
+            } else {
+                d.gW = xg32(2 * li); d.gbias = xg32(2 * li + 1);
+            }
         } else if ((step->flags & RTX_STEP_GRADS_BF16) && !e->grads16.empty()) {
             // data-parallel bf16 exchange: the gradient leaves the kernel as the bf16 image the all-reduce sends (no float32
             // store, no cast pass)
@@ -959,9 +1017,96 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         g.A = l.D; g.lda = l.outp; g.B = l.A; g.ldb = l.inp;
         g.k_slices = Bp / 32; g.tile_shape = RTX_TILE_128x128; g.m_tiles = l.outp / 128; g.n_tiles = l.inp / 128;
         g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
+        if (dp && dp->cfg.comm_dtype == RTX_FP32) { g.C = xg32(2 * li); g.gbias = xg32(2 * li + 1); }
         g.M_real = l.out; g.N_real = l.in;
         return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
     };
+    // ---- data parallel: exchange + optimizer of layers [l_lo, l_hi) on stream ws; `alt`: the big matrices' Adam writes the NEXT
+    //      step's compute copy (the chain on the other stream still reads this step's) -------------------------------------------
+    auto dp_bucket = [&](int l_lo, int l_hi, hipStream_t ws, bool alt) -> int {
+        DpState& d = *dp;
+        const int cdt = d.cfg.comm_dtype;
+        int order[2 * 2 * RTX_MAX_LAYERS];
+        const int n_order = dp_layout_order(e, order);
+        auto in_bucket = [&](int t) { return t / 2 >= l_lo && t / 2 < l_hi; };
+        // (1) staging: float32 numerics with a bf16 exchange cast their gradients; a float32 exchange hands the caller its copy
+        for (int q = 0; q < n_order; ++q) {
+            const int t = order[q];
+            if (!in_bucket(t)) continue;
+            const Layer& l = e->L[t / 2];
+            const size_t n = (t & 1) ? (size_t)l.out : (size_t)l.out * l.in;
+            if (!e->bf16 && cdt == RTX_BF16) RTX_TRY(rtx_launch_cast_f32_bf16(e->grads[t], xg16(t), (long)n, ws));
+            else if (keep_grads && cdt == RTX_FP32) RTX_HIP(hipMemcpyAsync(e->grads[t], xg32(t), n * sizeof(float), hipMemcpyDeviceToDevice, ws));
+        }
+        // (2) exchange: reduce-scatter of every sharded matrix, one all-reduce per contiguous run of replicated tensors
+        {
+            ScopedTimer tm(e, "dp_exchange", ws);
+            if (d.ops.group_start) RTX_CHECK(d.ops.group_start(d.ops.ctx) == 0, RTX_EHIP, "data parallel: group_start failed: %s", rtx_last_error_str());
+            long run_lo = -1, run_hi = -1;
+            auto flush = [&]() -> int {
+                if (run_lo >= 0 && run_hi > run_lo)
+                    RTX_CHECK(d.ops.all_reduce(d.ops.ctx, (char*)d.xg + (size_t)run_lo * d.xesz, run_hi - run_lo, cdt, ws) == 0, RTX_EHIP,
+                              "data parallel: all_reduce failed: %s", rtx_last_error_str());
+                run_lo = run_hi = -1;
+                return RTX_OK;
+            };
+            for (int q = 0; q < n_order; ++q) {
+                const int t = order[q];
+                const bool sharded_w = !(t & 1) && d.shard[t / 2];
+                if (!in_bucket(t) || sharded_w) {
+                    RTX_TRY(flush());
+                    if (in_bucket(t))
+                        RTX_CHECK(d.ops.reduce_scatter(d.ops.ctx, (char*)d.xg + d.xoff[t] * d.xesz, (int64_t)dp_region_elems(e, d, t), cdt, ws) == 0,
+                                  RTX_EHIP, "data parallel: reduce_scatter failed: %s", rtx_last_error_str());
+                    continue;
+                }
+                if (run_lo < 0) run_lo = (long)d.xoff[t];
+                run_hi = (long)(d.xoff[t] + dp_region_elems(e, d, t));
+            }
+            RTX_TRY(flush());
+            if (d.ops.group_end) RTX_CHECK(d.ops.group_end(d.ops.ctx) == 0, RTX_EHIP, "data parallel: group_end failed: %s", rtx_last_error_str());
+        }
+        // (3) Adam: replicated tensors in full, a sharded matrix on this rank's rows
+        RtxAdamArgs a = {};
+        int ids[RTX_MAX_TENSORS];
+        for (int li = l_lo; li < l_hi; ++li) {
+            Layer& l = e->L[li];
+            RtxAdamArgs one = {};
+            fill_adam_tensors(e, one, li, li + 1);
+            RtxAdamTensor w = one.t[0], b = one.t[1];
+            if (cdt == RTX_BF16) { w.g16 = xg16(2 * li); b.g16 = xg16(2 * li + 1); }
+            else { w.g = xg32(2 * li); b.g = xg32(2 * li + 1); }
+            if (alt && l.Wsh_alt) w.sh = l.Wsh_alt;
+            bool any_w = true;
+            if (d.shard[li]) {
+                const int per = l.outp / d.cfg.world;
+                const int lo = d.cfg.rank * per, hi = std::min((d.cfg.rank + 1) * per, l.out);   // padding rows hold no parameters
+                any_w = lo < hi;
+                const size_t off = (size_t)lo * l.in;
+                w.p += off; w.m += off; w.v += off;
+                if (w.g16) w.g16 += off; else w.g += off;
+                w.sh = (char*)w.sh + (size_t)lo * l.inp * e->esz;
+                w.rows = any_w ? hi - lo : 0;
+            }
+            if (any_w) { ids[a.n] = 2 * li; a.t[a.n++] = w; }
+            ids[a.n] = 2 * li + 1; a.t[a.n++] = b;
+        }
+        fill_adam_scalars(e, step, a, 0, ids);
+        {
+            ScopedTimer tm(e, "adam", ws);
+            RTX_TRY(rtx_launch_adam(a, e->bf16, ws));
+        }
+        // (4) the other ranks' rows of the compute copy
+        for (int li = l_lo; li < l_hi; ++li)
+            if (d.shard[li]) {
+                Layer& l = e->L[li];
+                ScopedTimer tm(e, "dp_allgather", ws);
+                RTX_CHECK(d.ops.all_gather(d.ops.ctx, (alt && l.Wsh_alt) ? l.Wsh_alt : l.Wsh, (int64_t)((size_t)l.outp * l.inp * e->esz), ws) == 0,
+                          RTX_EHIP, "data parallel: all_gather failed: %s", rtx_last_error_str());
+            }
+        return RTX_OK;
+    };
+    const bool dp_side = dp && on_side(NL - 1);
     if (!two) RTX_TRY(reduce_loss(st));
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
@@ -969,6 +1114,10 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             RTX_HIP(hipEventRecord(e->ev_d[li], st));
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[li], 0));
             RTX_TRY(weight_grad(li, e->side));
+            if (dp) {   // bucket A: the decoder matrix's exchange and optimizer pass run beside the chain; the loss sum rides along
+                RTX_TRY(reduce_loss(e->side));
+                RTX_TRY(dp_bucket(li, li + 1, e->side, true));
+            }
         }
         // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
         // the weight kernel of this layer, whose fused optimizer epilogue overwrites the compute copy.
@@ -1021,7 +1170,31 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (cb) cb(li, user);
     }
     hipStream_t rs = st;    // the stream the leftover Adam launch runs on
-    if (two && main_li >= 0) {
+    if (dp) {
+        // bucket B behind the chain on the caller's stream: the remaining weight kernels (bf16: grouped launches), their exchange,
+        // their optimizer pass -- the END of the step's critical path, so no stream hop before or between them
+        const int b_hi = dp_side ? NL - 1 : NL;
+        if (two) {
+            RtxDw grp[RTX_DW_GROUP_MAX];
+            int ng = 0;
+            for (int li = b_hi - 1; li >= 0; --li) {
+                make_dw(li, grp[ng++]);
+                if (ng == RTX_DW_GROUP_MAX || li == 0) {
+                    ScopedTimer tm(e, "gemm_dW_in", st);
+                    RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_GRAD, e->opt_dw_cfg, st));
+                    ng = 0;
+                }
+            }
+            if (!dp_side) RTX_TRY(reduce_loss(st));
+        }
+        RTX_TRY(dp_bucket(0, b_hi, st, false));
+        if (dp_side) {
+            std::swap(e->L[NL - 1].Wsh, e->L[NL - 1].Wsh_alt);
+            RTX_HIP(hipEventRecord(e->ev_done, e->side));
+            RTX_HIP(hipStreamWaitEvent(st, e->ev_done, 0));
+        }
+        e->shadows_valid = true;
+    } else if (two && main_li >= 0) {
         // behind the chain, on this stream: the encoder matrix's kernel and the small layers' (their compute copies have no
         // reader left) ...
         // ... ONE launch for the encoder matrix and the small fusable layers (small problems first); small layers that are not
@@ -1175,6 +1348,126 @@ int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream)
     return rtx_launch_cast_f32_bf16(src, dst, (long)n, (hipStream_t)stream);
 }
 
+// ---- data parallel: attach / step --------------------------------------------------------------------------------
+static int dp_rccl_all_reduce(void* c, void* buf, int64_t n, int32_t dt, void* st) { return rtx_comm_allreduce((rtx_comm*)c, buf, n, dt, st); }
+static int dp_rccl_reduce_scatter(void* c, void* buf, int64_t n, int32_t dt, void* st) { return rtx_comm_reduce_scatter((rtx_comm*)c, buf, n, dt, st); }
+static int dp_rccl_all_gather(void* c, void* buf, int64_t bytes, void* st) { return rtx_comm_allgather((rtx_comm*)c, buf, bytes, st); }
+static int dp_rccl_group_start(void* c) { return rtx_comm_group_start((rtx_comm*)c); }
+static int dp_rccl_group_end(void* c) { return rtx_comm_group_end((rtx_comm*)c); }
+
+// emulate: the bytes one rank of `world` sends + receives in a ring collective, as device-to-device copies through a scratch
+// buffer (reduce-scatter / all-gather: (world - 1) / world of the buffer read and written once; all-reduce: twice)
+static int dp_emu_move(DpState* d, void* buf, size_t bytes, bool back, hipStream_t st)
+{
+    const size_t w = (size_t)d->cfg.world;
+    size_t s = bytes / w * (w - 1);
+    s = std::min(s, d->emu_bytes) & ~(size_t)15;
+    if (s == 0) return RTX_OK;
+    char* rest = (char*)buf + (bytes - s);   // "the other ranks' blocks"
+    RTX_HIP(hipMemcpyAsync(d->emu_scratch, rest, s, hipMemcpyDeviceToDevice, st));
+    if (back) RTX_HIP(hipMemcpyAsync(rest, d->emu_scratch, s, hipMemcpyDeviceToDevice, st));   // (the same values: numerically a no-op)
+    return RTX_OK;
+}
+static int dp_emu_all_reduce(void* c, void* buf, int64_t n, int32_t dt, void* st)
+{
+    return dp_emu_move((DpState*)c, buf, (size_t)n * (dt == RTX_BF16 ? 2 : 4), true, (hipStream_t)st);
+}
+static int dp_emu_reduce_scatter(void* c, void* buf, int64_t n, int32_t dt, void* st)
+{
+    return dp_emu_move((DpState*)c, buf, (size_t)n * (dt == RTX_BF16 ? 2 : 4), false, (hipStream_t)st);
+}
+static int dp_emu_all_gather(void* c, void* buf, int64_t bytes, void* st) { return dp_emu_move((DpState*)c, buf, (size_t)bytes, false, (hipStream_t)st); }
+
+static void dp_release(rtx_engine* e)
+{
+    DpState& d = e->dp;
+    for (void* p : {d.xg, d.emu_scratch})
+        if (p) {
+            auto it = std::find(e->allocs.begin(), e->allocs.end(), p);
+            if (it != e->allocs.end()) e->allocs.erase(it);
+            (void)hipFree(p);
+        }
+    d = DpState();
+}
+
+int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    RTX_HIP(hipDeviceSynchronize());
+    dp_release(e);
+    if (!cfg) return RTX_OK;
+    RTX_CHECK(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, RTX_EINVAL, "dp_attach: rank %d of %d", cfg->rank, cfg->world);
+    RTX_CHECK(cfg->comm_dtype == RTX_FP32 || cfg->comm_dtype == RTX_BF16, RTX_EINVAL, "dp_attach: comm_dtype must be RTX_FP32 or RTX_BF16");
+    RTX_CHECK((cfg->emulate != 0) + (cfg->comm != nullptr) + (cfg->ops != nullptr) == 1, RTX_EINVAL,
+              "dp_attach: give exactly one of comm (RCCL), ops (caller's collectives) or emulate");
+    DpState& d = e->dp;
+    d.cfg = *cfg;
+    if (cfg->emulate) {
+        d.ops = rtx_dp_ops{dp_emu_all_reduce, dp_emu_reduce_scatter, dp_emu_all_gather, nullptr, nullptr, &e->dp};
+    } else if (cfg->comm) {
+        int32_t r = -1, w = -1;
+        RTX_TRY(rtx_comm_rank(cfg->comm, &r, &w));
+        RTX_CHECK(r == cfg->rank && w == cfg->world, RTX_EINVAL, "dp_attach: the communicator is rank %d of %d, the plan says %d of %d", r, w, cfg->rank, cfg->world);
+        d.ops = rtx_dp_ops{dp_rccl_all_reduce, dp_rccl_reduce_scatter, dp_rccl_all_gather, dp_rccl_group_start, dp_rccl_group_end, cfg->comm};
+    } else {
+        RTX_CHECK(cfg->ops->all_reduce && cfg->ops->reduce_scatter && cfg->ops->all_gather, RTX_EINVAL, "dp_attach: ops needs all_reduce, reduce_scatter and all_gather");
+        d.ops = *cfg->ops;
+    }
+    d.cfg.ops = nullptr;
+    d.xesz = cfg->comm_dtype == RTX_BF16 ? 2 : 4;
+    size_t biggest = 0;
+    for (int li = 0; li < e->NL; ++li) {
+        const Layer& l = e->L[li];
+        // a hidden layer that keeps a transposed compute copy (WshT) is never sharded: that copy is a column-block layout
+        d.shard[li] = cfg->sharded && layer_is_big(l) && !l.WshT && l.outp % cfg->world == 0;
+        biggest = std::max(biggest, (size_t)l.outp * l.inp * std::max(e->esz, d.xesz));
+    }
+    int order[2 * 2 * RTX_MAX_LAYERS];
+    const int n_order = dp_layout_order(e, order);
+    size_t off = 0;
+    for (int q = 0; q < n_order; ++q) {
+        d.xoff[order[q]] = off;
+        off += (dp_region_elems(e, d, order[q]) + 63) / 64 * 64;
+    }
+    d.xbytes = off * d.xesz;
+    RTX_TRY(dev_alloc(e, &d.xg, d.xbytes));
+    if (cfg->emulate) {
+        d.emu_bytes = biggest;
+        RTX_TRY(dev_alloc(e, &d.emu_scratch, d.emu_bytes, false));
+        // rows no rank updates here keep their weights in BOTH compute copies (the step alternates between them)
+        RTX_TRY(ensure_shadows(e, nullptr));
+        for (auto& l : e->L)
+            if (l.Wsh_alt) RTX_HIP(hipMemcpy(l.Wsh_alt, l.Wsh, (size_t)l.outp * l.inp * e->esz, hipMemcpyDeviceToDevice));
+    }
+    d.on = true;
+    return RTX_OK;
+}
+
+int rtx_engine_dp_owned_rows(const rtx_engine* e, int32_t layer, int32_t* row_lo, int32_t* row_hi, int32_t* sharded_out)
+{
+    RTX_CHECK(e && layer >= 0 && layer < e->NL, RTX_EINVAL, "dp_owned_rows: bad arguments");
+    const Layer& l = e->L[layer];
+    int lo = 0, hi = l.out, sh = 0;
+    if (e->dp.on && e->dp.shard[layer]) {
+        const int per = l.outp / e->dp.cfg.world;
+        lo = std::min(e->dp.cfg.rank * per, l.out);
+        hi = std::min((e->dp.cfg.rank + 1) * per, l.out);
+        sh = 1;
+    }
+    if (row_lo) *row_lo = lo;
+    if (row_hi) *row_hi = hi;
+    if (sharded_out) *sharded_out = sh;
+    return RTX_OK;
+}
+
+int rtx_engine_train_step_dp(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum, void* stream)
+{
+    RTX_TRY(check_ready(e, true));
+    RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "train_step_dp: step count must be >= 1");
+    RTX_CHECK(e->dp.on, RTX_ESTATE, "train_step_dp: rtx_engine_dp_attach() has not been called");
+    return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false, &e->dp);
+}
+
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                           void* stream)
 {
@@ -1223,6 +1516,29 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
         }
     } else {
         rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, sparse_in, small_fwd, small_bwd, dw_cfg, splitk)", key);
+        return RTX_EINVAL;
+    }
+    return RTX_OK;
+}
+
+int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
+{
+    RTX_CHECK(e && key && value, RTX_EINVAL, "get_option: NULL argument");
+    const std::string k(key);
+    if (k == "fuse_adam") *value = e->opt_fuse_adam;
+    else if (k == "lse_fuse") *value = e->opt_lse_fuse;
+    else if (k == "two_stream") *value = e->opt_two_stream;
+    else if (k == "side_low_prio") *value = e->opt_side_low_prio;
+    else if (k == "nt_regstage") *value = e->opt_nt_regstage;
+    else if (k == "in_on_main") *value = e->opt_in_on_main;
+    else if (k == "sparse_in") *value = e->opt_sparse_in;
+    else if (k == "small_fwd") *value = e->opt_small_fwd;
+    else if (k == "small_bwd") *value = e->opt_small_bwd;
+    else if (k == "dw_cfg") *value = e->opt_dw_cfg;
+    else if (k == "splitk") *value = e->cfg.splitk;
+    else if (k == "last_sparse_in") *value = e->last_sparse_in;   // 1: the last forward pass ran the first layer as the sparse product
+    else {
+        rtx_set_error("get_option: unknown key '%s'", key);
         return RTX_EINVAL;
     }
     return RTX_OK;

@@ -106,7 +106,7 @@ struct RtxDw {
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6
-// the same for up to RTX_DW_GROUP_MAX matrices in ONE launch (RTX_DW_ADAM only; equal k_slices)
+// the same for up to RTX_DW_GROUP_MAX matrices in ONE launch (equal k_slices, one epilogue)
 int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_t stream);
 
 // Gram matrix of the EASE solver (syrk.hip): C[m][n] = sum_k A[m][k] A[n][k] for the 128-column tiles on or below the

@@ -289,10 +289,41 @@ class Engine:
         check(lib().rtx_engine_train_step(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           stream_ptr()))
 
+    # ---- data parallel, scheduled by the engine (rtx_engine_dp_attach / rtx_engine_train_step_dp) --------------------
+    def dp_attach(self, plan):
+        """``plan``: a :class:`rectorch_amd.parallel.NativePlan` (rank, world, sharded, comm dtype and ONE of an RCCL
+        communicator, caller-supplied collectives, or emulation), or None to detach."""
+        if plan is None:
+            check(lib().rtx_engine_dp_attach(self.handle, None))
+            self._dp_plan = None
+            return
+        cfg = plan.c_cfg()
+        check(lib().rtx_engine_dp_attach(self.handle, C.byref(cfg)))
+        self._dp_plan = plan          # keeps the communicator / callback objects alive as long as the engine uses them
+
+    def train_step_dp(self, x, target, step, loss_out, loss_accum=None):
+        """one rank's train_batch of a data-parallel job: forward + loss + backward on this rank's users, the gradient exchange
+        and the optimizer in ONE call (``step.inv_batch`` = 1 / global batch)"""
+        keep = []
+        b = make_batch(x, target, keep=keep, n_items=self.n_items, n_in=self.n_in)
+        check(lib().rtx_engine_train_step_dp(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum), stream_ptr()))
+
+    def dp_owned_rows(self, layer):
+        """(row_lo, row_hi, sharded) of layer ``layer``'s weight matrix: the rows whose float32 master and Adam moments this rank
+        keeps current under the sharded optimizer"""
+        lo, hi, sh = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().rtx_engine_dp_owned_rows(self.handle, int(layer), C.byref(lo), C.byref(hi), C.byref(sh)))
+        return lo.value, hi.value, bool(sh.value)
+
     # ---- instrumentation --------------------------------------------------------------------------
     def set_option(self, key, value):
         """measurement knobs of the engine ("fuse_adam", "two_stream", "lse_fuse", "dw_cfg", "splitk", ...; include/rectorch_hip.h)"""
         check(lib().rtx_engine_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int32()
+        check(lib().rtx_engine_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
 
     def set_timing(self, site=None, enable=True):
         check(lib().rtx_engine_set_timing(self.handle, None if site is None else site.encode(), int(enable)))

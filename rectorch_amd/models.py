@@ -198,6 +198,7 @@ class AETrainer(TorchNNTrainer):
             for epoch in range(1, num_epochs + 1):
                 self.train_epoch(epoch, train_data, verbose)
                 if valid_data is not None:
+                    self.consolidate()          # (data parallel, sharded optimizer: every rank runs train() and gets here)
                     _validate(self, epoch, valid_data, valid_metric, valid_func)
         except KeyboardInterrupt:
             logger.warning('Handled KeyboardInterrupt: exiting from training early')
@@ -284,11 +285,12 @@ class AETrainer(TorchNNTrainer):
         st.adam_step += 1
         from .nets import draw_seed
         red = st.reducer
-        # data parallel, bf16 numerics and bf16 exchange with the optimizer behind each bucket: the weight-gradient kernels write
+        native = red is not None and getattr(red, "native", False)
+        # (python-driven reducer) data parallel, bf16 numerics and bf16 exchange with the optimizer behind each bucket: the weight-gradient kernels write
         # the bf16 images the all-reduce sends directly (no float32 gradient store, no cast pass); p.grad is not filled then
-        direct16 = (red is not None and self.numerics == "bf16" and red.flat16 is not None and red.on_device and
+        direct16 = (red is not None and not native and self.numerics == "bf16" and red.flat16 is not None and red.on_device and
                     getattr(red, "bucket_adam", False) and getattr(red, "allow_direct16", True) and not self.keep_grads)
-        if red is not None:
+        if red is not None and not native:
             red.direct16 = direct16
             eng.bind_grads16(red.grads16_ptrs() if direct16 else None)
         inj = self._rtx.inject or (None, None)     # (keep-mask uint8 [B, n_items], eps [B, latent]) for parity tests
@@ -304,6 +306,19 @@ class AETrainer(TorchNNTrainer):
         loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]
         if red is None:
             eng.train_step(x, target, step, loss_out, loss_acc)
+        elif native:
+            # the engine schedules the whole data-parallel step (rectorch_amd/parallel.py NativePlan): ONE call
+            if getattr(eng, "_dp_plan", None) is not red:
+                eng.dp_attach(red)                   # (a rebuilt engine -- a larger batch arrived -- attaches again)
+            try:
+                eng.train_step_dp(x, target, step, loss_out, loss_acc)
+            except _lib.RtxError:
+                if getattr(red, "error", None) is not None:
+                    raise red.error                  # a collective issued through torch.distributed failed: its own message
+                raise
+            if red.sharded and red.transport != "emulate":
+                st.masters_sharded = True
+                self.network._rtx_masters_stale = True
         else:
             if getattr(red, "bucket_adam", False):
                 g16 = red.grads16_ptrs()
@@ -316,6 +331,7 @@ class AETrainer(TorchNNTrainer):
                         None if g16 is None else g16[2 * layer], None if g16 is None else g16[2 * layer + 1])
                     red.shadow = eng.shadow_tensor
                     st.masters_sharded = True
+                    self.network._rtx_masters_stale = True
             else:
                 red.adam = None
             eng.loss_grads(x, target, step, loss_out, loss_acc, layer_cb=red.on_layer)
@@ -343,8 +359,11 @@ class AETrainer(TorchNNTrainer):
     # ----------------------------------------------------------------------------------- prediction
     def _predict_tuple(self, x, remove_train):
         _lib.require_gpu()
-        if self.predict_numerics != self.numerics:
-            self._gather_sharded_state()      # that engine's compute copies come from the float32 masters
+        if self._rtx.masters_sharded and self.predict_numerics != self.numerics:
+            # that engine's compute copies come from the float32 masters, of which this rank holds only its rows
+            raise _lib.RtxError("sharded optimizer: the float32 master rows of the other ranks are stale on this rank; call "
+                                "model.consolidate() on EVERY rank (it is a collective) before predict() in another numerics "
+                                "mode than the training one")
         self.network.eval()
         x_in = self.network._as_input(x)
         n = len(x_in) if isinstance(x_in, RowBatch) else x_in.shape[0]
@@ -364,14 +383,36 @@ class AETrainer(TorchNNTrainer):
         return (recon_x, )
 
     # -------------------------------------------------------------------------------- checkpointing
+    def consolidate(self):
+        """Data parallel with the sharded optimizer: every rank holds current float32 master rows (and Adam moments) only for
+        its own shard of the big matrices.  COLLECTIVE -- call it on EVERY rank -- before anything reads parameters from the
+        host side: checkpoints, ``state_dict()``, ``predict`` in another numerics mode, a larger batch (the engine is rebuilt
+        from the masters).  ``train()`` does so before each validation pass; ``save_model`` / ``predict`` raise when called with
+        stale rows.  A no-op without the sharded optimizer."""
+        self._gather_sharded_state()
+
     def _gather_sharded_state(self):
-        """Data parallel with the sharded optimizer: every rank holds current float32 rows (and Adam moments) only for
-        its own shard of the big matrices.  Collective: call on every rank before reading parameters from the host side
-        (checkpoints, ``state_dict()``, the float32 ``predict`` engine)."""
         st = self._rtx
         if st.reducer is None or not st.masters_sharded:
             return
         params = self.network._param_list()
+        if getattr(st.reducer, "native", False):
+            def tensors_n(layer):
+                p = params[2 * layer]
+                state = self.optimizer.state[p]
+                return [p.data, state['exp_avg'], state['exp_avg_sq']]
+            torch.cuda.current_stream().synchronize()
+            eng = self.network._rtx_engines[self.numerics]
+            st.reducer.gather_state(eng, tensors_n, len(params) // 2)
+            st.masters_sharded = False
+            self.network._rtx_masters_stale = False
+            keep = self.network._rtx_shadow_versions.get(self.numerics)
+            self.network._rtx_shadow_versions.clear()     # compute copies of the other numerics modes: refresh from the masters
+            if keep is not None:
+                # p.data was rewritten in place (version counters moved) with the values the training engine's compute copies
+                # already hold: that engine's copies stay valid
+                self.network._rtx_shadow_versions[self.numerics] = self.network._param_version()
+            return
 
         def tensors(layer):
             p = params[2 * layer]
@@ -380,7 +421,13 @@ class AETrainer(TorchNNTrainer):
         st.reducer.wait()
         st.reducer.gather_state(tensors)
         st.masters_sharded = False
+        self.network._rtx_masters_stale = False
         self.network._rtx_shadow_versions.clear()     # compute copies of the other numerics modes: refresh from the masters
+
+    def _require_consolidated(self, what):
+        if self._rtx.masters_sharded:
+            raise _lib.RtxError("sharded optimizer: %s() needs the float32 master rows of every rank; call model.consolidate() "
+                                "on EVERY rank first (it is a collective -- a rank-0-only checkpoint would deadlock inside it)" % what)
 
     def _sync_optimizer_state(self):
         """write the step count the fused Adam kernel is at into torch.optim.Adam's state"""
@@ -391,7 +438,7 @@ class AETrainer(TorchNNTrainer):
 
     def save_model(self, filepath, cur_epoch):
         r"""Save the model to file (reference models.py:475-489): ``epoch``, ``state_dict``, ``optimizer``."""
-        self._gather_sharded_state()
+        self._require_consolidated("save_model")
         self._sync_optimizer_state()
         state = {'epoch': cur_epoch,
                  'state_dict': self.network.state_dict(),
@@ -541,6 +588,7 @@ class MultiVAE(VAE):
             for epoch in range(1, num_epochs + 1):
                 self.train_epoch(epoch, train_data, verbose)
                 if valid_data:
+                    self.consolidate()          # (data parallel, sharded optimizer: every rank runs train() and gets here)
                     score = _validate(self, epoch, valid_data, valid_metric, valid_func)
                     if score > best:
                         self.save_model(best_path, epoch)
@@ -550,7 +598,7 @@ class MultiVAE(VAE):
 
     def save_model(self, filepath, cur_epoch):
         r"""Save the model to file (reference models.py:897-903): adds ``gradient_updates``."""
-        self._gather_sharded_state()
+        self._require_consolidated("save_model")
         self._sync_optimizer_state()
         state = {'epoch': cur_epoch,
                  'state_dict': self.network.state_dict(),

@@ -55,6 +55,7 @@ class AE_net(nn.Module):
         self.dec_dims = dec_dims
         self._rtx_engines = {}
         self._rtx_shadow_versions = {}
+        self._rtx_masters_stale = False     # data parallel, sharded optimizer: this rank's float32 masters hold only ITS rows
 
     def encode(self, x):
         raise NotImplementedError()
@@ -93,6 +94,12 @@ class AE_net(nn.Module):
         storage changes, shadows refreshed when the parameters were modified by anyone but the engine."""
         self._device()
         eng = self._rtx_engines.get(numerics)
+        if getattr(self, "_rtx_masters_stale", False) and (
+                eng is None or eng.max_batch < max_batch or self._rtx_shadow_versions.get(numerics) != self._param_version()):
+            # building an engine or refreshing its compute copies reads the float32 masters, of which this rank holds current
+            # values only for its own rows of the sharded matrices: wrong weights with no error otherwise
+            raise _lib.RtxError("sharded optimizer: an engine (%s numerics, batch %d) would be rebuilt from float32 masters whose "
+                                "rows of other ranks are stale; call model.consolidate() on EVERY rank first" % (numerics, max_batch))
         if eng is None or eng.max_batch < max_batch:
             mb = max(max_batch, DEFAULT_MAX_BATCH if eng is None else eng.max_batch)
             eng = Engine(self.enc_dims, self.dec_dims, self._variant, self.dropout.p, numerics, mb,

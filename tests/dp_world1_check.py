@@ -1,7 +1,8 @@
-"""Run by test_gpu_parity.py::test_dp_path_world1_rccl in its own process: the data-parallel step (per-layer callback ->
-RCCL all-reduce on a side stream -> per-bucket Adam on a third stream) with a world of ONE rank must reproduce the
-single-GPU step: exactly the golden G2 trajectory with the float32 exchange, and within bf16 rounding of the gradients
-with the bf16 exchange."""
+"""Run by test_gpu_parity.py::test_dp_path_world1_rccl in its own process: the data-parallel step with a world of ONE RCCL
+rank must reproduce the single-GPU step: exactly the golden G2 trajectory with the float32 exchange, and within bf16 rounding of
+the gradients with the bf16 exchange.  Both schedulers: "native" (the engine issues RCCL itself through its own communicator:
+rtx_engine_train_step_dp, one C call per step) and "python" (round 2's host-driven reducer: per-layer callback -> collective on
+a side stream -> per-bucket Adam on a third stream); in bf16 numerics the two must agree bit for bit."""
 import os
 import sys
 
@@ -23,7 +24,7 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype)
 
 
-def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False, numerics="fp32", direct16=True):
+def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False, numerics="fp32", direct16=True, engine="python"):
     enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
     beta, anneal, p, lr = [float(v) for v in g["meta"]]
     net = MultiVAE_net(dec, enc, dropout=p)
@@ -31,9 +32,13 @@ def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False, numerics="fp32", 
     net.to("cuda")
     model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics=numerics)
     if comm_dtype is not None:
-        red = parallel.attach(model, min_bucket_bytes=min_bucket, comm_dtype=comm_dtype, bucket_adam=bucket_adam, sharded=sharded)
-        red.allow_direct16 = direct16
-        assert len(red.buckets()) >= 2 and bool(red.shard_layers) == sharded
+        red = parallel.attach(model, min_bucket_bytes=min_bucket, comm_dtype=comm_dtype, bucket_adam=bucket_adam, sharded=sharded,
+                              engine=engine)
+        if engine == "python":
+            red.allow_direct16 = direct16
+            assert len(red.buckets()) >= 2 and bool(red.shard_layers) == sharded
+        else:
+            assert red.native and red.transport == "rccl" and red.sharded == sharded
     losses = []
     for t in range(g["xs"].shape[0]):
         model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), dev(g["eps_%d" % t]))
@@ -80,6 +85,24 @@ def main():
             assert np.array_equal(a, b), ("direct bf16 gradients must equal cast float32 gradients", sharded, k)
         for k, a, b in zip(keys, p_dir, one_params):
             assert float(np.max(np.abs(a - b))) < 3 * 1e-3 * 0.02 + 1e-6, (sharded, k, float(np.max(np.abs(a - b))))
+    # ---- the engine-scheduled step (rtx_engine_train_step_dp over the engine's own RCCL communicator) ------------------------
+    for sharded in (False, True):
+        losses, params = run(g, torch.float32, True, 256, sharded=sharded, engine="native")
+        assert losses == ref_losses, ("native", sharded, losses, ref_losses)
+        for k, a, b in zip(keys, params, ref_params):
+            assert np.array_equal(a, b), ("native fp32 exchange must be bit-identical to the single-GPU step", sharded, k)
+        losses, params = run(g, torch.bfloat16, True, 256, sharded=sharded, engine="native")
+        for k, a, b in zip(keys, params, ref_params):
+            assert float(np.max(np.abs(a - b))) < 3 * 1e-3 * 0.02 + 1e-6, ("native", sharded, k, float(np.max(np.abs(a - b))))
+        # bf16 numerics: the same bf16 gradient images, the same Adam kernel -> the same bits as the host-driven scheduler
+        l_nat, p_nat = run(g, torch.bfloat16, True, 256, sharded=sharded, numerics="bf16", engine="native")
+        l_py, p_py = run(g, torch.bfloat16, True, 256, sharded=sharded, numerics="bf16", direct16=True)
+        assert l_nat == l_py, (sharded, l_nat, l_py)
+        for k, a, b in zip(keys, p_nat, p_py):
+            assert np.array_equal(a, b), ("native and python schedulers must agree bit for bit", sharded, k)
+        l32, p32 = run(g, torch.float32, True, 256, sharded=sharded, numerics="bf16", engine="native")   # float32 exchange of bf16 numerics
+        for k, a, b in zip(keys, p32, one_params):
+            assert float(np.max(np.abs(a - b))) < 1e-6, ("bf16 numerics, float32 exchange = the fused single-GPU step", sharded, k, float(np.max(np.abs(a - b))))
     dist.destroy_process_group()
     print("DP_WORLD1_OK")
 

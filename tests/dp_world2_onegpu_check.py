@@ -26,14 +26,17 @@ def dev(a, dtype=torch.float32):
 def main():
     rank, world, _ = parallel.init_from_env(backend="gloo")
     assert world == 2
-    for name, comm, bucket_adam, tol, sharded in (("g2b_mvae_train_step_te", torch.float32, True, 5e-6, False),
+    cases = (("g2b_mvae_train_step_te", torch.float32, True, 5e-6, False),
                                                   ("g2c_mvae_train_step_deep", torch.float32, False, 5e-6, False),
                                                   ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5, False),
                                                   # sharded optimizer: reduce-scatter, Adam on the local rows, all-gather of
                                                   # the compute copies; the masters are gathered before they are compared
                                                   ("g2b_mvae_train_step_te", torch.float32, True, 5e-6, True),
                                                   ("g2c_mvae_train_step_deep", torch.float32, True, 5e-6, True),
-                                                  ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5, True)):
+                                                  ("g2c_mvae_train_step_deep", torch.bfloat16, True, 7e-5, True))
+    # both schedulers: "native" = the engine runs the step and calls back for the collectives (torch.distributed on its streams),
+    # "python" = round 2's host-driven reducer
+    for engine, (name, comm, bucket_adam, tol, sharded) in [(e, c) for e in ("native", "python") for c in cases]:
         g = load_golden(name)
         enc, dec = [int(v) for v in g["enc_dims"]], [int(v) for v in g["dec_dims"]]
         beta, anneal, p, lr = [float(v) for v in g["meta"]]
@@ -44,8 +47,11 @@ def main():
         net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
         net.to("cuda")
         model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
-        red = parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam, sharded=sharded)
-        assert bool(red.shard_layers) == sharded
+        red = parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam, sharded=sharded, engine=engine)
+        if engine == "native":
+            assert red.native and red.transport == "torch" and red.sharded == sharded
+        else:
+            assert bool(red.shard_layers) == sharded
         _, keys = params_in_order(sd_from(g, "sd0__"))
         for t in range(g["xs"].shape[0]):
             B = g["xs"][t].shape[0]
@@ -54,7 +60,7 @@ def main():
             gt = torch.from_numpy(g["gts"][t][s:e]) if "gts" in g else None
             loss = model.train_batch(torch.from_numpy(g["xs"][t][s:e]), gt)
             ref = float(g["loss_%d" % t])
-            assert abs(loss - ref) < (1e-5 if comm == torch.float32 else 1e-5) * abs(ref), (name, t, loss, ref)
+            assert abs(loss - ref) < (1e-5 if comm == torch.float32 else 1e-5) * abs(ref), (engine, name, t, loss, ref)
             sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
             if sharded:
                 assert model._rtx.masters_sharded
@@ -62,12 +68,12 @@ def main():
             for k, prm, want in zip(keys, net._param_list(), sd_t):
                 dl = np.abs(prm.detach().cpu().numpy() - want)
                 if comm == torch.float32:
-                    assert float(dl.max()) < tol, (name, str(comm), t, k, float(dl.max()))
+                    assert float(dl.max()) < tol, (engine, name, str(comm), t, k, float(dl.max()))
                 else:
                     # the two ranks' partial gradients are rounded to bf16 before they are summed: where they nearly
                     # cancel, the sign of the sum -- and with it Adam's +-lr move -- can flip on a few elements
                     assert float(dl.max()) <= (t + 1) * 2.1e-3 and float(np.mean(dl > tol)) < 0.03, \
-                        (name, str(comm), t, k, float(dl.max()), float(np.mean(dl > tol)))
+                        (engine, name, str(comm), t, k, float(dl.max()), float(np.mean(dl > tol)))
     dist.barrier()
     if rank == 0:
         print("DP_WORLD2_OK")

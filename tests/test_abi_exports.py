@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, "declared in include/*.h but not exported: %s" % missing
     # the ctypes signature table covers exactly the declared symbols
     assert set(_lib.SIGNATURES) == syms
-    assert _lib.lib().rtx_abi_version() == 4
+    assert _lib.lib().rtx_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header():
@@ -106,5 +106,6 @@ def _header_struct_fields(name):
 def test_header_struct_fields_match_the_binding():
     """field names and order of the C structs in include/rectorch_hip.h equal the ctypes mirrors"""
     from rectorch_amd import _lib
-    for cname, struct in (("rtx_cfg", _lib.Cfg), ("rtx_batch", _lib.Batch), ("rtx_step", _lib.Step), ("rtx_svae_cfg", _lib.SvaeCfg)):
+    for cname, struct in (("rtx_cfg", _lib.Cfg), ("rtx_batch", _lib.Batch), ("rtx_step", _lib.Step), ("rtx_svae_cfg", _lib.SvaeCfg),
+                          ("rtx_dp_cfg", _lib.DpCfg)):
         assert _header_struct_fields(cname) == [f[0] for f in struct._fields_], cname
