@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--replicated", action="store_true", help="data parallel: all-reduce + the whole Adam update on every rank")
     ap.add_argument("--dp-engine", default=None, choices=["native", "python"],
                     help="who schedules the data-parallel step: the engine (one C call per step, default) or round 2's Python reducer")
+    ap.add_argument("--dp-transport", default=None, choices=["rccl", "torch"],
+                    help="engine-scheduled step: RCCL through the engine's own communicator (default) or torch.distributed callbacks")
     ap.add_argument("--emulate-world", type=int, default=0, metavar="G",
                     help="one GPU plays rank 0 of a G-rank job: the engine's data-parallel schedule with every collective replaced by "
                          "device copies of the bytes a rank moves and Adam on 1/G of the rows (HBM cost of the per-GPU step; timing only)")
@@ -232,6 +234,11 @@ def main():
     rccl_ranks = None
     dp = world > 1 or args.force_dp or emu > 0
     plan = None
+    if emu and os.environ.get("RTX_PROBE_INIT_PG"):      # experiment: a live nccl process group that the step never uses
+        import tempfile
+        dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="rtx_pg_"), "store"), rank=0, world_size=1)
+        _p = torch.ones(1, device="cuda")
+        dist.all_reduce(_p)
     if emu:
         # rank 0 of an emu-rank job on this one GPU: weak scaling keeps --batch users here, strong scaling --batch / emu
         if args.scaling == "strong":
@@ -243,7 +250,10 @@ def main():
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)                                 # an actual RCCL collective: the line is self-checking
         rccl_ranks = int(round(float(probe.item())))
-        plan = parallel.attach(model, fixed_global_batch=global_batch, sharded=args.sharded, engine=args.dp_engine)
+        if os.environ.get("RTX_PROBE_IDLE_COMM"):          # experiment: an RCCL communicator that is never used
+            from rectorch_amd.parallel import NativePlan
+            _idle = NativePlan(rank, world, False, torch.bfloat16, None, "rccl")
+        plan = parallel.attach(model, fixed_global_batch=global_batch, sharded=args.sharded, engine=args.dp_engine, transport=args.dp_transport)
     # resident sampler over the global batch; each rank takes its slice of every global batch
     np.random.seed(20240927)
     smp = DataSampler(Xin, Xtg, batch_size=global_batch, shuffle=True)
@@ -261,10 +271,11 @@ def main():
             model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
 
     if args.opt:
-        run(1, 0)                                       # the first step creates the engine
+        st_, _, m_, v_ = model._ensure_train_state()    # the engine exists before its first step: some knobs must be set by then
+        eng0 = net.rtx_engine(args.numerics, B, train_buffers=(st_.grads, m_, v_))
         for kv in args.opt:                             # measurement knobs (rtx_engine_set_option), e.g. --opt two_stream=0
             k, v = kv.split("=")
-            net._rtx_engines[args.numerics].set_option(k, int(v))
+            eng0.set_option(k, int(v))
     run(args.warmup, 0)
     torch.cuda.synchronize()
     _flush_c_stdio()
@@ -342,6 +353,7 @@ def main():
                    "parallelism": mode + (("-sharded-adam" if args.sharded else "-replicated-adam") if dp else ""),
                    "dp_scheduler": (None if not dp else ("engine (%s)" % plan.transport if getattr(plan, "native", False) else "python reducer")),
                    "first_layer": "sparse (k_spmm_in, VALU)" if sparse_first else "dense (MFMA split-K GEMM)",
+                   "second_stream_concurrent": bool(eng.get_option("side_concurrent")),
                    "numerics": "bf16 MFMA operands, f32 accumulate, f32 master weights + Adam" if args.numerics == "bf16"
                                else "f32 MFMA (parity mode)"},
         "windows": {"n": args.windows, "steps_each": args.steps, "seconds": wins, "reported": "median"},

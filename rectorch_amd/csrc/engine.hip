@@ -73,6 +73,11 @@ struct DpState {
     bool shard[2 * RTX_MAX_LAYERS] = {};        // per layer: weight matrix reduce-scattered / updated by rows / all-gathered
     void* emu_scratch = nullptr;              // emulate: where the stand-in copies go
     size_t emu_bytes = 0;
+    // emulate: the collectives of one group become ONE copy launch (as RCCL fuses a group into one kernel)
+    struct EmuPiece { void* buf; size_t bytes; int back; };
+    EmuPiece emu_q[8];
+    int emu_n = 0, emu_grouped = 0;
+    hipStream_t emu_stream = nullptr;
 };
 
 struct rtx_engine {
@@ -102,14 +107,20 @@ struct rtx_engine {
     int64_t in_cap_chunks = 0;
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
+    hipStream_t side_for = nullptr;   // the caller's stream the side stream was probed against (make_side_stream)
+    int side_concurrent = 0;          // 1: the probe saw the two streams run at the same time
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
     hipEvent_t ev_done = nullptr;      // everything the step put on the side stream is complete
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
+    int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
-    int opt_side_low_prio = 1;  // ... created with the lowest stream priority
+    int opt_side_low_prio = 0;  // ... created with the lowest stream priority (1).  Round 3: OFF.  Neutral for the single-GPU step
+                                //   (307.1 / 308.0 vs 308.2 / 308.5 us, A/B in one call), and with a live RCCL communicator in the process
+                                //   -- any data-parallel job -- a lowest-priority queue beside RCCL's makes EVERY kernel of the step run 2-3x
+                                //   slower (769 vs 343 us/step, profiles/r3_dp_priority_experiment.txt)
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
     int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
     int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_layers.hip)
@@ -870,6 +881,66 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && (l.in & 3) == 0 && l.in >= 4; }
 static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
 
+// ---- the second stream of the step ------------------------------------------------------------------------------------------
+// HIP maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order.  A process that also
+// runs RCCL / torch.distributed has created a dozen streams before the engine's first step, and the engine's new stream can land
+// on the SAME hardware queue as the caller's: its kernels then simply queue up behind / in front of the caller's and the step
+// runs serially (rocprofv3 showed both streams on queue 1: 397 us/step against 343 -- profiles/r3_dp_priority_experiment.txt).
+// So the stream is PROBED: a kernel that spins for ~150 us goes on the caller's stream, an empty kernel on the candidate; the
+// candidate is kept if its kernel finishes while the spinner is still running.  Up to 8 candidates at normal priority, then
+// one at the highest priority (a different queue pool); with none found the step falls back to one stream.
+__global__ void k_probe_spin(unsigned long long ticks, int* sink)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz counter
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {}
+    if (sink && ticks == 0xffffffffffffffffull) *sink = 1;
+}
+__global__ void k_probe_nop() {}
+
+static int make_side_stream(rtx_engine* e, hipStream_t st)
+{
+    RTX_HIP(hipStreamSynchronize(st));
+    if (e->side) {
+        RTX_HIP(hipStreamSynchronize(e->side));
+        (void)hipStreamDestroy(e->side);
+        e->side = nullptr;
+    }
+    e->side_for = st;
+    int prio_least = 0, prio_greatest = 0;
+    RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    if (e->opt_side_low_prio) {   // measurement knob: no probing
+        RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least));
+        e->side_concurrent = 1;
+        return RTX_OK;
+    }
+    hipEvent_t ev_spin = nullptr, ev_cand = nullptr;
+    RTX_HIP(hipEventCreateWithFlags(&ev_spin, hipEventDisableTiming));
+    RTX_HIP(hipEventCreateWithFlags(&ev_cand, hipEventDisableTiming));
+    std::vector<hipStream_t> rejected;
+    hipStream_t found = nullptr;
+    for (int attempt = 0; attempt < 9 && !found; ++attempt) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, attempt < 8 ? 0 : prio_greatest) != hipSuccess) break;
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, st, 15000ull, (int*)nullptr);   // 150 us
+        (void)hipEventRecord(ev_spin, st);
+        hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(64), 0, cand);
+        (void)hipEventRecord(ev_cand, cand);
+        (void)hipEventSynchronize(ev_cand);
+        const bool concurrent = hipEventQuery(ev_spin) == hipErrorNotReady;   // the spinner is still at it: different hardware queues
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        if (concurrent) found = cand;
+        else rejected.push_back(cand);
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipEventDestroy(ev_spin);
+    (void)hipEventDestroy(ev_cand);
+    e->side_concurrent = found != nullptr;
+    if (!found) RTX_HIP(hipStreamCreateWithFlags(&found, hipStreamNonBlocking));   // (keeps the code paths alive; the step still orders everything by events)
+    e->side = found;
+    return RTX_OK;
+}
+
 // tensors of the exchange buffer in layout order (DpState): W[NL-1], b[NL-1], ..., W[1], b[1], b[0], W[0]
 static int dp_layout_order(const rtx_engine* e, int* order)
 {
@@ -902,18 +973,16 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     // (see below for what the two streams do)
     // (data parallel: the second stream carries the decoder matrix's weight kernel, its exchange and its optimizer pass; the
     //  float32 parity mode keeps one compute copy per matrix and therefore one stream)
-    const bool two = (fuse || (dp && e->bf16)) && e->opt_two_stream;
-    if (two && !e->side) {
-        // lowest priority: the long streaming kernels take the workgroup slots the short launches of the chain leave free,
-        // not the other way round (with equal priorities the chain's kernels waited for slots: k_reduce_loss 17 us, k_post
-        // 16 us under contention against 5 and 8 us alone)
-        int prio_least = 0, prio_greatest = 0;
-        RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, e->opt_side_low_prio ? prio_least : 0));
-        // (events created with hipEventReleaseToDevice -- a device-scope release at the record -- measure the same: 328.0 vs 327.7 us)
-        for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+    bool two = (fuse || (dp && e->bf16)) && e->opt_two_stream;
+    if (two && (!e->side || e->side_for != st)) {
+        RTX_TRY(make_side_stream(e, st));
+        if (!e->ev_done) {
+            // (events created with hipEventReleaseToDevice -- a device-scope release at the record -- measure the same: 328.0 vs 327.7 us)
+            for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
+            RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        }
     }
+    if (two && !e->side_concurrent) two = false;   // no stream that really runs beside the caller's: one stream, no event traffic
     const int main_li = (two && fuse && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
     if (dae_reg) {
@@ -952,6 +1021,10 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         return two && layer_is_big(e->L[li]) && li != main_li && !e->L[li].WshT;
     };
     const bool keep_grads = (step->flags & RTX_STEP_KEEP_GRADS) != 0;
+    // tile of the weight-gradient kernels: 64 x 128 for the fused Adam epilogue (an HBM streaming kernel: many small workgroups);
+    // the data-parallel step stores bf16 gradient images instead and is bound by operand delivery: 128 x 128 tiles halve the
+    // operand bytes per parameter (emulated 8-rank step 262.3 vs 268.8 us, one box)
+    const int dw_cfg = (dp && !e->opt_dw_cfg_set) ? RTX_DW_128x128 : e->opt_dw_cfg;
     // data parallel: where tensor t's gradient is produced (the exchange buffer, in comm dtype)
     auto xg16 = [&](int t) { return (bf16_t*)dp->xg + dp->xoff[t]; };
     auto xg32 = [&](int t) { return (float*)dp->xg + dp->xoff[t]; };
@@ -969,7 +1042,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         const bool fused = fuse && layer_fusable(e, l);
         d = RtxDw{};
         d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-        d.m_tiles = l.outp / rtx_dw_tile_rows(e->opt_dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+        d.m_tiles = l.outp / rtx_dw_tile_rows(dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
         d.M_real = l.out; d.N_real = l.in;
         if (fused) {
             RtxAdamArgs sc = {};
@@ -1010,7 +1083,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d;
             make_dw(li, d);
-            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, e->opt_dw_cfg, ws);
+            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, dw_cfg, ws);
         }
         RtxGemm g = {};
         g.form = RTX_FORM_TN;
@@ -1181,7 +1254,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
                 make_dw(li, grp[ng++]);
                 if (ng == RTX_DW_GROUP_MAX || li == 0) {
                     ScopedTimer tm(e, "gemm_dW_in", st);
-                    RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_GRAD, e->opt_dw_cfg, st));
+                    RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_GRAD, dw_cfg, st));
                     ng = 0;
                 }
             }
@@ -1210,7 +1283,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         make_dw(main_li, grp[ng++]);
         {
             ScopedTimer tm(e, "dW_adam_in", st);
-            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, e->opt_dw_cfg, st));
+            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, dw_cfg, st));
         }
         RTX_TRY(reduce_loss(e->side));
         if (rest.n > 0) {   // gradients from both streams feed the leftover Adam launch: the side stream waits for this one, then runs it
@@ -1355,19 +1428,57 @@ static int dp_rccl_all_gather(void* c, void* buf, int64_t bytes, void* st) { ret
 static int dp_rccl_group_start(void* c) { return rtx_comm_group_start((rtx_comm*)c); }
 static int dp_rccl_group_end(void* c) { return rtx_comm_group_end((rtx_comm*)c); }
 
-// emulate: the bytes one rank of `world` sends + receives in a ring collective, as device-to-device copies through a scratch
-// buffer (reduce-scatter / all-gather: (world - 1) / world of the buffer read and written once; all-reduce: twice)
-static int dp_emu_move(DpState* d, void* buf, size_t bytes, bool back, hipStream_t st)
+// emulate: the bytes one rank of `world` sends + receives in a ring collective, as device copies through a scratch buffer
+// (reduce-scatter / all-gather: (world - 1) / world of the buffer read and written once; all-reduce: twice -- there and back,
+// numerically a no-op).  One launch per collective, or per group of collectives, like RCCL's own kernels.
+struct EmuCopyArgs {
+    struct { const uint4* src; uint4* dst; unsigned long n16; int back; } p[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_emu_copy(const EmuCopyArgs a)
 {
-    const size_t w = (size_t)d->cfg.world;
-    size_t s = bytes / w * (w - 1);
-    s = std::min(s, d->emu_bytes) & ~(size_t)15;
-    if (s == 0) return RTX_OK;
-    char* rest = (char*)buf + (bytes - s);   // "the other ranks' blocks"
-    RTX_HIP(hipMemcpyAsync(d->emu_scratch, rest, s, hipMemcpyDeviceToDevice, st));
-    if (back) RTX_HIP(hipMemcpyAsync(rest, d->emu_scratch, s, hipMemcpyDeviceToDevice, st));   // (the same values: numerically a no-op)
+    for (int k = 0; k < a.n; ++k) {
+        const uint4* __restrict__ src = a.p[k].src;
+        uint4* __restrict__ dst = a.p[k].dst;
+        for (unsigned long i = (unsigned long)blockIdx.x * 256 + threadIdx.x; i < a.p[k].n16; i += (unsigned long)gridDim.x * 256) {
+            const uint4 v = src[i];
+            dst[i] = v;
+            if (a.p[k].back) ((uint4*)src)[i] = v;   // the all-gather half of an all-reduce writes the block back
+        }
+    }
+}
+static int dp_emu_flush(DpState* d)
+{
+    if (d->emu_n == 0) return RTX_OK;
+    EmuCopyArgs a = {};
+    size_t used = 0;
+    for (int k = 0; k < d->emu_n; ++k) {
+        const size_t w = (size_t)d->cfg.world, bytes = d->emu_q[k].bytes;
+        size_t s = (bytes / w * (w - 1)) & ~(size_t)15;
+        s = std::min(s, d->emu_bytes - used);
+        if (s == 0) continue;
+        a.p[a.n].src = (const uint4*)((char*)d->emu_q[k].buf + ((bytes - s) & ~(size_t)15));   // "the other ranks' blocks"
+        a.p[a.n].dst = (uint4*)((char*)d->emu_scratch + used);
+        a.p[a.n].n16 = s / 16;
+        a.p[a.n].back = d->emu_q[k].back;
+        used += s;
+        ++a.n;
+    }
+    d->emu_n = 0;
+    if (a.n == 0) return RTX_OK;
+    hipLaunchKernelGGL(k_emu_copy, dim3(2048), dim3(256), 0, d->emu_stream, a);
+    RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
+static int dp_emu_move(DpState* d, void* buf, size_t bytes, bool back, hipStream_t st)
+{
+    if (d->emu_n == 8) RTX_TRY(dp_emu_flush(d));
+    d->emu_stream = st;
+    d->emu_q[d->emu_n++] = DpState::EmuPiece{buf, bytes, back ? 1 : 0};
+    return d->emu_grouped ? RTX_OK : dp_emu_flush(d);
+}
+static int dp_emu_group_start(void* c) { ((DpState*)c)->emu_grouped = 1; return RTX_OK; }
+static int dp_emu_group_end(void* c) { ((DpState*)c)->emu_grouped = 0; return dp_emu_flush((DpState*)c); }
 static int dp_emu_all_reduce(void* c, void* buf, int64_t n, int32_t dt, void* st)
 {
     return dp_emu_move((DpState*)c, buf, (size_t)n * (dt == RTX_BF16 ? 2 : 4), true, (hipStream_t)st);
@@ -1403,7 +1514,7 @@ int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
     DpState& d = e->dp;
     d.cfg = *cfg;
     if (cfg->emulate) {
-        d.ops = rtx_dp_ops{dp_emu_all_reduce, dp_emu_reduce_scatter, dp_emu_all_gather, nullptr, nullptr, &e->dp};
+        d.ops = rtx_dp_ops{dp_emu_all_reduce, dp_emu_reduce_scatter, dp_emu_all_gather, dp_emu_group_start, dp_emu_group_end, &e->dp};
     } else if (cfg->comm) {
         int32_t r = -1, w = -1;
         RTX_TRY(rtx_comm_rank(cfg->comm, &r, &w));
@@ -1432,7 +1543,7 @@ int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
     d.xbytes = off * d.xesz;
     RTX_TRY(dev_alloc(e, &d.xg, d.xbytes));
     if (cfg->emulate) {
-        d.emu_bytes = biggest;
+        d.emu_bytes = 2 * biggest;
         RTX_TRY(dev_alloc(e, &d.emu_scratch, d.emu_bytes, false));
         // rows no rank updates here keep their weights in BOTH compute copies (the step alternates between them)
         RTX_TRY(ensure_shadows(e, nullptr));
@@ -1499,6 +1610,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;
+        e->opt_dw_cfg_set = 1;
     } else if (k == "splitk") {
         RTX_CHECK(value >= 0, RTX_EINVAL, "set_option: splitk must be >= 0");
         // the scratch was sized for the automatic choice: only accept factors it can hold
@@ -1536,7 +1648,8 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "small_bwd") *value = e->opt_small_bwd;
     else if (k == "dw_cfg") *value = e->opt_dw_cfg;
     else if (k == "splitk") *value = e->cfg.splitk;
-    else if (k == "last_sparse_in") *value = e->last_sparse_in;   // 1: the last forward pass ran the first layer as the sparse product
+    else if (k == "last_sparse_in") *value = e->last_sparse_in;
+    else if (k == "side_concurrent") *value = e->side_concurrent;   // 1: the step's second stream was seen to run beside the caller's   // 1: the last forward pass ran the first layer as the sparse product
     else {
         rtx_set_error("get_option: unknown key '%s'", key);
         return RTX_EINVAL;

@@ -343,6 +343,7 @@ void rtx_gemm_dma_tile_dims(int cfg, int* bm, int* bn)
     switch (cfg) {
     case RTX_DMA_512x128: *bm = 512; *bn = 128; break;
     case RTX_DMA_256x256: *bm = 256; *bn = 256; break;
+    case RTX_DMA_256x256_W4: *bm = 256; *bn = 256; break;
     default: *bm = 128; *bn = 128; break;
     }
 }
@@ -367,6 +368,7 @@ template <int FORM, int EPI> static int gd_launch_cfg(const RtxGemm& g, dim3 gri
     case RTX_DMA_512x128: return gd_launch<FORM, EPI, 4, 2, 4, 2, 2>(g, grid, stream);
     case RTX_DMA_256x256: return gd_launch<FORM, EPI, 2, 4, 4, 2, 2>(g, grid, stream);
     case RTX_DMA_128x128_S2: return gd_launch<FORM, EPI, 2, 2, 2, 2, 2>(g, grid, stream);
+    case RTX_DMA_256x256_W4: return gd_launch<FORM, EPI, 2, 2, 4, 4, 2>(g, grid, stream);
     default: return gd_launch<FORM, EPI, 2, 2, 2, 2, 3>(g, grid, stream);
     }
 }
@@ -378,7 +380,7 @@ int rtx_gemm_dma_launch(const RtxGemm& g, int epilogue, hipStream_t stream)
     RTX_CHECK(epilogue == RTX_EPI_STORE || epilogue == RTX_EPI_BIAS_ROWS, RTX_EINVAL, "gemm_dma: bad epilogue %d", epilogue);
     RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm_dma: empty problem");
     RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm_dma: split-K only with EPI_STORE");
-    RTX_CHECK(g.tile_shape >= RTX_DMA_128x128 && g.tile_shape <= RTX_DMA_128x128_S2, RTX_EINVAL, "gemm_dma: bad tile configuration %d", g.tile_shape);
+    RTX_CHECK(g.tile_shape >= RTX_DMA_128x128 && g.tile_shape <= RTX_DMA_256x256_W4, RTX_EINVAL, "gemm_dma: bad tile configuration %d", g.tile_shape);
     RTX_CHECK((g.splits - 1) * ((g.k_slices + g.splits - 1) / g.splits) < g.k_slices, RTX_EINVAL, "gemm_dma: %d splits leave an empty split of %d slices",
               g.splits, g.k_slices);
     const int tiles = g.m_tiles * g.n_tiles;

@@ -783,6 +783,66 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
     const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
     const int cl = (tid & 15) * 4;
     const bool vec = (t.cols & 3) == 0;
+    if (vec && t.cols >= 4) {
+        // Rows of whole float4s: EVERY load of the thread's four passes (p, m, v, g: 16 x 16 B) is issued before the first
+        // update is computed -- one round trip per tile instead of four (the passes' stores may alias the next pass's loads as
+        // far as the compiler knows, so written pass by pass each pass waits for the one before).  Out-of-range threads load a
+        // clamped (valid) address and skip the stores: no branch around a load.  A rank of the sharded optimizer runs this on
+        // 1/8 of the rows, where the launch is all latency: 35 -> ~15 us in the data-parallel step (profiles/r3_adam_probe.txt).
+        float4 P4[4], M4[4], V4[4], G4[4];
+        const int cc = min(c0 + cl, t.cols - 4);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int rc = min(r0 + pass * 16 + (tid >> 4), t.rows - 1);
+            const size_t o = (size_t)rc * t.cols + cc;
+            P4[pass] = *(const float4*)(t.p + o);
+            if (a.update) {
+                M4[pass] = *(const float4*)(t.m + o);
+                V4[pass] = *(const float4*)(t.v + o);
+                if (t.g16) {   // data parallel, bf16 exchange: the reduced gradient arrives as bf16
+                    const uint2 u = *(const uint2*)(t.g16 + o);
+                    G4[pass] = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffff)), bf16_to_f32((bf16_t)(u.x >> 16)),
+                                           bf16_to_f32((bf16_t)(u.y & 0xffff)), bf16_to_f32((bf16_t)(u.y >> 16)));
+                } else {
+                    G4[pass] = *(const float4*)(t.g + o);
+                }
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int rl = pass * 16 + (tid >> 4);
+            const int r = r0 + rl, c = c0 + cl;
+            const bool ok = r < t.rows && c < t.cols;
+            float pv[4] = {P4[pass].x, P4[pass].y, P4[pass].z, P4[pass].w};
+            if (ok) {
+                const size_t o = (size_t)r * t.cols + c;
+                if (a.update) {
+                    const float gv[4] = {G4[pass].x, G4[pass].y, G4[pass].z, G4[pass].w};
+                    float mv[4] = {M4[pass].x, M4[pass].y, M4[pass].z, M4[pass].w};
+                    float vv[4] = {V4[pass].x, V4[pass].y, V4[pass].z, V4[pass].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float g = gv[e] * a.grad_scale + reg * pv[e];
+                        if (a.weight_decay != 0.f) g += a.weight_decay * pv[e];
+                        const float m = mv[e] + (g - mv[e]) * (1.f - a.beta1);
+                        const float v = vv[e] * a.beta2 + (1.f - a.beta2) * g * g;
+                        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+                        pv[e] = pv[e] - a.step_size * (m / denom);
+                        mv[e] = m;
+                        vv[e] = v;
+                    }
+                    *(float4*)(t.p + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    *(float4*)(t.m + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                    *(float4*)(t.v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+                if (t.sh) store4<T>((T*)t.sh + (size_t)r * t.ld_sh + c, pv[0], pv[1], pv[2], pv[3]);   // ld_sh is a multiple of 128 -> aligned
+            }
+            if (t.shT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[rl][cl + e] = ok ? pv[e] : 0.f;
+            }
+        }
+    } else {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int rl = pass * 16 + (tid >> 4);
@@ -792,27 +852,9 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
             const size_t o = (size_t)r * t.cols + c;
             const int nv = min(4, t.cols - c);
             float gv[4], mv[4], vv[4];
-            if (vec) {
-                const float4 p4 = *(const float4*)(t.p + o);
-                pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
-                if (a.update) {
-                    const float4 m4 = *(const float4*)(t.m + o), v4 = *(const float4*)(t.v + o);
-                    if (t.g16) {   // data parallel, bf16 exchange: the all-reduced gradient arrives as bf16
-                        const uint2 u = *(const uint2*)(t.g16 + o);
-                        gv[0] = bf16_to_f32((bf16_t)(u.x & 0xffff)); gv[1] = bf16_to_f32((bf16_t)(u.x >> 16));
-                        gv[2] = bf16_to_f32((bf16_t)(u.y & 0xffff)); gv[3] = bf16_to_f32((bf16_t)(u.y >> 16));
-                    } else {
-                        const float4 g4 = *(const float4*)(t.g + o);
-                        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
-                    }
-                    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
-                    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
-                }
-            } else {
-                for (int e = 0; e < nv; ++e) {
-                    pv[e] = t.p[o + e];
-                    if (a.update) { gv[e] = t.g16 ? bf16_to_f32(t.g16[o + e]) : t.g[o + e]; mv[e] = t.m[o + e]; vv[e] = t.v[o + e]; }
-                }
+            for (int e = 0; e < nv; ++e) {
+                pv[e] = t.p[o + e];
+                if (a.update) { gv[e] = t.g16 ? bf16_to_f32(t.g16[o + e]) : t.g[o + e]; mv[e] = t.m[o + e]; vv[e] = t.v[o + e]; }
             }
             if (a.update) {
 #pragma unroll
@@ -828,16 +870,10 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
                         vv[e] = v;
                     }
                 }
-                if (vec) {
-                    *(float4*)(t.p + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                    *(float4*)(t.m + o) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-                    *(float4*)(t.v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                } else {
-                    for (int e = 0; e < nv; ++e) { t.p[o + e] = pv[e]; t.m[o + e] = mv[e]; t.v[o + e] = vv[e]; }
-                }
+                for (int e = 0; e < nv; ++e) { t.p[o + e] = pv[e]; t.m[o + e] = mv[e]; t.v[o + e] = vv[e]; }
             }
             if (t.sh) {
-                T* s = (T*)t.sh + (size_t)r * t.ld_sh + c;  // ld_sh is a multiple of 128 -> aligned
+                T* s = (T*)t.sh + (size_t)r * t.ld_sh + c;
                 if (nv == 4) store4<T>(s, pv[0], pv[1], pv[2], pv[3]);
                 else for (int e = 0; e < nv; ++e) s[e] = Elem<T>::from(pv[e]);
             }
@@ -846,6 +882,7 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) tile[rl][cl + e] = (r < t.rows && c + e < t.cols) ? pv[e] : 0.f;
         }
+    }
     }
     if (t.shT) {
         __syncthreads();
@@ -874,7 +911,8 @@ int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
         // flat walk: no transposed copy to produce, rows not 16-byte periodic, buffers 16-byte aligned
         const RtxAdamTensor& tk = a.t[k];
         const bool aligned = (((uintptr_t)tk.p | (uintptr_t)tk.m | (uintptr_t)tk.v | (uintptr_t)tk.g | (uintptr_t)tk.g16) & 15) == 0;
-        a.t[k].flat = (!tk.shT && (tk.cols & 3) != 0 && tk.rows > 1 && aligned) ? 1 : 0;
+        // ... and a bias (one row) always: a handful of 4096-element tiles instead of one 64-column tile per workgroup
+        a.t[k].flat = (!tk.shT && aligned && (((tk.cols & 3) != 0 && tk.rows > 1) || tk.rows == 1)) ? 1 : 0;
         if (a.t[k].flat) tiles += (int)(((long)tk.rows * tk.cols + 4095) / 4096);
         else tiles += ((a.t[k].rows + 63) / 64) * ((a.t[k].cols + 63) / 64);
     }

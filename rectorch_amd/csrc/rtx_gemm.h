@@ -49,7 +49,7 @@ void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
 // gradient).  TN: A is [k][m] and B is [k][n] (the weight gradient straight from the row-major activations / deltas).
 enum RtxForm { RTX_FORM_NT = 0, RTX_FORM_NN = 1, RTX_FORM_TN = 2 };
 // tile configurations of the LDS-DMA GEMM (gemm_dma.hip): 4-wave 128x128, 8-wave 512x128 (all rows of a B = 500 step), 8-wave 256x256
-enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2, RTX_DMA_128x128_S2 = 3 };   // _S2: two stages (64 KB of LDS: co-resident with other kernels)
+enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2, RTX_DMA_128x128_S2 = 3, RTX_DMA_256x256_W4 = 4 };   // _S2: two stages (64 KB of LDS: co-resident with other kernels); _W4: 256x256 tile on FOUR waves, 128x128 of C per wave (256 accumulator registers): half the LDS bytes per MFMA of the 8-wave tile
 void rtx_gemm_dma_tile_dims(int cfg, int* bm, int* bn);
 
 struct RtxGemm {

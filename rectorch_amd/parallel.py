@@ -463,7 +463,7 @@ def init_from_env(backend=None):
 
 
 def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None, comm_dtype=None, bucket_adam=True, sharded=False,
-           engine=None, emulate_world=0):
+           engine=None, emulate_world=0, transport=None):
     """Turn a :class:`rectorch_amd.models.AETrainer` into a data-parallel replica: broadcasts rank 0's
     parameters, then every ``train_batch`` exchanges the gradients as described above.  Each rank must feed
     ITS slice of the global batch (see ``shard_rows``).
@@ -478,6 +478,8 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
     ``emulate_world`` = G > 0 (native only, no process group needed): this process plays rank 0 of a G-rank job with the
     collectives replaced by same-size device copies -- timing of the per-GPU step, not training (the other ranks' rows never
     change).
+    ``transport`` (native engine): None -> "rccl" (the engine's own communicator) when the process group is nccl, else "torch"
+    (``torch.distributed`` calls on the engine's streams).
     ``bucket_adam`` / ``min_bucket_bytes`` steer the python engine only."""
     st, params, m, v = model._ensure_train_state()
     if comm_dtype is None:
@@ -499,7 +501,8 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
     world = dist.get_world_size(group)
     if engine == "native":
         assert on_device, "the native data-parallel step needs the network on the GPU"
-        transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
+        if transport is None:
+            transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
         plan = None
         if transport == "rccl":
             # the engine's own communicator; every rank must agree on whether it came up (a rank that fell back alone would

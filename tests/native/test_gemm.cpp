@@ -608,6 +608,23 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  gcnArch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+    if (argc > 1 && !strcmp(argv[1], "big")) {   // only the big-tile GEMM lines (round 3)
+        for (int cfg : {RTX_DMA_256x256, RTX_DMA_256x256_W4}) {
+            for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
+                fails += run_dma_case("store", form, cfg, 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, 0);
+                fails += run_dma_case("bias", form, cfg, 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, 0);
+            }
+            perf_dma("sq4k", RTX_FORM_NT, cfg, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+            perf_dma("sq4k", RTX_FORM_NN, cfg, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+            perf_dma("sq8k", RTX_FORM_NT, cfg, 8192, 8192, 8192, 1, RTX_EPI_STORE);
+            perf_dma("nflx-logits", RTX_FORM_NT, cfg, 4096, 17920, 640, 1, RTX_EPI_BIAS_ROWS);
+            perf_dma("nflx-fwd1", RTX_FORM_NT, cfg, 4096, 768, 17920, 5, RTX_EPI_STORE);
+            perf_dma("nflx-dH3", RTX_FORM_NN, cfg, 4096, 768, 17920, 5, RTX_EPI_STORE);
+            perf_dma("logits", RTX_FORM_NT, cfg, 512, 20224, 640, 1, RTX_EPI_BIAS_ROWS);
+        }
+        printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
+        return fails ? 1 : 0;
+    }
     for (int shape = 0; shape < 3; ++shape) {   // 128x128, 256x128, 128x256
         fails += run_case<bf16_t>("store", 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, shape);
         fails += run_case<bf16_t>("splitk3", 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, shape);
@@ -623,7 +640,7 @@ int main(int argc, char** argv)
         fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
     }
     fails += tr_probe();
-    for (int cfg = 0; cfg < 4; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages), 128x128 (2 stages)
+    for (int cfg = 0; cfg < 5; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages), 128x128 (2 stages), 256x256 on 4 waves
         for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
             fails += run_dma_case("store", form, cfg, 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, 0);
             fails += run_dma_case("splitk3", form, cfg, 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, 0);
