@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "librectorch_hip.so")
+# RTX_LIB_PATH: load another build of the library (A/B measurements of one kernel variant against the shipped one in ONE gpurun call)
+LIB_PATH = os.environ.get("RTX_LIB_PATH") or os.path.join(CSRC, "librectorch_hip.so")
 MAX_LAYERS = 8
 
 RTX_VAE, RTX_DAE = 0, 1

@@ -125,6 +125,7 @@ struct rtx_engine {
     int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
     int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_layers.hip)
     int opt_small_bwd = 1;      // ... and of the data-gradient chain (reads the transposed compute copies of the hidden layers)
+    int opt_big_batch_tiles = 1;   // batches of >= 1024 rows: 512 x 128 data-gradient tiles (configs[3] on one GPU: 1486 -> 1343 us/step)
     int last_sparse_in = 0;     // what the last forward pass did with the first layer (rtx_engine_get_option "last_sparse_in")
     int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
                                 //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
@@ -252,6 +253,9 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form 
         // data-gradient chain beside the weight-gradient kernels (two streams): a 64-KB-LDS configuration, so that its
         // workgroups fit on a CU next to one of theirs (the 512-row tile takes the whole LDS of a CU)
         if (form == RTX_FORM_NN && e->opt_fuse_adam && e->opt_two_stream) pl.cfg = RTX_DMA_128x128_S2;
+        // a batch of thousands of rows (configs[3] on one GPU: B = 4096): the product is no longer a skinny one hiding beside a
+        // streaming kernel but 90 GFLOP of its own -- the 512-row tile needs a third of the operand bytes per flop of the 128 x 128 one
+        if (big && e->opt_big_batch_tiles && Mp >= 1024) pl.cfg = RTX_DMA_512x128;
         rtx_gemm_dma_tile_dims(pl.cfg, &pl.bm, &pl.bn);
     } else {
         pl.cfg = RTX_TILE_128x128;
@@ -1024,6 +1028,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     // tile of the weight-gradient kernels: 64 x 128 for the fused Adam epilogue (an HBM streaming kernel: many small workgroups);
     // the data-parallel step stores bf16 gradient images instead and is bound by operand delivery: 128 x 128 tiles halve the
     // operand bytes per parameter (emulated 8-rank step 262.3 vs 268.8 us, one box)
+    // (not so the fused epilogue, even at K = 4096 batch rows: configs[3] on one GPU 1343 us/step with 64 x 128, 1380 with 128 x 128)
     const int dw_cfg = (dp && !e->opt_dw_cfg_set) ? RTX_DW_128x128 : e->opt_dw_cfg;
     // data parallel: where tensor t's gradient is produced (the exchange buffer, in comm dtype)
     auto xg16 = [&](int t) { return (bf16_t*)dp->xg + dp->xoff[t]; };
@@ -1607,6 +1612,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "sparse_in") e->opt_sparse_in = value != 0;
     else if (k == "small_fwd") e->opt_small_fwd = value != 0;
     else if (k == "small_bwd") e->opt_small_bwd = value != 0;
+    else if (k == "big_batch_tiles") e->opt_big_batch_tiles = value != 0;
     else if (k == "dw_cfg") {
         RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128, RTX_EINVAL, "set_option: dw_cfg must be 0..3");
         e->opt_dw_cfg = value;
@@ -1627,7 +1633,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
             return RTX_EINVAL;
         }
     } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, sparse_in, small_fwd, small_bwd, dw_cfg, splitk)", key);
+        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, sparse_in, small_fwd, small_bwd, big_batch_tiles, dw_cfg, splitk)", key);
         return RTX_EINVAL;
     }
     return RTX_OK;
@@ -1646,6 +1652,7 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "sparse_in") *value = e->opt_sparse_in;
     else if (k == "small_fwd") *value = e->opt_small_fwd;
     else if (k == "small_bwd") *value = e->opt_small_bwd;
+    else if (k == "big_batch_tiles") *value = e->opt_big_batch_tiles;
     else if (k == "dw_cfg") *value = e->opt_dw_cfg;
     else if (k == "splitk") *value = e->cfg.splitk;
     else if (k == "last_sparse_in") *value = e->last_sparse_in;

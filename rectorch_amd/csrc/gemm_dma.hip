@@ -28,6 +28,10 @@
 
 #include <utility>
 
+#ifndef GD_SCHED
+#define GD_SCHED 0   // where in a slice's compute step the next slice's DMA is issued (see compute())
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 gd_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float gd_f32x16;
 typedef __attribute__((ext_vector_type(4))) float gd_f32x4;   // native vectors: arrays of them stay in registers (HIP's uint2 / float4
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 1 ? (WM * WN) / 4 : 1)
             }
         };
         const bool pf = pf_t >= 0;
+#if GD_SCHED == 0
         frag(x, std::integral_constant<int, 0>{});
         frag(y, std::integral_constant<int, 1>{});
         gd_wait_lgkm<NR>();
@@ -237,6 +242,42 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 1 ? (WM * WN) / 4 : 1)
         gd_wait_lgkm<0>();
         mma(y);
         if (pf) load_part(pf_stage, pf_t, std::integral_constant<int, 3>{});
+#elif GD_SCHED == 1
+        // front-loaded: the whole next slice is requested in the first half of this slice's compute, so every piece has at
+        // least half a slice of MFMA time to land before the wait at the top of the next iteration
+        frag(x, std::integral_constant<int, 0>{});
+        frag(y, std::integral_constant<int, 1>{});
+        if (pf) { load_part(pf_stage, pf_t, std::integral_constant<int, 0>{}); load_part(pf_stage, pf_t, std::integral_constant<int, 1>{}); }
+        gd_wait_lgkm<NR>();
+        mma(x);
+        if (pf) { load_part(pf_stage, pf_t, std::integral_constant<int, 2>{}); load_part(pf_stage, pf_t, std::integral_constant<int, 3>{}); }
+        frag(x, std::integral_constant<int, 2>{});
+        gd_wait_lgkm<NR>();
+        mma(y);
+        frag(y, std::integral_constant<int, 3>{});
+        gd_wait_lgkm<NR>();
+        mma(x);
+        gd_wait_lgkm<0>();
+        mma(y);
+#else
+        // everything right behind the barrier (the Gram kernel's order)
+        if (pf) {
+            load_part(pf_stage, pf_t, std::integral_constant<int, 0>{}); load_part(pf_stage, pf_t, std::integral_constant<int, 1>{});
+            load_part(pf_stage, pf_t, std::integral_constant<int, 2>{}); load_part(pf_stage, pf_t, std::integral_constant<int, 3>{});
+        }
+        frag(x, std::integral_constant<int, 0>{});
+        frag(y, std::integral_constant<int, 1>{});
+        gd_wait_lgkm<NR>();
+        mma(x);
+        frag(x, std::integral_constant<int, 2>{});
+        gd_wait_lgkm<NR>();
+        mma(y);
+        frag(y, std::integral_constant<int, 3>{});
+        gd_wait_lgkm<NR>();
+        mma(x);
+        gd_wait_lgkm<0>();
+        mma(y);
+#endif
     };
 
     // ---- main loop: ring of NS stages, slices t .. t+NS-2 in flight at the top of iteration t ------------------------

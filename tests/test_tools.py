@@ -53,3 +53,47 @@ def test_timeline_anchors_on_the_first_kernel_of_a_step(tmp_path):
         assert first[:20] in body[4]                                         # the second step starts with it again
         # the gap column is measured on the kernel's own queue: 1 us between consecutive launches of queue 1
         assert abs(float(body[1].split()[3]) - 1.0) < 1e-6
+
+
+def _pmc_db(tmp_path, counters):
+    """a rocpd-shaped counters_collection view: per (kernel, counter) `calls` rows of `value`"""
+    path = str(tmp_path / "pmc_results.db")
+    con = sqlite3.connect(path)
+    con.execute("create table counters_collection (kernel_name text, counter_name text, grid_size integer, value real, duration integer)")
+    for kernel, grid, dur_us, vals in counters:
+        for ctr, v in vals.items():
+            for _ in range(12):
+                con.execute("insert into counters_collection values (?,?,?,?,?)", (kernel, ctr, grid, v, int(dur_us * 1000)))
+    con.commit()
+    con.close()
+    return path
+
+
+def test_mfma_utilisation_and_hbm_json_from_the_pmc_passes(tmp_path):
+    """tools/pmc_bench.sh's post-processing: MFMA busy cycles / (active cycles x 1024 SIMDs), and HBM bytes per launch with the
+    gfx950 FETCH_SIZE x 2 correction"""
+    import json
+    import rocprof_summary as rs
+    dw, gemm = "void rtx_dw_tn<2, 4, 3, 1>(RtxDw)", "void rtx_gemm_nt<unsigned short, 1, 2, 2, 2>(RtxGemm)"
+    d = tmp_path / "pmc"
+    d.mkdir()
+    for tag, key in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE")):
+        sub = tmp_path / tag
+        sub.mkdir()
+        db = _pmc_db(sub, [(dw, 404480, 72.0, {key: 90000.0 if tag == "FETCH_SIZE" else 170000.0}),
+                           (dw, 20480, 14.0, {key: 900.0 if tag == "FETCH_SIZE" else 1700.0}),     # a hidden layer's launch: not "dominant"
+                           (gemm, 161792, 36.0, {key: 12000.0 if tag == "FETCH_SIZE" else 41000.0})])
+        (d / ("bench_%s.txt" % tag)).write_text(_run(rs.pmc, db))
+    j = json.loads(_run(rs.pmcjson, str(d)))
+    k = j["kernels"]["%s grid=404480" % dw]
+    assert abs(k["read_bytes_per_launch"] - 2 * 90000.0 * 1024) < 1 and abs(k["write_bytes_per_launch"] - 170000.0 * 1024) < 1
+    assert abs(j["hbm_bytes_per_launch"] - (2 * 90000.0 + 170000.0) * 1024) < 1          # the dominant pair = the rtx_dw_tn launches
+    assert abs(k["hbm_TBps"] - (2 * 90000.0 + 170000.0) * 1024 / 72e-6 / 1e12) < 1e-9
+    sq = tmp_path / "SQ"
+    sq.mkdir()
+    # 36 us at 2.4 GHz = 86 400 cycles per XCD (GRBM_GUI_ACTIVE arrives summed over the 8 XCDs); 1024 SIMDs busy a quarter of the time
+    db = _pmc_db(sq, [(gemm, 161792, 36.0, {"SQ_VALU_MFMA_BUSY_CYCLES": 86400.0 * 1024 * 0.25, "GRBM_GUI_ACTIVE": 8 * 86400.0, "SQ_BUSY_CU_CYCLES": 1.0})])
+    table = tmp_path / "bench_SQ.txt"
+    table.write_text(_run(rs.pmc, db))
+    out = [ln for ln in _run(rs.mfma, str(table)).splitlines() if ln.startswith("void rtx_gemm_nt")]
+    assert len(out) == 1 and abs(float(out[0].split()[-1]) - 0.25) < 1e-4 and abs(float(out[0].split()[-2]) - 0.25) < 1e-4

@@ -62,5 +62,79 @@ def timeline(path, anchor="k_gather", nth=40, count=2):
         print("%9.2f %9.2f %8.2f %8.2f  q%-3s s%-3s %s" % ((st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3, gap, q, sid, n[:70]))
 
 
+def _read_pmc_table(path):
+    """rows of a `pmc` summary written above: (kernel, counter, grid, calls, avg_value, avg_us)"""
+    out = []
+    for ln in open(path):
+        if ln.startswith("#") or ln.startswith("kernel "):
+            continue
+        # the kernel name is a fixed-width field of 56 characters and may contain spaces
+        name, rest = ln[:56].strip(), ln[56:].split()
+        if len(rest) == 5:
+            out.append((name, rest[0], int(rest[1]), int(rest[2]), float(rest[3]), float(rest[4])))
+    return out
+
+
+N_XCD, SIMD_PER_XCD, CLOCK_GHZ = 8, 32 * 4, 2.4     # MI355X: 8 XCDs x 32 CUs x 4 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def mfma(path):
+    """MFMA utilisation per kernel from the SQ pass.  SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles summed over all SIMDs (32 per
+    v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md); GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (a 37-us kernel reports 0.8 M
+    cycles = 8 x 37 us x 2.7 GHz incl. the counter start/stop), so
+        util_active = MFMA_BUSY / (GUI_ACTIVE x 128 SIMDs per XCD)            (the counters' own time base)
+        util_wall   = MFMA_BUSY / (duration x 2.4 GHz x 1024 SIMDs)           (the traced duration)
+    1.0 = every SIMD's matrix pipe busy all the time = the dense peak of the instruction mix (2.5 PFLOP/s for bf16)."""
+    rows = _read_pmc_table(path)
+    by = {}
+    for name, ctr, grid, calls, val, us in rows:
+        by.setdefault((name, grid), {})[ctr] = (val, us, calls)
+    print("# MFMA utilisation per kernel (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE; counters serialise")
+    print("# the streams: every kernel is ALONE on the device here, and the step runs its one-stream schedule).")
+    print("# util_active = MFMA_BUSY / (GRBM_GUI_ACTIVE [summed over %d XCDs] x %d SIMDs per XCD); util_wall = MFMA_BUSY / (avg_us x %.1f GHz x %d SIMDs)"
+          % (N_XCD, SIMD_PER_XCD, CLOCK_GHZ, N_XCD * SIMD_PER_XCD))
+    print("%-56s %10s %6s %10s %14s %14s %12s %10s" % ("kernel", "grid", "calls", "avg_us", "mfma_busy_cyc", "gui_active_cyc", "util_active", "util_wall"))
+    for (name, grid), c in sorted(by.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0, 0))[0]):
+        busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0.0, 0.0, 0))
+        act = c.get("GRBM_GUI_ACTIVE", (0.0, 0.0, 0))
+        ua = busy[0] / (act[0] * SIMD_PER_XCD) if act[0] else float("nan")
+        uw = busy[0] / (busy[1] * 1e3 * CLOCK_GHZ * N_XCD * SIMD_PER_XCD) if busy[1] else float("nan")
+        print("%-56s %10d %6d %10.2f %14.0f %14.0f %12.4f %10.4f" % (name, grid, busy[2], busy[1], busy[0], act[0], ua, uw))
+
+
+def pmcjson(directory):
+    """FETCH_SIZE / WRITE_SIZE summaries of one tools/pmc_bench.sh run -> JSON: HBM bytes per launch of every kernel and of the
+    dominant pair (the two weight-gradient + Adam launches).  gfx950 correction: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)."""
+    import json
+    import os
+    import subprocess
+    f = {(r[0], r[2]): r for r in _read_pmc_table(os.path.join(directory, "bench_FETCH_SIZE.txt"))}
+    w = {(r[0], r[2]): r for r in _read_pmc_table(os.path.join(directory, "bench_WRITE_SIZE.txt"))}
+    kernels = {}
+    for key, fr in f.items():
+        wr = w.get(key)
+        if wr is None:
+            continue
+        rd, wrb = fr[4] * 1024.0 * 2.0, wr[4] * 1024.0          # the counters report KB
+        kernels["%s grid=%d" % key] = {"calls": fr[3], "FETCH_SIZE_KB_reported": fr[4], "WRITE_SIZE_KB": wr[4], "read_bytes_per_launch": rd,
+                                       "write_bytes_per_launch": wrb, "hbm_bytes_per_launch": rd + wrb, "avg_us_serialised": fr[5],
+                                       "hbm_TBps": (rd + wrb) / (fr[5] * 1e-6) / 1e12 if fr[5] else None}
+    dw = [v for k, v in kernels.items() if k.startswith("void rtx_dw_tn") and v["calls"] >= 10]
+    top = max((v["hbm_bytes_per_launch"] for v in dw), default=0.0)
+    dom = [v for v in dw if v["hbm_bytes_per_launch"] >= 0.5 * top]      # the n_items x 600 matrices, not the hidden layers' launches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    git = None
+    try:
+        git = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        if os.path.exists(os.path.join(root, ".git_rev")):                # the GPU box has no .git: tools/gpu.sh leaves the hash here
+            git = open(os.path.join(root, ".git_rev")).read().strip()
+    print(json.dumps({"correction": "gfx950 rocprofv3: FETCH_SIZE doubled (reports 1/2 of a wide coalesced streaming read), WRITE_SIZE as reported; KB -> bytes",
+                      "source": "tools/pmc_bench.sh: bench.py under rocprofv3, separate --pmc passes (kernels serialised: each is alone on the device)",
+                      "git": git, "kernels": kernels,
+                      "hbm_bytes_per_launch": (sum(v["hbm_bytes_per_launch"] for v in dom) / len(dom)) if dom else None,
+                      "dominant": "mean over the weight-gradient + Adam launches (rtx_dw_tn / rtx_dw_tn_group)"}, indent=1))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline, "mfma": mfma, "pmcjson": pmcjson}[sys.argv[1]](sys.argv[2])
