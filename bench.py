@@ -291,6 +291,11 @@ def main():
     n_steps_total = args.warmup + args.steps * args.windows
     loss_mean = model._read_loss_sum() / n_steps_total
 
+    if world > 1:
+        dist.barrier()
+    if plan is not None and hasattr(plan, "close"):
+        eng.dp_attach(None)
+        plan.close()                 # the engine's own RCCL communicator goes while every rank is still here
     if rank != 0:
         dist.destroy_process_group()
         return

@@ -417,15 +417,21 @@ class NativePlan:
                 _all_gather_blocks(buf, self.rank, self.world, self.group, native)
                 t.view(-1).copy_(buf[:rows * cols])
 
-    def __del__(self):
+    def close(self):
+        """destroy the engine's RCCL communicator (every rank, while its peers are still alive: before
+        ``dist.destroy_process_group()`` / interpreter exit).  The engines that were attached to this plan must not step again."""
         h = getattr(self, "comm", None)
         if h is not None and h.value:
             try:
                 from . import _lib
+                torch.cuda.synchronize()
                 _lib.lib().rtx_comm_destroy(h)
             except Exception:
                 pass
             self.comm = None
+
+    def __del__(self):
+        self.close()
 
 
 def _all_gather_blocks(flat, rank, world, group, native):

@@ -234,7 +234,9 @@ def test_g5_resident_sampler_matches_reference_batches():
 
 
 # ---------------------------------------------------------------------------------------------- end-to-end trajectory
-@pytest.mark.parametrize("numerics,tol_loss,tol_metric", [("fp32", 2e-4, 2e-3), ("bf16", 2e-2, 3e-2)])
+# bounds = a few times the deviations achieved on MI355X (round 3: fp32 loss 1.6e-7 / metrics 0; bf16 loss 1.7e-5 / metrics 9.2e-4;
+# round 2 asserted 2e-2 / 3e-2 for bf16)
+@pytest.mark.parametrize("numerics,tol_loss,tol_metric", [("fp32", 2e-6, 2e-4), ("bf16", 6e-5, 2e-3)])
 def test_g8_epoch_curve(numerics, tol_loss, tol_metric):
     """5 epochs (8 batches each) on 512x128 synthetic data with the reference's RNG draws injected: per-batch
     loss trajectory, and nDCG@100 / Recall@50 per epoch through evaluate()."""
@@ -252,6 +254,7 @@ def test_g8_epoch_curve(numerics, tol_loss, tol_metric):
     val_tr, val_te = csr_matrix(g["val_tr"].astype(np.float64)), csr_matrix(g["val_te"].astype(np.float64))
     masks = np.unpackbits(g["mask_bits"], axis=-1)[..., :I]
     n_epochs = g["losses"].shape[0]
+    worst_loss, worst_metric = 0.0, 0.0
     for e in range(n_epochs):
         np.random.seed(8000 + e)
         smp = DataSampler(train, batch_size=B, shuffle=True)
@@ -260,10 +263,14 @@ def test_g8_epoch_curve(numerics, tol_loss, tol_metric):
             assert np.array_equal(rb.rows.cpu().numpy(), g["perms"][e][b * B:(b + 1) * B])
             model._rtx.inject = (dev(masks[e, b], torch.uint8), dev(g["eps"][e, b]))
             loss = model._fused_step(rb, None, want_loss=True)
+            worst_loss = max(worst_loss, abs(loss - g["losses"][e, b]) / abs(g["losses"][e, b]))
             assert abs(loss - g["losses"][e, b]) < tol_loss * abs(g["losses"][e, b]), (e, b, loss, g["losses"][e, b])
         res = evaluate(model, DataSampler(val_tr, val_te, batch_size=32, shuffle=False), ["ndcg@100", "recall@50"])
+        worst_metric = max(worst_metric, abs(np.mean(res["ndcg@100"]) - g["ndcg100"][e]), abs(np.mean(res["recall@50"]) - g["recall50"][e]))
         assert abs(np.mean(res["ndcg@100"]) - g["ndcg100"][e]) < tol_metric
         assert abs(np.mean(res["recall@50"]) - g["recall50"][e]) < tol_metric
+    print("g8 %s: worst loss deviation %.2e relative, worst |nDCG@100 / Recall@50 - reference| %.2e (bounds %.0e / %.0e)"
+          % (numerics, worst_loss, worst_metric, tol_loss, tol_metric))
     if numerics == "fp32":
         assert np.max(np.abs(res["ndcg@100"] - g["ndcg100_users"])) < 2e-2    # per-user, rank flips on near-ties only
         sdf = sd_from(g, "sd_final__")
@@ -1530,5 +1537,5 @@ def test_trained_model_ndcg_recall_parity_bf16_vs_cpu_port():
           % (nd_h, nd_c, abs(nd_h - nd_c) / nd_c, rc_h, rc_c, abs(rc_h - rc_c) / rc_c,
              float(np.max(np.abs(res["ndcg@100"] - ro["ndcg@100"])))))
     assert nd_c > 0.15, "the CPU port must have learned the groups' rankings in %d steps (untrained: 0.05)" % K
-    assert curve < 1e-2, curve
+    assert curve < 1e-3, curve                       # (achieved on MI355X: 8e-6; nDCG 2e-5, Recall 3e-3 relative)
     assert abs(nd_h - nd_c) < 1e-2 * nd_c and abs(rc_h - rc_c) < 1e-2 * rc_c
