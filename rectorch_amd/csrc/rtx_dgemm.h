@@ -34,3 +34,6 @@ int rtx_dgemm_launch(const RtxDgemm& g, hipStream_t stream);
 // leaf of the recursive Cholesky: W = inv(chol(Akk)) of one 128x128 block into Wkk (lower) and WTkk (upper), both with
 // leading dimension ldw; *status = 1 if the block is not positive definite (potf2.hip)
 int rtx_potf2_inv_launch(const double* Akk, long ld, double* Wkk, double* WTkk, long ldw, int* status, hipStream_t stream);
+// measurement knob: 1 (default) = the blocked leaf (four 32-column panels, ~30 barriers), 0 = one barrier per column (round 1)
+void rtx_potf2_set_blocked(int on);
+void rtx_potf2_set_stamps(unsigned long long* dev);   // measurement: >= 16 device entries receive 100-MHz clock stamps of the blocked leaf's phases

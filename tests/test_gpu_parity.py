@@ -54,10 +54,10 @@ def make_dae(enc, dec, p, sd, **kw):
 
 
 # ---------------------------------------------------------------------------------------------- native drivers
-@pytest.mark.parametrize("exe", ["test_gemm", "test_spmm", "test_engine"])
+@pytest.mark.parametrize("exe", ["test_gemm", "test_spmm", "test_engine", "test_potf2"])
 def test_native_driver(exe):
     """the no-Python drivers: MFMA GEMM vs host double loops; the sparse first layer vs a host loop over the same stored
-    entries; the whole engine vs the C oracle via the C ABI"""
+    entries; the whole engine vs the C oracle via the C ABI; the EASE solver's leaf (both versions) vs a host Cholesky + inverse"""
     path = os.path.join(ROOT, "build", "native", exe)
     if not os.path.exists(path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native")])
