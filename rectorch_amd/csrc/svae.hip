@@ -54,6 +54,8 @@ struct rtx_svae {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t gru_fwd_lds = 0;          // > 0: the weight-resident forward recurrence runs, with this much dynamic LDS
+    size_t gru_rows_lds = 0;         // > 0: ... its 512-thread whole-row form (round 3), preferred when it fits
+    int opt_gru_rows = 1;            // measurement knob (RTX_SVAE_GRU_ROWS=0 in the environment at create time)
     int gru_kh = 0;                  //      K of the first half of a row
     size_t gru_bwd_lds = 0;          // > 0: the weight-resident backward recurrence runs
     int gru_nc = 0, gru_rp = 0;      //      its row chunks and rows per chunk
@@ -426,6 +428,154 @@ __global__ __launch_bounds__(1024) void k_sv_gru_fwd_all(const float* __restrict
     }
 }
 
+// Round 3: the same weight-resident recurrence on 512 threads (8 waves, two per SIMD: 256 registers per lane).  The 1024-thread
+// kernel above keeps 80 weights per thread and has 128 registers to do it in: hipcc spills ~17 of them and reloads them every
+// step (3.6 us per step).  Here a thread owns a WHOLE row of W_hh: its first KR = 160 weights in registers, the rest of the row
+// in LDS ([chunk of 4 k][512][4]); rows beyond the 512th live in LDS entirely and are summed as two half-rows each by the first
+// 2 NE threads (R = 200: 88 rows, 176 threads; as four quarter-rows on 352 threads the first waves' mat-vec is shorter but the
+// others' longer -- the LDS pipe is shared -- and the step is 5 % slower).  512 x 160 registers + 82 KB + 70 KB of LDS hold the 120 000 weights of R = 200;
+// the hidden state is read as broadcast float4s.  No spills (207 VGPRs), one mat-vec phase and one gate phase per step as before.
+// Measured (tools/svae_stamps.py, shader clock): 6 300 cycles = 2.6 us per step -- mat-vec 4 700 (the LDS pipe: every thread
+// reads all of h, 50 float4, plus its LDS-resident weights), barrier 180, gate phase 1 040, barrier + loop 340 -- against 3.6 us
+// for the 1024-thread kernel: 806 -> 893 users/s with one user per optimizer step.  The first version of this kernel carried an
+// `if (q < nq)` inside the unrolled loop and took 10 200 cycles: a guard per float4 makes every read its own basic block.
+#define SV_GRU_KR2 160
+__host__ __device__ inline void sv_gru_rows_shape(int R, int KR, int* NE, int* Kh, int* CA, int* CB, int* HS)
+{
+    const int R3 = 3 * R;
+    *NE = R3 > 512 ? R3 - 512 : 0;
+    *Kh = (((R + 1) / 2) + 3) & ~3;                  // extra rows: first half k < Kh, second half the rest
+    *CA = R > KR ? (R - KR + 3) / 4 : 0;
+    *CB = (*Kh + 3) / 4;
+    const int reach_own = KR + 4 * *CA, reach_x = *Kh + 4 * *CB;   // the register-resident prefix is summed unconditionally (zero weights past R)
+    const int reach = reach_own > reach_x ? reach_own : reach_x;
+    *HS = ((reach > R ? reach : R) + 7) & ~3;
+}
+__host__ __device__ inline size_t sv_gru_rows_lds(int R, int KR)
+{
+    int NE, Kh, CA, CB, HS;
+    sv_gru_rows_shape(R, KR, &NE, &Kh, &CA, &CB, &HS);
+    return sizeof(float) * ((size_t)HS + ((3 * R + 3) & ~3) + ((2 * NE + 3) & ~3) + (size_t)CA * 512 * 4 + (size_t)CB * 2 * NE * 4);
+}
+
+__device__ unsigned long long* g_sv_stamps = nullptr;   // measurement: shader-clock stamps of the first steps of the forward recurrence
+template <int KR>
+__global__ __launch_bounds__(512) void k_sv_gru_fwd_rows(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                         const int32_t* __restrict__ seq_ptr, int T_one, int R, float* __restrict__ Hout,
+                                                         float* __restrict__ Hprev, float* __restrict__ Gr, float* __restrict__ Gz,
+                                                         float* __restrict__ Gn, float* __restrict__ Ghn)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h [HS] | gp [3R] | gx [2 NE] | wlA [CA][512][4] | wlB [CB][2 NE][4]
+    int NE, Kh, CA, CB, HS;
+    sv_gru_rows_shape(R, KR, &NE, &Kh, &CA, &CB, &HS);
+    const int R3 = 3 * R, NX = 2 * NE;
+    float* h = sm;
+    float* gp = sm + HS;
+    float* gx = gp + ((R3 + 3) & ~3);
+    float* wlA = gx + ((NX + 3) & ~3);
+    float* wlB = wlA + (size_t)CA * 512 * 4;
+    const int tid = threadIdx.x;
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    GI += (size_t)t0 * R3;
+    Hout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
+    const bool own = tid < R3;                     // (R3 < 512: the upper threads idle through the mat-vec)
+    const int row = own ? tid : 0;
+    const int last = R3 * R - 1;
+    float wr[KR];
+    {
+        const int base = row * R;
+#pragma unroll
+        for (int q = 0; q < KR; ++q) {
+            const float v = Whh[min(base + q, last)];
+            wr[q] = (own && q < R) ? v : 0.f;
+        }
+        for (int q = 0; q < CA * 4; ++q) {
+            const float v = Whh[min(base + KR + q, last)];
+            wlA[((size_t)(q >> 2) * 512 + tid) * 4 + (q & 3)] = (own && KR + q < R) ? v : 0.f;
+        }
+    }
+    const bool extra = tid < NX;
+    const int xrow = extra ? 512 + (tid >> 1) : 0, xk0 = (tid & 1) ? Kh : 0, xlen = extra ? ((tid & 1) ? R - Kh : Kh) : 0;
+    if (extra)
+        for (int q = 0; q < CB * 4; ++q) {
+            const float v = Whh[min(xrow * R + xk0 + q, last)];
+            wlB[((size_t)(q >> 2) * NX + tid) * 4 + (q & 3)] = q < xlen ? v : 0.f;
+        }
+    for (int j = tid; j < HS; j += 512) h[j] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float4* hv = (const float4*)h;
+    const float4* hvx = (const float4*)(h + xk0);
+    constexpr int NQ = KR / 4;
+    float gir = 0.f, giz = 0.f, gin = 0.f;
+    if (tid < R && T > 0) { gir = GI[tid]; giz = GI[R + tid]; gin = GI[2 * R + tid]; }
+    unsigned long long* stamps = (tid == 0 && blockIdx.x == 0) ? g_sv_stamps : nullptr;
+    for (int t = 0; t < T; ++t) {
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 0] = __builtin_readcyclecounter();
+        float nir = 0.f, niz = 0.f, nin = 0.f;
+        if (tid < R && t + 1 < T) {
+            const float* gi = GI + (size_t)(t + 1) * R3;
+            nir = gi[tid]; niz = gi[R + tid]; nin = gi[2 * R + tid];
+        }
+        {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            // no condition inside the unrolled loop: a (uniform) guard per float4 turned every read into its own basic block with its
+            // own s_waitcnt -- 8 200 cycles for this phase instead of ~2 000 (tools/svae_stamps.py)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float4 x = hv[q];
+                s0 += wr[4 * q] * x.x; s1 += wr[4 * q + 1] * x.y; s2 += wr[4 * q + 2] * x.z; s3 += wr[4 * q + 3] * x.w;
+            }
+#pragma unroll 5
+            for (int c = 0; c < CA; ++c) {
+                const float4 w = *(const float4*)(wlA + ((size_t)c * 512 + tid) * 4);
+                const float4 x = hv[NQ + c];
+                s0 += w.x * x.x; s1 += w.y * x.y; s2 += w.z * x.z; s3 += w.w * x.w;
+            }
+            if (own) gp[tid] = (s0 + s1) + (s2 + s3);
+            if (extra) {
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+#pragma unroll 5
+                for (int c = 0; c < CB; ++c) {
+                    const float4 w = *(const float4*)(wlB + ((size_t)c * NX + tid) * 4);
+                    const float4 x = hvx[c];
+                    e0 += w.x * x.x; e1 += w.y * x.y; e2 += w.z * x.z; e3 += w.w * x.w;
+                }
+                gx[tid] = (e0 + e1) + (e2 + e3);
+            }
+        }
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 1] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 2] = __builtin_readcyclecounter();
+        if (tid < R) {
+            const int j = tid;
+            auto G = [&](int i) { return (i < 512 ? gp[i] : gx[2 * (i - 512)] + gx[2 * (i - 512) + 1]) + bhh[i]; };
+            const float ghr = G(j), ghz = G(R + j), hn = G(2 * R + j);
+            const float r = sv_sigmoid(gir + ghr);
+            const float z = sv_sigmoid(giz + ghz);
+            const float n = tanhf(gin + r * hn);
+            const float hp = h[j];
+            const float hvv = (1.f - z) * n + z * hp;
+            Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
+            Hprev[(size_t)t * R + j] = hp;
+            Hout[(size_t)t * R + j] = hvv;
+            h[j] = hvv;
+        }
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 3] = __builtin_readcyclecounter();
+        gir = nir; giz = niz; gin = nin;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+extern "C" void rtxdbg_svae_set_stamps(unsigned long long* dev)   // measurement hook (tools/svae_stamps.py): 16 device entries; not part of the ABI
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sv_stamps), &dev, sizeof(dev));
+}
+
 // GRU backward through time.  dHout[t] = gradient w.r.t. the GRU output at step t.  Writes the gate pre-activation
 // gradients dGI [T][3R] (input side) and dGH [T][3R] (hidden side; differs in the n block by the factor r).
 // dh_{t-1} += W_hh^T dgh: thread (column k, row chunk c) sums W_hh[i][k] dgh[i] over its chunk of rows -- consecutive
@@ -778,7 +928,10 @@ static int sv_forward(rtx_svae* s, const int32_t* items, int T, const int32_t* s
     hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
     RTX_TRY(sv_gemm(s, st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
                     s->params[sv_tail(s, SV_T_BIH)]));
-    if (s->gru_fwd_lds > 0) {   // all of W_hh resident in registers + LDS
+    if (s->gru_rows_lds > 0 && s->opt_gru_rows) {   // all of W_hh resident: whole rows on 512 threads (no spills)
+        hipLaunchKernelGGL(k_sv_gru_fwd_rows<SV_GRU_KR2>, dim3(seq_ptr ? n_seq : 1), dim3(512), s->gru_rows_lds, st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
+                           s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
+    } else if (s->gru_fwd_lds > 0) {   // all of W_hh resident in registers + LDS
         hipLaunchKernelGGL(k_sv_gru_fwd_all<SV_GRU_KR>, dim3(seq_ptr ? n_seq : 1), dim3(1024), s->gru_fwd_lds, st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
                            s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->gru_kh, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
     } else {
@@ -881,6 +1034,16 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
             s->gru_fwd_lds = lds;
             s->gru_kh = (int)Kh;
         }
+    }
+    if (3 * R <= 1024 && R <= SV_GRU_KR2 + 4 * 64) {
+        // the 512-thread whole-row form: rows beyond the 512th must find their two halves a thread each (2 NE <= 512)
+        const size_t lds = sv_gru_rows_lds((int)R, SV_GRU_KR2);
+        const long ne = 3 * (long)R > 512 ? 3 * (long)R - 512 : 0;
+        const char* off = getenv("RTX_SVAE_GRU_ROWS");
+        s->opt_gru_rows = !(off && off[0] == '0');
+        if (2 * ne <= 512 && lds <= 160 * 1024 &&
+            hipFuncSetAttribute((const void*)k_sv_gru_fwd_rows<SV_GRU_KR2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            s->gru_rows_lds = lds;
     }
     if (R <= 1024) {
         // LDS of the weight-resident backward recurrence: dh [Rp] | dgh [NC * RP] | part [NC * R] | wl [CL][1024][4]
