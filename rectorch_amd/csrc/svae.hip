@@ -726,7 +726,7 @@ __global__ __launch_bounds__(1024) void k_sv_gru_bwd_all(const float* __restrict
                 const float4 x = dv[i >> 2];
                 a0 += wr[i] * x.x; a1 += wr[i + 1] * x.y; a2 += wr[i + 2] * x.z; a3 += wr[i + 3] * x.w;
             }
-#pragma nounroll
+#pragma nounroll   // (unrolling by 4 / 2 spills 8 / 3 registers at the 128-VGPR cap of a 1024-thread workgroup: 896 -> 799 users/s)
             for (int q = 0; q < CL; ++q) {
                 const float4 w = *(const float4*)(wl + ((size_t)q * 1024 + tid) * 4);
                 const float4 x = dv[(KRB >> 2) + q];
