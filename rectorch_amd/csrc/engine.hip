@@ -1378,6 +1378,10 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
     RTX_CHECK(layer >= 0 && layer < e->NL, RTX_EINVAL, "apply_adam_rows: layer %d out of range", layer);
     const Layer& l = e->L[layer];
     RTX_CHECK(row_lo >= 0 && row_lo <= row_hi && row_hi <= l.outp, RTX_EINVAL, "apply_adam_rows: bad row range [%d, %d) of %d", row_lo, row_hi, l.outp);
+    // a hidden layer keeps a transposed compute copy (WshT, a column-block layout the caller's row-block all-gather cannot
+    // complete): its rows cannot be updated piecewise
+    RTX_CHECK(!l.WshT || (row_lo == 0 && row_hi >= l.out), RTX_EINVAL,
+              "apply_adam_rows: layer %d keeps a transposed compute copy and cannot be sharded by rows (shard the first / last layer only)", layer);
     hipStream_t st = (hipStream_t)stream;
     RtxAdamArgs full = {}, a = {};
     fill_adam_tensors(e, full, layer, layer + 1);

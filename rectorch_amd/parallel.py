@@ -531,10 +531,13 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
         return plan
     shard_layers = {}
     if sharded:
-        for l in range(len(params) // 2):
+        n_layers = len(params) // 2
+        for l in range(n_layers):
             w = params[2 * l]
             prow = (w.shape[0] + 1 + 127) // 128 * 128
-            if w.numel() * 4 >= min_bucket_bytes and prow % world == 0:
+            # (only the input and output layers: a hidden layer may keep a transposed compute copy in the engine, which a
+            #  row-block all-gather cannot complete -- rtx_engine_apply_adam_rows refuses it)
+            if l in (0, n_layers - 1) and w.numel() * 4 >= min_bucket_bytes and prow % world == 0:
                 shard_layers[l] = (int(w.shape[0]), int(w.shape[1]), prow)
     red = GradAllReducer(st.flat_grads, st.layer_ranges, group, min_bucket_bytes, comm_dtype, st.tensor_offsets, shard_layers)
     red.bucket_adam = bool(bucket_adam) or bool(shard_layers)
