@@ -199,15 +199,19 @@ def test_g3_full_size_bf16_within_stated_tolerance():
     y, mu, logvar = eng.forward(net._as_input(x))
     e_logits = rel(y.cpu().numpy()[:, ::257], g["logits_s257"])
     print("bf16 logits rel err at K=20108: %.3e" % e_logits)
-    assert e_logits < 3e-2
+    assert e_logits < 2e-3          # achieved on MI355X: 5.0e-4 (round 2 asserted 3e-2)
     mask = np.unpackbits(g["mask_bits"], axis=1)[:, :I]
     model._rtx.inject = (dev(mask, torch.uint8), dev(g["eps"]))
     model.keep_grads = True
     loss = model.train_batch(x)
-    assert abs(loss - float(g["train_loss"])) < 5e-3 * abs(float(g["train_loss"]))
     ps = net._param_list()
-    assert rel(ps[6].grad.cpu().numpy()[::211, ::37], g["gW4_s"]) < 5e-2
-    assert rel(ps[0].grad.cpu().numpy()[::37, ::211], g["gW1_s"]) < 5e-2
+    e_loss = abs(loss - float(g["train_loss"])) / abs(float(g["train_loss"]))
+    e_w4, e_w1 = rel(ps[6].grad.cpu().numpy()[::211, ::37], g["gW4_s"]), rel(ps[0].grad.cpu().numpy()[::37, ::211], g["gW1_s"])
+    print("bf16 train step at K=20108: loss rel %.2e, gW4 rel %.2e, gW1 rel %.2e" % (e_loss, e_w4, e_w1))
+    # achieved on MI355X (round 3): loss 8.9e-7, gW4 4.8e-3, gW1 2.8e-3 relative (round 2 asserted 5e-3 / 5e-2 / 5e-2)
+    assert e_loss < 1e-5
+    assert e_w4 < 1.5e-2
+    assert e_w1 < 1e-2
 
 
 # ---------------------------------------------------------------------------------------------- sampler on the device
@@ -1200,18 +1204,24 @@ def test_config3_netflix_shape_two_steps_vs_oracle(numerics):
         loss = model._fused_step(rb, None, want_loss=True)
         dense = np.asarray(X[t * B:(t + 1) * B].toarray(), dtype=np.float32)
         ref_loss = ref.train_batch(dense, None, mask.numpy(), eps.numpy())
-        assert abs(loss - ref_loss) < (2e-5 if numerics == "fp32" else 3e-3) * abs(ref_loss), (t, loss, ref_loss)
+        worst = 0.0
         for k, prm, gr in zip(keys, net._param_list(), ref.last["grads"]):
             scale = max(1e-9, float(np.max(np.abs(gr))))
             err = float(np.max(np.abs(prm.grad.cpu().numpy() - gr))) / scale
-            assert err < (3e-4 if numerics == "fp32" else 5e-2), (t, k, err)
+            worst = max(worst, err)
+            assert err < (1e-4 if numerics == "fp32" else 3e-2), (t, k, err)      # achieved: 2.3e-5 / 1.1e-2
+        print("config3 %s step %d: loss rel %.2e, worst gradient rel %.2e" % (numerics, t, abs(loss - ref_loss) / abs(ref_loss), worst))
+        assert abs(loss - ref_loss) < (1e-6 if numerics == "fp32" else 5e-6) * abs(ref_loss), (t, loss, ref_loss)   # achieved: 5e-8 / 2.5e-7
     for prm, r, k in zip(net._param_list(), ref.params, keys):
         d = np.abs(prm.detach().cpu().numpy() - r)
+        print("config3 %s %-22s |dp| max %.2e mean %.2e frac>2e-5 %.2e frac>5e-4 %.2e" % (numerics, k, float(d.max()), float(d.mean()), float(np.mean(d > 2e-5)), float(np.mean(d > 5e-4))))
         if numerics == "fp32":
             # Adam's normalised step turns a gradient that is round-off noise around zero into a +-lr move (see config0)
-            assert float(d.max()) < 2.1e-3 and float(np.mean(d > 2e-5)) < 2e-4, (k, float(d.max()), float(np.mean(d > 2e-5)))
+            # achieved (round 3): max 1.4e-4, at most 1.7e-5 of a tensor's elements off by more than 2e-5
+            assert float(d.max()) < 6e-4 and float(np.mean(d > 2e-5)) < 7e-5 and float(d.mean()) < 5e-9, (k, float(d.max()), float(np.mean(d > 2e-5)))
         else:
-            assert float(d.max()) < 4.2e-3 and float(np.mean(d > 5e-4)) < 0.03, (k, float(d.max()), float(np.mean(d > 5e-4)))
+            # achieved (round 3): mean 0.4-5.0e-6, at most 0.13 % of a tensor's elements off by more than 5e-4 (round 2 accepted 3 %)
+            assert float(d.max()) < 4.2e-3 and float(np.mean(d > 5e-4)) < 5e-3 and float(d.mean()) < 1.5e-5, (k, float(d.max()), float(np.mean(d > 5e-4)))
 
 
 def test_config3_global_batch_4096_on_one_gpu_is_the_sum_of_its_shards():
