@@ -1549,3 +1549,84 @@ def test_trained_model_ndcg_recall_parity_bf16_vs_cpu_port():
     assert nd_c > 0.15, "the CPU port must have learned the groups' rankings in %d steps (untrained: 0.05)" % K
     assert curve < 1e-3, curve                       # (achieved on MI355X: 8e-6; nDCG 2e-5, Recall 3e-3 relative)
     assert abs(nd_h - nd_c) < 1e-2 * nd_c and abs(rc_h - rc_c) < 1e-2 * rc_c
+
+
+def test_dp_native_plan_issues_the_documented_collectives():
+    """The engine-scheduled data-parallel step (rtx_engine_train_step_dp) as rank 3 of 8 with RECORDING collectives (caller-supplied
+    rtx_dp_ops that move nothing): which collectives it issues, on which buffers, of which sizes, in which order -- DESIGN 6.1's
+    plan -- and that the sharded optimizer touches exactly this rank's rows of the two big matrices (everything else of the
+    network is replicated and updated in full)."""
+    import ctypes as C
+    from rectorch_amd import _lib
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L, B, G, RANK = 20108, 600, 200, 64, 8, 3
+    X = synth_interactions(B, I, seed=3)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 5, bias_std=0.05)
+    calls = []
+
+    def rec(name):
+        def f(_ctx, buf, n, *rest):
+            calls.append((name, int(buf), int(n), int(rest[-1] or 0)))       # (collective, buffer, count, stream)
+            return 0
+        return f
+
+    def grp(name):
+        def f(_ctx):
+            calls.append((name, 0, 0, 0))
+            return 0
+        return f
+
+    for sharded in (True, False):
+        net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, numerics="bf16")
+        st, params, m, v = model._ensure_train_state()
+        eng = net.rtx_engine("bf16", B, train_buffers=(st.grads, m, v))
+        ops = _lib.DpOps()
+        keep = (_lib.DP_REDUCE_FN(rec("all_reduce")), _lib.DP_REDUCE_FN(rec("reduce_scatter")), _lib.DP_GATHER_FN(rec("all_gather")),
+                _lib.DP_GROUP_FN(grp("group_start")), _lib.DP_GROUP_FN(grp("group_end")))
+        ops.all_reduce, ops.reduce_scatter, ops.all_gather, ops.group_start, ops.group_end = keep
+        cfg = _lib.DpCfg()
+        cfg.rank, cfg.world, cfg.sharded, cfg.comm_dtype, cfg.emulate, cfg.comm, cfg.ops = RANK, G, int(sharded), _lib.RTX_BF16, 0, None, C.pointer(ops)
+        _lib.check(_lib.lib().rtx_engine_dp_attach(eng.handle, C.byref(cfg)))
+        (rb,) = list(DataSampler(X, batch_size=B, shuffle=False).iter_rows())
+        before = [p.detach().clone() for p in params]
+        step = eng._step(seed=1, beta=0.1, lam=0.0, inv_batch=1.0 / (B * G), lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1)
+        del calls[:]
+        eng.train_step_dp(rb, None, step, st.loss_buf[0:1], st.loss_buf[1:2])
+        torch.cuda.synchronize()
+        names = [c[0] for c in calls]
+        prow_out, prow_in = (I + 1 + 127) // 128 * 128, (H + 1 + 127) // 128 * 128          # 20224, 640
+        if sharded:
+            # bucket A (decoder matrix, side stream): RS of its padded region + AR of its bias in ONE group, then the all-gather of
+            # its compute copy; bucket B (caller's stream): AR of the small layers + b0 as one range, RS of the encoder matrix, AG
+            assert names == ["group_start", "reduce_scatter", "all_reduce", "group_end", "all_gather",
+                             "group_start", "all_reduce", "reduce_scatter", "group_end", "all_gather"], names
+            rsA, arA, agA, arB, rsB, agB = calls[1], calls[2], calls[4], calls[6], calls[7], calls[9]
+            assert rsA[2] == prow_out * H and rsA[2] % G == 0 and arA[2] == I
+            assert agA[2] == prow_out * 640 * 2                                              # bf16 compute copy [P(I)][P(600)]
+            assert rsB[2] == prow_in * I and rsB[2] % G == 0
+            assert arB[2] >= 400 * 600 + 400 + 600 * 200 + 600 + 600 and arB[2] < 400 * 600 + 600 * 200 + 4 * 1024   # W2,b2,W3,b3(dec0),b0 + alignment
+            assert agB[2] == prow_in * ((I + 1 + 127) // 128 * 128) * 2
+            assert rsA[3] == arA[3] == agA[3] != rsB[3] == arB[3] == agB[3]                   # bucket A on the side stream, B on the caller's
+            assert arA[1] == rsA[1] + 2 * (prow_out * H + (-(prow_out * H)) % 64)             # the bias follows the padded region (64-element alignment)
+        else:
+            assert names == ["group_start", "all_reduce", "group_end", "group_start", "all_reduce", "group_end"], names
+            assert calls[1][2] >= I * H + I and calls[4][2] >= H * I + 400 * 600 + 600 * 200
+            assert calls[1][3] != calls[4][3]
+        lo0, hi0, sh0 = eng.dp_owned_rows(0)
+        lo3, hi3, sh3 = eng.dp_owned_rows(3)
+        if sharded:
+            assert (lo3, hi3, sh3) == (RANK * prow_out // G, (RANK + 1) * prow_out // G, True)
+            assert (lo0, hi0, sh0) == (RANK * prow_in // G, (RANK + 1) * prow_in // G, True)
+            assert eng.dp_owned_rows(1) == (0, 400, False)
+        else:
+            assert (lo3, hi3, sh3) == (0, I, False) and (lo0, hi0, sh0) == (0, H, False)
+        for t, (p, b) in enumerate(zip(params, before)):
+            changed = (p.detach() != b)
+            if sharded and t in (0, 6):
+                lo, hi = (lo0, hi0) if t == 0 else (lo3, hi3)
+                assert bool(changed[lo:hi].any()) and not bool(changed[:lo].any()) and not bool(changed[hi:].any()), t
+            else:
+                assert bool(changed.any()), t
+        _lib.check(_lib.lib().rtx_engine_dp_attach(eng.handle, None))
+        del keep
