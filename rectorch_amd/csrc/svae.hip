@@ -51,7 +51,7 @@ struct rtx_svae {
     float* part = nullptr;           // split-K partial sums
     float* part2 = nullptr;          // ... of the GEMMs on the side stream
     hipStream_t side = nullptr;      // weight-gradient GEMMs of the MLPs: they overlap the single-workgroup GRU backward
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t gru_fwd_lds = 0;          // > 0: the weight-resident forward recurrence runs, with this much dynamic LDS
     size_t gru_rows_lds = 0;         // > 0: ... its 512-thread whole-row form (round 3), preferred when it fits
@@ -173,6 +173,23 @@ __global__ __launch_bounds__(256) void k_sv_colsum(const float* D, long ld, int 
     float s = 0.f;
     for (int t = t0; t < t1; ++t) s += D[(size_t)t * ld + n];
     atomicAdd(out + n, s);
+}
+
+// the same in ONE pass for short inputs (one user: T ~ 150): a workgroup owns 64 columns, its four waves take every fourth row and
+// meet in LDS -- no zero fill of the output, no atomics (round 3: the per-user step issued six 5-us memsets for these sums)
+__global__ __launch_bounds__(256) void k_sv_colsum1(const float* D, long ld, int T, int N, float* out)
+{
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        int t = rg;
+        for (; t + 4 < T; t += 8) { s0 += D[(size_t)t * ld + n]; s1 += D[(size_t)(t + 4) * ld + n]; }
+        if (t < T) s0 += D[(size_t)t * ld + n];
+    }
+    part[rg][c] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && n < N) out[n] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 __global__ __launch_bounds__(256) void k_sv_embed(const int32_t* items, int T, int E, const float* emb, float* X)
@@ -892,6 +909,11 @@ static int sv_gemm(rtx_svae* s, hipStream_t st, const float* A, long sam, long s
 
 static int sv_colsum(hipStream_t st, const float* D, long ld, int T, int N, float* out)
 {
+    if (T <= 2048) {
+        hipLaunchKernelGGL(k_sv_colsum1, dim3((N + 63) / 64), dim3(256), 0, st, D, ld, T, N, out);
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
+    }
     RTX_HIP(hipMemsetAsync(out, 0, sizeof(float) * N, st));
     hipLaunchKernelGGL(k_sv_colsum, dim3((N + 255) / 256, (T + 31) / 32), dim3(256), 0, st, D, ld, T, N, out);
     RTX_HIP(hipGetLastError());
@@ -1064,7 +1086,8 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
         return RTX_EHIP;
     }
     if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_fork2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_join2, hipEventDisableTiming) != hipSuccess) {
         rtx_set_error("svae_create: cannot create the side stream");
         rtx_svae_destroy(s);
         return RTX_EHIP;
@@ -1079,6 +1102,8 @@ int rtx_svae_destroy(rtx_svae* s)
     if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->ev_fork2) (void)hipEventDestroy(s->ev_fork2);
+    if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
     for (void* p : s->allocs) (void)hipFree(p);
     delete s;
     return RTX_OK;
@@ -1176,6 +1201,8 @@ static int sv_train(rtx_svae* s, const int32_t* items, int T, const int32_t* seq
         RTX_TRY(sv_gemm(s, s->side, l.D, 1, l.out, in, 1, ld_in, s->grads[2 * li], l.in, l.out, l.in, T, SV_EPI_NONE, nullptr, nullptr, 0, 1));
         RTX_TRY(sv_colsum(s->side, l.D, (long)l.out, T, l.out, s->grads[2 * li + 1]));
     }
+    // (the zero fill of the embedding gradient -- I x E floats -- rides along: nothing reads it before the scatter-add at the end)
+    RTX_HIP(hipMemsetAsync(s->grads[sv_tail(s, SV_T_EMB)], 0, sizeof(float) * (size_t)I * E, s->side));
     RTX_HIP(hipEventRecord(s->ev_join, s->side));
     hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, nll_scale, kl_scale, loss_out,
                        loss_accum);
@@ -1186,15 +1213,20 @@ static int sv_train(rtx_svae* s, const int32_t* items, int T, const int32_t* seq
     else
         hipLaunchKernelGGL(k_sv_gru_bwd, dim3(seq_ptr ? n_seq : 1), dim3(1024), sizeof(float) * 20 * R, st, s->dH, s->params[sv_tail(s, SV_T_WHH)], seq_ptr,
                            T, R, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
-    RTX_TRY(sv_gemm(s, st, s->dGH, 1, 3 * R, s->Hprev, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T));      // dW_hh = dGH^T H_prev
-    RTX_TRY(sv_colsum(st, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]));
+    // the hidden-side gradients (dW_hh, db_hh) go to the side stream, the input-side ones and the embedding's stay here: five
+    // independent ~12-us launches become two chains of 2 and 4
+    RTX_HIP(hipEventRecord(s->ev_fork2, st));
+    RTX_HIP(hipStreamWaitEvent(s->side, s->ev_fork2, 0));
+    RTX_TRY(sv_gemm(s, s->side, s->dGH, 1, 3 * R, s->Hprev, 1, R, s->grads[sv_tail(s, SV_T_WHH)], R, 3 * R, R, T, SV_EPI_NONE, nullptr, nullptr, 0, 1));   // dW_hh = dGH^T H_prev
+    RTX_TRY(sv_colsum(s->side, s->dGH, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BHH)]));
+    RTX_HIP(hipEventRecord(s->ev_join2, s->side));
     RTX_TRY(sv_gemm(s, st, s->dGI, 1, 3 * R, s->X, 1, E, s->grads[sv_tail(s, SV_T_WIH)], E, 3 * R, E, T));          // dW_ih = dGI^T X
     RTX_TRY(sv_colsum(st, s->dGI, (long)3 * R, T, 3 * R, s->grads[sv_tail(s, SV_T_BIH)]));
     RTX_TRY(sv_gemm(s, st, s->dGI, 3 * R, 1, s->params[sv_tail(s, SV_T_WIH)], 1, E, s->dX, E, T, E, 3 * R));        // dX = dGI W_ih
-    RTX_HIP(hipMemsetAsync(s->grads[sv_tail(s, SV_T_EMB)], 0, sizeof(float) * (size_t)I * E, st));
+    RTX_HIP(hipStreamWaitEvent(st, s->ev_join, 0));     // the MLPs' gradients and the zeroed embedding gradient (done long ago)
     hipLaunchKernelGGL(k_sv_embed_grad, dim3(T), dim3(256), 0, st, items, T, E, s->dX, s->grads[sv_tail(s, SV_T_EMB)]);
     RTX_HIP(hipGetLastError());
-    RTX_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
+    RTX_HIP(hipStreamWaitEvent(st, s->ev_join2, 0));
     // ---- torch.optim.Adam (coupled weight decay 5e-3, models.py:1618-1620) over every tensor
     RtxAdamArgs a = {};
     a.n = 0;
