@@ -314,6 +314,7 @@ static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const 
     g.C = e->Cacc; g.ldc = Np; g.slab_stride = (long)Mp * Np;
     RTX_CHECK((size_t)g.splits * Mp * Np <= e->cacc_elems, RTX_ESTATE, "internal: Cacc too small (%d x %d x %d)", g.splits, Mp, Np);
     *splits_out = g.splits;
+    g.xcd_block = 1;   // (the launcher keeps the strip order for split-K and for grids under 8 x 4 tiles)
     if (!pl.regstage) return rtx_gemm_dma_launch(g, RTX_EPI_STORE, st);
     if (form == RTX_FORM_NT) return rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_STORE, st);
     return rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, st);
@@ -453,6 +454,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
                 rtx_gemm_dma_tile_dims(g.tile_shape, &bm, &bn);
                 g.m_tiles = Bp / bm; g.n_tiles = l.outp / bn;
                 if (want_lse && e->opt_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }   // (see lse_fused)
+                g.xcd_block = 1;
                 RTX_TRY(rtx_gemm_dma_launch(g, RTX_EPI_BIAS_ROWS, st));
             } else {
                 g.tile_shape = RTX_TILE_128x128;

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
         __syncthreads();   // every wave has finished reading the operand stages
         float* wreg = (float*)smem + wave * (32 * WLD);
         const int erow = lane >> 1, ehalf = lane & 1;
+        constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;   // store pass: lanes per row, rows per store instruction
+        const int srow = lane / LPR, scol = (lane % LPR) * 4;
         const int col0 = tn * BN + wn * WCOLS;
         float bj[NB];
 #pragma unroll
@@ -274,17 +276,25 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
                 sum += __shfl_xor(sum, 1, 64);
                 if (ehalf == 0 && row < p.M_real) p.lse_part[(size_t)row * p.lse_ld + (tn * WN + wn)] = make_float2(mm, sum);
             }
-            if (row < p.M_real) {
-                float* dst = p.C + (size_t)row * ld + colh;
+            // the stores take a second, column-major read of the parked block: LPR lanes side by side cover one row's WCOLS * 4
+            // bytes, so a store instruction writes RPI whole row segments (full 128-byte lines) -- the row-per-lane-pair
+            // registers above would put each lane's 16 bytes on a line of its own (64 partial-line requests per instruction)
+            f32x4_t w[32 / RPI];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int c = colh + q * 4;
+            for (int it = 0; it < 32 / RPI; ++it) w[it] = *(const f32x4_t*)(wreg + (it * RPI + srow) * WLD + scol);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int orow = tm * BM + wm * 64 + i * 32 + it * RPI + srow;
+                const int c = col0 + scol;
+                if (orow < p.M_real) {
+                    float* dst = p.C + (size_t)orow * ld + c;
                     if (vec_ok && c + 3 < p.N_real) {
-                        *(f32x4_t*)(dst + q * 4) = v[q];
+                        *(f32x4_t*)dst = w[it];
                     } else {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (c + k < p.N_real) dst[q * 4 + k] = v[q][k];
+                            if (c + k < p.N_real) dst[k] = w[it][k];
                     }
                 }
             }

@@ -49,7 +49,7 @@ void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
 // gradient).  TN: A is [k][m] and B is [k][n] (the weight gradient straight from the row-major activations / deltas).
 enum RtxForm { RTX_FORM_NT = 0, RTX_FORM_NN = 1, RTX_FORM_TN = 2 };
 // tile configurations of the LDS-DMA GEMM (gemm_dma.hip): 4-wave 128x128, 8-wave 512x128 (all rows of a B = 500 step), 8-wave 256x256
-enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2, RTX_DMA_128x128_S2 = 3, RTX_DMA_256x256_W4 = 4 };   // _S2: two stages (64 KB of LDS: co-resident with other kernels); _W4: 256x256 tile on FOUR waves, 128x128 of C per wave (256 accumulator registers): half the LDS bytes per MFMA of the 8-wave tile
+enum RtxDmaCfg { RTX_DMA_128x128 = 0, RTX_DMA_512x128 = 1, RTX_DMA_256x256 = 2, RTX_DMA_128x128_S2 = 3, RTX_DMA_256x256_W4 = 4, RTX_DMA_256x256_LW = 5 };   // _S2: two stages (64 KB of LDS: co-resident with other kernels); _W4: 256x256 tile on FOUR waves, 128x128 of C per wave (256 accumulator registers): half the LDS bytes per MFMA of the 8-wave tile
 void rtx_gemm_dma_tile_dims(int cfg, int* bm, int* bn);
 
 struct RtxGemm {
@@ -70,6 +70,8 @@ struct RtxGemm {
     int M_real, N_real;
     float2* lse_part;    // RTX_EPI_BIAS_ROWS (nullable): per row, per 64-column strip (running max, sum exp) of the
     int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
+    int xcd_block;       // gemm_dma, splits == 1: 1 = every XCD works on 8 x 4 blocks of tiles (12 operand panels per 32 tiles in its
+                         //   L2 instead of the strip order's 18 or 33)
 };
 
 // operand element type.  RTX_DT_F32 = 0 and RTX_DT_BF16 = 1 keep the meaning of the former `is_bf16` flag.
@@ -103,6 +105,8 @@ struct RtxDw {
     float* bias_v;
     const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
 };
+void rtx_gemm_dma_set_skip(int v);   // measurement only (gemm_dma.hip g_gd_skip)
+void rtx_gemm_dma_set_stamps(unsigned long long* dev);   // measurement hook: 32 device entries (gemm_dma.hip)
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6

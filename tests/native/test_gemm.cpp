@@ -172,6 +172,8 @@ static int tr_probe()
     return bad != 0;
 }
 
+static int g_xcd_block = 0;   // RtxGemm::xcd_block of the LDS-DMA cases below (second argument "xcd")
+
 // ---- LDS-DMA GEMM (gemm_dma.hip): NT / NN, store (split-K) and bias (+ log-sum-exp partials) epilogues -------------------------
 static int run_dma_case(const char* name, int form, int cfg, int M, int N, int K, int splits, int epi, int M_real, int N_real, int odd_ld)
 {
@@ -204,6 +206,7 @@ static int run_dma_case(const char* name, int form, int cfg, int M, int N, int K
     int bm, bn;
     rtx_gemm_dma_tile_dims(cfg, &bm, &bn);
     g.tile_shape = cfg; g.m_tiles = M / bm; g.n_tiles = N / bn; g.k_slices = K / 64; g.splits = splits;
+    g.xcd_block = (splits == 1) ? g_xcd_block : 0;
     g.C = C; g.ldc = ldc; g.slab_stride = (long)M * N; g.bias = bias; g.M_real = M_real; g.N_real = N_real;
     if (epi == RTX_EPI_BIAS_ROWS) { g.lse_part = part; g.lse_ld = strips; }
     int rc = rtx_gemm_dma_launch(g, epi, 0);
@@ -286,6 +289,7 @@ static void perf_dma(const char* name, int form, int cfg, int M, int N, int K, i
     rtx_gemm_dma_tile_dims(cfg, &bm, &bn);
     g.tile_shape = cfg; g.m_tiles = M / bm; g.n_tiles = N / bn; g.k_slices = K / 64; g.splits = splits;
     g.C = C; g.ldc = N; g.slab_stride = (long)M * N; g.bias = bias; g.M_real = M - 12; g.N_real = N - 116;
+    g.xcd_block = g_xcd_block;
     if (epi == RTX_EPI_BIAS_ROWS) { g.lse_part = part; g.lse_ld = N / 64; }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -608,8 +612,59 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  gcnArch=%s\n", prop.name, prop.multiProcessorCount, prop.gcnArchName);
+    if (argc > 2 && !strcmp(argv[2], "xcd")) g_xcd_block = 1;
+    if (argc > 1 && !strcmp(argv[1], "ingest")) {   // the loader-wave variant with the compute waves idle: what a CU can take in
+        unsigned long long* dst;
+        CK(hipMalloc(&dst, 72 * 8));
+        for (int skip : {2, 1, 0}) {
+            CK(hipMemset(dst, 0, 72 * 8));
+            rtx_gemm_dma_set_stamps(dst);
+            rtx_gemm_dma_set_skip(skip);
+            perf_dma(skip == 2 ? "dma-only" : skip == 1 ? "dma+fragment reads" : "all", RTX_FORM_NT, RTX_DMA_256x256_LW, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+            rtx_gemm_dma_set_stamps(nullptr);
+            rtx_gemm_dma_set_skip(0);
+            unsigned long long h[72];
+            CK(hipMemcpy(h, dst, sizeof(h), hipMemcpyDeviceToHost));
+            printf("  a LOADER wave:  wait for my DMA | barrier | issue of the next slice's 16 pieces | total\n");
+            for (int k = 0; k < 7; ++k)
+                printf("    slice %2d: %6llu %6llu %6llu   = %llu\n", 8 + k, h[32 + k * 4 + 1] - h[32 + k * 4], h[32 + k * 4 + 2] - h[32 + k * 4 + 1],
+                       h[32 + k * 4 + 3] - h[32 + k * 4 + 2], h[32 + (k + 1) * 4] - h[32 + k * 4]);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "stamps")) {   // where a K slice of the LDS-DMA GEMM goes (wave 0 of workgroup 0, slices 8..15)
+        unsigned long long* dst;
+        CK(hipMalloc(&dst, 72 * 8));
+        for (int cfg : {RTX_DMA_256x256_LW, RTX_DMA_256x256, RTX_DMA_256x256_W4, RTX_DMA_512x128, RTX_DMA_128x128}) {
+            CK(hipMemset(dst, 0, 72 * 8));
+            rtx_gemm_dma_set_stamps(dst);
+            perf_dma("sq4k-stamped", RTX_FORM_NT, cfg, 4096, 4096, 4096, 1, RTX_EPI_STORE);
+            rtx_gemm_dma_set_stamps(nullptr);
+            unsigned long long h[72];
+            CK(hipMemcpy(h, dst, sizeof(h), hipMemcpyDeviceToHost));
+            printf("  cfg %d, cycles per slice:  wait for my DMA | barrier | fragment reads + MFMAs (+ next slice's DMA issue) | total\n", cfg);
+            for (int k = 0; k < 7; ++k)
+                printf("    slice %2d: %6llu %6llu %6llu   = %llu\n", 8 + k, h[k * 4 + 1] - h[k * 4], h[k * 4 + 2] - h[k * 4 + 1], h[k * 4 + 3] - h[k * 4 + 2],
+                       h[(k + 1) * 4] - h[k * 4]);
+            printf("  workgroup 0: entry -> main loop done %llu cycles, epilogue %llu cycles; whole %llu cycles in %.2f us = %.3f GHz shader clock\n", h[66] - h[64],
+                   h[67] - h[66], h[67] - h[64], (h[68] - h[65]) * 0.01, (double)(h[67] - h[64]) / ((h[68] - h[65]) * 10.0));
+            if (cfg == RTX_DMA_256x256_LW) {
+                printf("  cfg %d, a LOADER wave:  wait for my DMA | barrier | issue of the next slice's 16 pieces | total\n", cfg);
+                for (int k = 0; k < 7; ++k)
+                    printf("    slice %2d: %6llu %6llu %6llu   = %llu\n", 8 + k, h[32 + k * 4 + 1] - h[32 + k * 4], h[32 + k * 4 + 2] - h[32 + k * 4 + 1],
+                           h[32 + k * 4 + 3] - h[32 + k * 4 + 2], h[32 + (k + 1) * 4] - h[32 + k * 4]);
+            }
+        }
+        hipFree(dst);
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "chan")) {   // power-of-two row strides against odd multiples of 128 B (L2 channel spread)
+        for (int cfg : {RTX_DMA_256x256, RTX_DMA_256x256_W4, RTX_DMA_256x256_LW})
+            for (int K : {4096, 4160, 4032, 8192, 8256}) perf_dma("chan", RTX_FORM_NT, cfg, 4096, 4096, K, 1, RTX_EPI_STORE);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "big")) {   // only the big-tile GEMM lines (round 3)
-        for (int cfg : {RTX_DMA_256x256, RTX_DMA_256x256_W4}) {
+        for (int cfg : {RTX_DMA_256x256, RTX_DMA_256x256_W4, RTX_DMA_512x128}) {
             for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
                 fails += run_dma_case("store", form, cfg, 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, 0);
                 fails += run_dma_case("bias", form, cfg, 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, 0);
@@ -640,7 +695,7 @@ int main(int argc, char** argv)
         fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
     }
     fails += tr_probe();
-    for (int cfg = 0; cfg < 5; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages), 128x128 (2 stages), 256x256 on 4 waves
+    for (int cfg = 0; cfg < 6; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages), 128x128 (2 stages), 256x256 on 4 waves, 256x256 on 8 + 4 loader waves
         for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
             fails += run_dma_case("store", form, cfg, 512, 768, 704, 1, RTX_EPI_STORE, 512, 768, 0);
             fails += run_dma_case("splitk3", form, cfg, 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, 0);
