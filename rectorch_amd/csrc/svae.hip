@@ -18,6 +18,8 @@
 // rtx_svae_train_pack (round 2) takes several users per optimizer step: concatenated rows, one recurrence workgroup per user
 // side by side, [sum T, .] products on the float32 MFMA, the recurrences with W_hh resident in registers + LDS -- 440 -> 806 users/s
 // per user, 21 600 users/s with packs of 128 at the ml-1m shape (SVAE_Sampler(pack=N)).
+// Round 3: the forward recurrence with its mat-vec split over K inside the wave (k_sv_gru_fwd_ks: 1.6 us per time step, 3.6 in
+// round 2) -- 1 090-1 100 users/s per user, 24 200 with packs of 64.
 #include "../../include/rectorch_hip.h"
 #include "rtx_kernels.h"
 
@@ -55,6 +57,7 @@ struct rtx_svae {
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t gru_fwd_lds = 0;          // > 0: the weight-resident forward recurrence runs, with this much dynamic LDS
     size_t gru_rows_lds = 0;         // > 0: ... its 512-thread whole-row form (round 3), preferred when it fits
+    size_t gru_ks_lds = 0;           // > 0: ... its K-sliced form (round 3), for 8 SL >= R and 64 NR >= 3R
     int opt_gru_rows = 1;            // measurement knob (RTX_SVAE_GRU_ROWS=0 in the environment at create time)
     int gru_kh = 0;                  //      K of the first half of a row
     size_t gru_bwd_lds = 0;          // > 0: the weight-resident backward recurrence runs
@@ -223,6 +226,15 @@ __global__ __launch_bounds__(256) void k_sv_transpose(const float* __restrict__ 
 }
 
 __device__ __forceinline__ float sv_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+// the recurrence's gate phase is one dependent chain per thread (200 of the 512 threads, nothing to hide it behind): libm's expf /
+// tanhf / IEEE division make it ~1 000 cycles per time step.  v_exp_f32 / v_rcp_f32 (1 ulp each; the argument's scaling by log2 e
+// adds |x| * 6e-8 relative) keep sigmoid within 3e-7 and tanh within 6e-7 absolute of libm's.
+__device__ __forceinline__ float sv_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float sv_tanh_fast(float x) { return 2.f * sv_sigmoid_fast(2.f * x) - 1.f; }
+template <int CTRL> __device__ __forceinline__ float sv_dpp(float v)   // v of the lane DPP control CTRL points at (all rows, all banks)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 
 // block-wide reductions for 256-thread blocks; red must hold >= 4 floats; result broadcast to all threads
 __device__ __forceinline__ float block_sum(float v, float* red)
@@ -588,6 +600,127 @@ __global__ __launch_bounds__(512) void k_sv_gru_fwd_rows(const float* __restrict
     }
 }
 
+// Round 3, second form: the mat-vec split over K inside the wave.  The whole-row kernel above is bound by the LDS pipe: every
+// thread reads ALL of h (50 broadcast float4) plus its LDS-resident weights, ~520 LDS wave-instructions per step = the 4 700
+// cycles of its mat-vec phase.  Here lane = (row group g = lane >> 3, K slice s = lane & 7): a thread owns NR rows (g + 64 i of
+// the wave's... 64 row slots x NR covers 3R) times ONE slice of SL = R / 8 columns, so it reads only its slice of h (7 float4,
+// all requested up front) and keeps the same ~250 weights (KG in registers, the rest in LDS as before).  The 8 slices of a row
+// meet through three DPP adds per accumulator (quad_perm xor 1, xor 2, row_half_mirror: no LDS), then the 8 lanes of a group
+// write one or two of the NR sums each.  ~180 LDS wave-instructions per step instead of ~520; the VALU work grows from 200 to
+// ~280 operations per thread (the DPP reduction).  h lives slice-major ([8][SLP]) so a slice is 16-byte aligned.
+template <int SL, int NR, int KG>
+__global__ __launch_bounds__(512) void k_sv_gru_fwd_ks(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                       const int32_t* __restrict__ seq_ptr, int T_one, int R, float* __restrict__ Hout,
+                                                       float* __restrict__ Hprev, float* __restrict__ Gr, float* __restrict__ Gz,
+                                                       float* __restrict__ Gn, float* __restrict__ Ghn)
+{
+    constexpr int SLP = (SL + 3) & ~3, NQ = SLP / 4, NWT = NR * SL, CL = (NWT - KG + 3) / 4, GPN = 64 * NR;
+    static_assert(KG % 4 == 0 && KG <= NWT, "register-resident weights: whole float4 groups");
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // h2 [8][SLP] | gp [64 NR] | wl [CL][512][4]
+    float* h2 = sm;
+    float* gp = sm + 8 * SLP;
+    float* wl = gp + GPN;
+    const int R3 = 3 * R;
+    const int tid = threadIdx.x, lane = tid & 63, s = lane & 7, slot = (tid >> 6) * 8 + (lane >> 3);
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    GI += (size_t)t0 * R3;
+    Hout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
+    // weight q = i * SL + kk of this thread is W_hh[slot + 64 i][s * SL + kk] (zero outside the matrix)
+    const int last = R3 * R - 1;
+    auto wload = [&](int q) {
+        const int i = q / SL, kk = q % SL, row = slot + 64 * i, k = s * SL + kk;
+        // every load unconditional (clamped address), the mask a factor: a select lets hipcc sink the load into a branch of its own,
+        // and 250 such branches serialise the kernel's start
+        const float v = Whh[min(row * R + k, last)];
+        return v * ((row < R3 && k < R && q < NWT) ? 1.f : 0.f);
+    };
+    float wr[KG];
+#pragma unroll
+    for (int q = 0; q < KG; ++q) wr[q] = wload(q);
+#pragma unroll 8
+    for (int q = 0; q < CL * 4; ++q) wl[((size_t)(q >> 2) * 512 + tid) * 4 + (q & 3)] = wload(KG + q);
+    for (int j = tid; j < 8 * SLP; j += 512) h2[j] = 0.f;
+    for (int j = tid; j < GPN; j += 512) gp[j] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float4* hs = (const float4*)(h2 + s * SLP);
+    const int hj = (tid / SL) * SLP + (tid % SL);      // where h[tid] lives (gate-phase threads: tid < R)
+    float gir = 0.f, giz = 0.f, gin = 0.f;
+    if (tid < R && T > 0) { gir = GI[tid]; giz = GI[R + tid]; gin = GI[2 * R + tid]; }
+    unsigned long long* stamps = (tid == 0 && blockIdx.x == 0) ? g_sv_stamps : nullptr;
+    for (int t = 0; t < T; ++t) {
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 0] = __builtin_readcyclecounter();
+        float nir = 0.f, niz = 0.f, nin = 0.f;
+        if (tid < R && t + 1 < T) {
+            const float* gi = GI + (size_t)(t + 1) * R3;
+            nir = gi[tid]; niz = gi[R + tid]; nin = gi[2 * R + tid];
+        }
+        {
+            float4 hq[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hq[q] = hs[q];
+            float acc[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+            auto hval = [&](int kk) { const float4 v = hq[kk >> 2]; return (kk & 3) == 0 ? v.x : (kk & 3) == 1 ? v.y : (kk & 3) == 2 ? v.z : v.w; };
+#pragma unroll
+            for (int q = 0; q < KG; ++q) acc[q / SL] += wr[q] * hval(q % SL);
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                const float4 w = *(const float4*)(wl + ((size_t)c * 512 + tid) * 4);
+                const float we[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = KG + 4 * c + e;
+                    if (q < NWT) acc[q / SL] += we[e] * hval(q % SL);
+                }
+            }
+            // the 8 K slices of a row sit in 8 neighbouring lanes
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                acc[i] += sv_dpp<0xB1>(acc[i]);    // quad_perm [1,0,3,2]
+                acc[i] += sv_dpp<0x4E>(acc[i]);    // quad_perm [2,3,0,1]
+                acc[i] += sv_dpp<0x141>(acc[i]);   // row_half_mirror: the other quad of the 8
+            }
+            // lane s of the group writes sums s and s + 8
+            float v0 = acc[0], v1 = acc[NR > 8 ? 8 : 0];
+#pragma unroll
+            for (int i = 1; i < 8 && i < NR; ++i) v0 = (s == i) ? acc[i] : v0;
+#pragma unroll
+            for (int i = 9; i < NR; ++i) v1 = (s == i - 8) ? acc[i] : v1;
+            if (s < NR) gp[slot + 64 * s] = v0;
+            if (s + 8 < NR) gp[slot + 64 * (s + 8)] = v1;
+        }
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 1] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 2] = __builtin_readcyclecounter();
+        if (tid < R) {
+            const int j = tid;
+            const float ghr = gp[j] + bhh[j], ghz = gp[R + j] + bhh[R + j], hn = gp[2 * R + j] + bhh[2 * R + j];
+            const float r = sv_sigmoid_fast(gir + ghr);
+            const float z = sv_sigmoid_fast(giz + ghz);
+            const float n = sv_tanh_fast(gin + r * hn);
+            const float hp = h2[hj];
+            const float hvv = (1.f - z) * n + z * hp;
+            Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
+            Hprev[(size_t)t * R + j] = hp;
+            Hout[(size_t)t * R + j] = hvv;
+            h2[hj] = hvv;
+        }
+        if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 3] = __builtin_readcyclecounter();
+        gir = nir; giz = niz; gin = nin;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+#define SV_KS_SL 25
+#define SV_KS_NR 10
+#define SV_KS_KG 180
+static size_t sv_gru_ks_lds() { return sizeof(float) * (8 * ((SV_KS_SL + 3) & ~3) + 64 * SV_KS_NR + (size_t)((SV_KS_NR * SV_KS_SL - SV_KS_KG + 3) / 4) * 512 * 4); }
+
 extern "C" void rtxdbg_svae_set_stamps(unsigned long long* dev)   // measurement hook (tools/svae_stamps.py): 16 device entries; not part of the ABI
 {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sv_stamps), &dev, sizeof(dev));
@@ -950,7 +1083,10 @@ static int sv_forward(rtx_svae* s, const int32_t* items, int T, const int32_t* s
     hipLaunchKernelGGL(k_sv_embed, dim3(T), dim3(256), 0, st, items, T, E, s->params[sv_tail(s, SV_T_EMB)], s->X);
     RTX_TRY(sv_gemm(s, st, s->X, E, 1, s->params[sv_tail(s, SV_T_WIH)], E, 1, s->GI, 3 * R, T, 3 * R, E, SV_EPI_BIAS,
                     s->params[sv_tail(s, SV_T_BIH)]));
-    if (s->gru_rows_lds > 0 && s->opt_gru_rows) {   // all of W_hh resident: whole rows on 512 threads (no spills)
+    if (s->gru_ks_lds > 0) {   // all of W_hh resident, the mat-vec split over K inside the wave
+        hipLaunchKernelGGL((k_sv_gru_fwd_ks<SV_KS_SL, SV_KS_NR, SV_KS_KG>), dim3(seq_ptr ? n_seq : 1), dim3(512), s->gru_ks_lds, st, s->GI,
+                           s->params[sv_tail(s, SV_T_WHH)], s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
+    } else if (s->gru_rows_lds > 0 && s->opt_gru_rows) {   // all of W_hh resident: whole rows on 512 threads (no spills)
         hipLaunchKernelGGL(k_sv_gru_fwd_rows<SV_GRU_KR2>, dim3(seq_ptr ? n_seq : 1), dim3(512), s->gru_rows_lds, st, s->GI, s->params[sv_tail(s, SV_T_WHH)],
                            s->params[sv_tail(s, SV_T_BHH)], seq_ptr, T, R, s->Hout, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn);
     } else if (s->gru_fwd_lds > 0) {   // all of W_hh resident in registers + LDS
@@ -1066,6 +1202,13 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
         if (2 * ne <= 512 && lds <= 160 * 1024 &&
             hipFuncSetAttribute((const void*)k_sv_gru_fwd_rows<SV_GRU_KR2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             s->gru_rows_lds = lds;
+    }
+    if (R > 128 && R <= 8 * SV_KS_SL && 3 * R <= 64 * SV_KS_NR) {   // (narrower GRUs: the whole-row form wastes less)
+        const char* off = getenv("RTX_SVAE_GRU_KS");
+        const size_t lds = sv_gru_ks_lds();
+        if (!(off && off[0] == '0') && lds <= 160 * 1024 &&
+            hipFuncSetAttribute((const void*)k_sv_gru_fwd_ks<SV_KS_SL, SV_KS_NR, SV_KS_KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            s->gru_ks_lds = lds;
     }
     if (R <= 1024) {
         // LDS of the weight-resident backward recurrence: dh [Rp] | dgh [NC * RP] | part [NC * R] | wl [CL][1024][4]

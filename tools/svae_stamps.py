@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where a time step of the SVAE forward recurrence (k_sv_gru_fwd_rows) goes: shader-clock stamps of steps 8..11 taken by
+"""Where a time step of the SVAE forward recurrence (k_sv_gru_fwd_ks; RTX_SVAE_GRU_KS=0: k_sv_gru_fwd_rows) goes: shader-clock stamps of steps 8..11 taken by
 thread 0 -- step start | mat-vec done | past barrier 1 | gate phase done (the next step's start closes barrier 2)."""
 import ctypes as C
 import os
