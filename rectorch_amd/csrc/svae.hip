@@ -18,8 +18,8 @@
 // rtx_svae_train_pack (round 2) takes several users per optimizer step: concatenated rows, one recurrence workgroup per user
 // side by side, [sum T, .] products on the float32 MFMA, the recurrences with W_hh resident in registers + LDS -- 440 -> 806 users/s
 // per user, 21 600 users/s with packs of 128 at the ml-1m shape (SVAE_Sampler(pack=N)).
-// Round 3: the forward recurrence with its mat-vec split over K inside the wave (k_sv_gru_fwd_ks: 1.6 us per time step, 3.6 in
-// round 2) -- 1 090-1 100 users/s per user, 24 200 with packs of 64.
+// Round 3: both recurrences with the mat-vec split over K inside the wave (k_sv_gru_fwd_ks 1.43 us per time step, 3.6 in round 2;
+// k_sv_gru_bwd_ks 1.63, was 2.06) -- 1 175-1 196 users/s per user, 26 900 with packs of 64.
 #include "../../include/rectorch_hip.h"
 #include "rtx_kernels.h"
 
@@ -57,6 +57,7 @@ struct rtx_svae {
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t gru_fwd_lds = 0;          // > 0: the weight-resident forward recurrence runs, with this much dynamic LDS
     size_t gru_rows_lds = 0;         // > 0: ... its 512-thread whole-row form (round 3), preferred when it fits
+    size_t gru_bwd_ks_lds = 0;       // > 0: the backward recurrence in the same K-sliced layout
     size_t gru_ks_lds = 0;           // > 0: ... its K-sliced form (round 3), for 8 SL >= R and 64 NR >= 3R
     int opt_gru_rows = 1;            // measurement knob (RTX_SVAE_GRU_ROWS=0 in the environment at create time)
     int gru_kh = 0;                  //      K of the first half of a row
@@ -649,13 +650,17 @@ __global__ __launch_bounds__(512) void k_sv_gru_fwd_ks(const float* __restrict__
     const int hj = (tid / SL) * SLP + (tid % SL);      // where h[tid] lives (gate-phase threads: tid < R)
     float gir = 0.f, giz = 0.f, gin = 0.f;
     if (tid < R && T > 0) { gir = GI[tid]; giz = GI[R + tid]; gin = GI[2 * R + tid]; }
+    // the hidden-side biases of this thread's three gates, once (read inside the loop they are three global loads and a vmcnt(0)
+    // -- an L2 round trip -- in every step's gate phase)
+    const int bj = min(tid, R - 1);
+    const float bh_r = bhh[bj], bh_z = bhh[R + bj], bh_n = bhh[2 * R + bj];
     unsigned long long* stamps = (tid == 0 && blockIdx.x == 0) ? g_sv_stamps : nullptr;
     for (int t = 0; t < T; ++t) {
         if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 0] = __builtin_readcyclecounter();
         float nir = 0.f, niz = 0.f, nin = 0.f;
         if (tid < R && t + 1 < T) {
-            const float* gi = GI + (size_t)(t + 1) * R3;
-            nir = gi[tid]; niz = gi[R + tid]; nin = gi[2 * R + tid];
+            const unsigned o = (unsigned)(t + 1) * (unsigned)R3 + (unsigned)tid;
+            nir = GI[o]; niz = GI[o + (unsigned)R]; nin = GI[o + 2u * (unsigned)R];
         }
         {
             float4 hq[NQ];
@@ -699,15 +704,16 @@ __global__ __launch_bounds__(512) void k_sv_gru_fwd_ks(const float* __restrict__
         if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 2] = __builtin_readcyclecounter();
         if (tid < R) {
             const int j = tid;
-            const float ghr = gp[j] + bhh[j], ghz = gp[R + j] + bhh[R + j], hn = gp[2 * R + j] + bhh[2 * R + j];
+            const float ghr = gp[j] + bh_r, ghz = gp[R + j] + bh_z, hn = gp[2 * R + j] + bh_n;
             const float r = sv_sigmoid_fast(gir + ghr);
             const float z = sv_sigmoid_fast(giz + ghz);
             const float n = sv_tanh_fast(gin + r * hn);
             const float hp = h2[hj];
             const float hvv = (1.f - z) * n + z * hp;
-            Gr[(size_t)t * R + j] = r; Gz[(size_t)t * R + j] = z; Gn[(size_t)t * R + j] = n; Ghn[(size_t)t * R + j] = hn;
-            Hprev[(size_t)t * R + j] = hp;
-            Hout[(size_t)t * R + j] = hvv;
+            const unsigned o = (unsigned)t * (unsigned)R + (unsigned)j;   // 32-bit offsets: scalar base + one VGPR per store
+            Gr[o] = r; Gz[o] = z; Gn[o] = n; Ghn[o] = hn;
+            Hprev[o] = hp;
+            Hout[o] = hvv;
             h2[hj] = hvv;
         }
         if (stamps && t >= 8 && t < 12) stamps[(t - 8) * 4 + 3] = __builtin_readcyclecounter();
@@ -721,7 +727,156 @@ __global__ __launch_bounds__(512) void k_sv_gru_fwd_ks(const float* __restrict__
 #define SV_KS_KG 180
 static size_t sv_gru_ks_lds() { return sizeof(float) * (8 * ((SV_KS_SL + 3) & ~3) + 64 * SV_KS_NR + (size_t)((SV_KS_NR * SV_KS_SL - SV_KS_KG + 3) / 4) * 512 * 4); }
 
-extern "C" void rtxdbg_svae_set_stamps(unsigned long long* dev)   // measurement hook (tools/svae_stamps.py): 16 device entries; not part of the ABI
+// Backward recurrence in the K-sliced layout of k_sv_gru_fwd_ks (same thread -> weights map: rows slot + 64 i, columns of slice s):
+// dh_{t-1}[k] += sum_i W_hh[i][k] dgh[i] -- a thread multiplies its 10 x 25 weights with its 10 values of dgh (LDS, slot-major: three
+// float4) into 25 column sums, the 8 row groups of the wave meet by a reduce-scatter over lanes (permlane32_swap, permlane16_swap,
+// row_ror:8 -- two values per instruction, ~50 operations for the 25 sums; lane group g ends with columns 8 m + bitrev3(g)), the 8
+// waves through part [8][R] in LDS.  Two barriers per step (k_sv_gru_bwd_all: three), ~240 LDS wave-instructions (~650).
+__device__ __forceinline__ void sv_permlane32_swap(float& x, float& y)   // rows 2,3 of x <-> rows 0,1 of y
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+__device__ __forceinline__ void sv_permlane16_swap(float& x, float& y)   // odd rows of x <-> even rows of y
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+}
+template <int SL, int NR, int KG>
+__global__ __launch_bounds__(512) void k_sv_gru_bwd_ks(const float* __restrict__ dHout, const float* __restrict__ Whh, const int32_t* __restrict__ seq_ptr,
+                                                       int T_one, int R, const float* __restrict__ Hprev, const float* __restrict__ Gr,
+                                                       const float* __restrict__ Gz, const float* __restrict__ Gn, const float* __restrict__ Ghn,
+                                                       float* __restrict__ dGI, float* __restrict__ dGH)
+{
+    constexpr int GS = (NR + 3) & ~3, NWT = NR * SL, CL = (NWT - KG + 3) / 4, PS = 8 * SL;
+    constexpr int N32 = (SL + 1) / 2, N16 = (N32 + 1) / 2, N8 = (N16 + 1) / 2;
+    static_assert(KG % 4 == 0 && KG <= NWT, "register-resident weights: whole float4 groups");
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // dg2 [64][GS] | part [8][PS] | wl [CL][512][4]
+    float* dg2 = sm;
+    float* part = sm + 64 * GS;
+    float* wl = part + 8 * PS;
+    const int R3 = 3 * R;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, s = lane & 7, slot = wv * 8 + (lane >> 3);
+    const int t0 = seq_ptr ? seq_ptr[blockIdx.x] : 0;
+    const int T = seq_ptr ? seq_ptr[blockIdx.x + 1] - t0 : T_one;
+    dHout += (size_t)t0 * R; Hprev += (size_t)t0 * R;
+    Gr += (size_t)t0 * R; Gz += (size_t)t0 * R; Gn += (size_t)t0 * R; Ghn += (size_t)t0 * R;
+    dGI += (size_t)t0 * R3; dGH += (size_t)t0 * R3;
+    const int last = R3 * R - 1;
+    auto wload = [&](int q) {
+        const int i = q / SL, kk = q % SL, row = slot + 64 * i, k = s * SL + kk;
+        const float v = Whh[min(row * R + k, last)];
+        return v * ((row < R3 && k < R && q < NWT) ? 1.f : 0.f);
+    };
+    float wr[KG];
+#pragma unroll
+    for (int q = 0; q < KG; ++q) wr[q] = wload(q);
+#pragma unroll 8
+    for (int q = 0; q < CL * 4; ++q) wl[((size_t)(q >> 2) * 512 + tid) * 4 + (q & 3)] = wload(KG + q);
+    for (int j = tid; j < 64 * GS + 8 * PS; j += 512) sm[j] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // gate threads: column gj = tid for tid < R; the threads beyond shadow column R - 1 (same loads, same arithmetic, same stores to
+    // the same places) so that the step has NO divergent block around its global loads and stores: behind an `if (tid < R)` hipcc
+    // cannot count the outstanding stores on both paths and waits vmcnt(0) -- a store round trip per time step
+    const int gj = min(tid, R - 1);
+    // where this gate thread's three rows of dgh live: row i -> [(i & 63)][i >> 6]
+    const int p0 = (gj & 63) * GS + (gj >> 6), p1 = ((R + gj) & 63) * GS + ((R + gj) >> 6), p2 = ((2 * R + gj) & 63) * GS + ((2 * R + gj) >> 6);
+    const bool b3 = (lane & 8) != 0;
+    const int rev = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // 4 b3 + 2 b4 + b5
+    float dh = 0.f;
+    float vd = 0.f, vr = 0.f, vz = 0.f, vn = 0.f, vhn = 0.f, vhp = 0.f;
+    if (T > 0) {
+        const size_t o = (size_t)(T - 1) * R + gj;
+        vd = dHout[o]; vr = Gr[o]; vz = Gz[o]; vn = Gn[o]; vhn = Ghn[o]; vhp = Hprev[o];
+    }
+    const float4* gv = (const float4*)(dg2 + slot * GS);
+    unsigned long long* stamps = (tid == 0 && blockIdx.x == 0 && g_sv_stamps) ? g_sv_stamps + 16 : nullptr;   // entries 16..31: this kernel
+    for (int t = T - 1; t >= 0; --t) {
+        const bool stamp = stamps && t >= T - 12 && t < T - 8;
+        if (stamp) stamps[(T - 9 - t) * 4 + 0] = __builtin_readcyclecounter();
+        {
+            const int j = gj;
+            const float d = dh + vd;
+            const float dn = d * (1.f - vz);
+            const float dzp = d * (vhp - vn) * vz * (1.f - vz);
+            const float dnp = dn * (1.f - vn * vn);
+            const float drp = dnp * vhn * vr * (1.f - vr);
+            const unsigned o = (unsigned)t * (unsigned)R3 + (unsigned)j, oz = o + (unsigned)R, on = o + 2u * (unsigned)R;
+            dGI[o] = drp; dGI[oz] = dzp; dGI[on] = dnp;
+            dGH[o] = drp; dGH[oz] = dzp; dGH[on] = dnp * vr;
+            dg2[p0] = drp; dg2[p1] = dzp; dg2[p2] = dnp * vr;
+            dh = d * vz;   // the direct path h_{t-1} -> h_t; the path through the gates is added below
+        }
+        // the saved gate values of step t - 1, requested BEHIND this step's use of its own (and unconditionally, clamped): requested
+        // in front of it, under a condition, hipcc waits vmcnt(0) before the gate arithmetic -- for the loads it has just issued,
+        // a full L2 round trip per time step (1 200 cycles in this phase instead of ~300)
+        float nd, nr, nz, nn, nhn, nhp;
+        {
+            const unsigned o = (unsigned)max(t - 1, 0) * (unsigned)R + (unsigned)gj;   // 32-bit offsets: scalar base + one VGPR
+            nd = dHout[o]; nr = Gr[o]; nz = Gz[o]; nn = Gn[o]; nhn = Ghn[o]; nhp = Hprev[o];
+        }
+        if (stamp) stamps[(T - 9 - t) * 4 + 1] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (stamp) stamps[(T - 9 - t) * 4 + 2] = __builtin_readcyclecounter();
+        {
+            float4 gq[GS / 4];
+#pragma unroll
+            for (int q = 0; q < GS / 4; ++q) gq[q] = gv[q];
+            auto gval = [&](int i) { const float4 v = gq[i >> 2]; return (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; };
+            float acc[SL];
+#pragma unroll
+            for (int kk = 0; kk < SL; ++kk) acc[kk] = 0.f;
+#pragma unroll
+            for (int q = 0; q < KG; ++q) acc[q % SL] += wr[q] * gval(q / SL);
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                const float4 w = *(const float4*)(wl + ((size_t)c * 512 + tid) * 4);
+                const float we[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = KG + 4 * c + e;
+                    if (q < NWT) acc[q % SL] += we[e] * gval(q / SL);
+                }
+            }
+            // reduce-scatter over the 8 row groups of the wave (lane bits 5, 4, 3)
+            float u[N32];
+#pragma unroll
+            for (int p = 0; p < N32; ++p) {
+                float x = acc[2 * p], y = acc[2 * p + 1 < SL ? 2 * p + 1 : 2 * p];
+                sv_permlane32_swap(x, y);
+                u[p] = x + y;          // lanes 0-31: column 2p summed over bit 5, lanes 32-63: column 2p + 1
+            }
+            float v[N16];
+#pragma unroll
+            for (int n = 0; n < N16; ++n) {
+                float x = u[2 * n], y = u[2 * n + 1 < N32 ? 2 * n + 1 : 2 * n];
+                sv_permlane16_swap(x, y);
+                v[n] = x + y;          // even rows: u[2n] summed over bit 4, odd rows: u[2n + 1]
+            }
+#pragma unroll
+            for (int m = 0; m < N8; ++m) {
+                const float pz = v[2 * m], qz = v[2 * m + 1 < N16 ? 2 * m + 1 : 2 * m];
+                const float keep = b3 ? qz : pz, send = b3 ? pz : qz;
+                const float f = keep + sv_dpp<0x128>(send);   // row_ror:8
+                const int idx = 8 * m + rev;
+                if (idx < SL) part[wv * PS + s * SL + idx] = f;
+            }
+        }
+        if (stamp) stamps[(T - 9 - t) * 4 + 3] = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += part[w * PS + gj];
+            dh += a;
+        }
+        asm volatile("" : "+v"(nd), "+v"(nr), "+v"(nz), "+v"(nn), "+v"(nhn), "+v"(nhp));   // they landed a mat-vec ago: the wait belongs HERE
+        vd = nd; vr = nr; vz = nz; vn = nn; vhn = nhn; vhp = nhp;
+    }
+}
+
+extern "C" void rtxdbg_svae_set_stamps(unsigned long long* dev)   // measurement hook (tools/svae_stamps.py): 32 device entries (forward 0..15, backward 16..31); not part of the ABI
 {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sv_stamps), &dev, sizeof(dev));
 }
@@ -1209,6 +1364,11 @@ int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out)
         if (!(off && off[0] == '0') && lds <= 160 * 1024 &&
             hipFuncSetAttribute((const void*)k_sv_gru_fwd_ks<SV_KS_SL, SV_KS_NR, SV_KS_KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             s->gru_ks_lds = lds;
+        const char* offb = getenv("RTX_SVAE_GRU_BWD_KS");
+        const size_t ldsb = sizeof(float) * (64 * ((SV_KS_NR + 3) & ~3) + 8 * 8 * SV_KS_SL + (size_t)((SV_KS_NR * SV_KS_SL - SV_KS_KG + 3) / 4) * 512 * 4);
+        if (!(offb && offb[0] == '0') && ldsb <= 160 * 1024 &&
+            hipFuncSetAttribute((const void*)k_sv_gru_bwd_ks<SV_KS_SL, SV_KS_NR, SV_KS_KG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess)
+            s->gru_bwd_ks_lds = ldsb;
     }
     if (R <= 1024) {
         // LDS of the weight-resident backward recurrence: dh [Rp] | dgh [NC * RP] | part [NC * R] | wl [CL][1024][4]
@@ -1350,7 +1510,10 @@ static int sv_train(rtx_svae* s, const int32_t* items, int T, const int32_t* seq
     hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, nll_scale, kl_scale, loss_out,
                        loss_accum);
     // ---- GRU backward through time, then its weight gradients over all steps at once
-    if (s->gru_bwd_lds > 0)
+    if (s->gru_bwd_ks_lds > 0)
+        hipLaunchKernelGGL((k_sv_gru_bwd_ks<SV_KS_SL, SV_KS_NR, SV_KS_KG>), dim3(seq_ptr ? n_seq : 1), dim3(512), s->gru_bwd_ks_lds, st, s->dH,
+                           s->params[sv_tail(s, SV_T_WHH)], seq_ptr, T, R, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
+    else if (s->gru_bwd_lds > 0)
         hipLaunchKernelGGL(k_sv_gru_bwd_all<SV_GRU_KRB>, dim3(seq_ptr ? n_seq : 1), dim3(1024), s->gru_bwd_lds, st, s->dH, s->params[sv_tail(s, SV_T_WHH)],
                            seq_ptr, T, R, s->gru_nc, s->gru_rp, s->Hprev, s->Gr, s->Gz, s->Gn, s->Ghn, s->dGI, s->dGH);
     else

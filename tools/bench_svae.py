@@ -77,15 +77,15 @@ def main():
            "pack": a.pack, "users_per_s": users_t / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / users_t * 1e3,
            "ms_per_optimizer_step": dt / (n - w) * 1e3, "mean_len": steps_t / users_t, "users_timed": users_t,
            "optimizer_steps_timed": n - w, "dtype": "f32"}
-    # the recurrences (k_sv_gru_fwd_ks / k_sv_gru_bwd_all: one persistent workgroup per sequence) keep W_hh resident -- 180 / 88
+    # the recurrences (k_sv_gru_fwd_ks / k_sv_gru_bwd_ks: one persistent workgroup per sequence) keep W_hh resident -- 180 of 250
     # weights per thread in registers, the rest in LDS -- so what a time step moves is the LDS-resident part of the weights
-    # (18 x 8 KB forward + 128 KB backward at R = 200) through one CU's LDS port (128 B/clk at 2.4 GHz = 307 GB/s per sequence in
+    # (18 x 8 KB forward + 18 x 8 KB backward at R = 200) through one CU's LDS port (128 B/clk at 2.4 GHz = 307 GB/s per sequence in
     # flight).  `achieved` prices those bytes for the LONGEST sequence of every step (the recurrences of a pack run side by side)
     # against the WHOLE step time -- a lower bound for the recurrence kernels themselves, since the step also holds the GEMMs and
     # Adam; the forward kernel's own cycles per time step: tools/svae_stamps.py (profiles/r3_svae_gru_step_cycles.txt).
-    lds_bytes = (144 + 128) * 1024
+    lds_bytes = (144 + 144) * 1024
     ach = lds_bytes * longest / dt / 1e9
-    out["roofline"] = {"kernel": "k_sv_gru_fwd_ks + k_sv_gru_bwd_all (weights resident in registers + LDS, one workgroup per sequence)",
+    out["roofline"] = {"kernel": "k_sv_gru_fwd_ks + k_sv_gru_bwd_ks (weights resident in registers + LDS, one workgroup per sequence)",
                        "bound": "lds_port_of_one_cu", "achieved": ach, "peak": 307.2, "unit": "GB/s per sequence in flight", "frac": ach / 307.2,
                        "traffic": None, "algorithmic_bytes_per_time_step": lds_bytes,
                        "note": "lower bound (whole-step time); the recurrences are latency-bound: two / three barriers and an LDS round trip per step"}
