@@ -95,7 +95,10 @@ typedef __attribute__((ext_vector_type(4))) float sv_f32x4;
 // tens of GFLOP and the matrix pipes carry them.  The operands are still read in place with two strides.
 __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
 {
-    __shared__ float sA[16][65], sB[16][65];
+    // (K chunks of 32 instead of 16 -- twice the MFMA time per chunk over the next chunk's load latency -- measured slower per
+    //  user, 1 164 vs 1 194 users/s: the per-user products are a handful of workgroups each, bound by their first loads and the launch)
+    constexpr int KC = 16, NQ = KC / 4;
+    __shared__ float sA[KC][65], sB[KC][65];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -105,19 +108,19 @@ __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int kbeg = g.kchunk ? blockIdx.z * g.kchunk : 0;
     const int kend = g.kchunk ? min(g.K, kbeg + g.kchunk) : g.K;
-    // 64 x 16 elements per operand and K chunk, 4 per thread; the faster-varying thread index follows the unit-stride axis.
+    // 64 x KC elements per operand and K chunk, NQ per thread; the faster-varying thread index follows the unit-stride axis.
     // The next chunk's values are requested (into registers) before this chunk's MFMAs, so their latency runs under them.
-    int amm[4], akk[4], bnn[4], bkk[4];
+    int amm[NQ], akk[NQ], bnn[NQ], bkk[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int e = tid + q * 256;
-        if (g.sak == 1) { akk[q] = e & 15; amm[q] = e >> 4; } else { amm[q] = e & 63; akk[q] = e >> 6; }
-        if (g.sbk == 1) { bkk[q] = e & 15; bnn[q] = e >> 4; } else { bnn[q] = e & 63; bkk[q] = e >> 6; }
+        if (g.sak == 1) { akk[q] = e % KC; amm[q] = e / KC; } else { amm[q] = e & 63; akk[q] = e >> 6; }
+        if (g.sbk == 1) { bkk[q] = e % KC; bnn[q] = e / KC; } else { bnn[q] = e & 63; bkk[q] = e >> 6; }
     }
-    float ra[4], rb[4];
+    float ra[NQ], rb[NQ];
     auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int m = m0 + amm[q], k = k0 + akk[q];
             ra[q] = (m < g.M && k < kend) ? g.A[(size_t)m * g.sam + (size_t)k * g.sak] : 0.f;
             const int n = n0 + bnn[q], kb = k0 + bkk[q];
@@ -125,32 +128,46 @@ __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
         }
     };
     if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    for (int k0 = kbeg; k0 < kend; k0 += KC) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { sA[akk[q]][amm[q]] = ra[q]; sB[bkk[q]][bnn[q]] = rb[q]; }
+        for (int q = 0; q < NQ; ++q) { sA[akk[q]][amm[q]] = ra[q]; sB[bkk[q]][bnn[q]] = rb[q]; }
         __syncthreads();
-        if (k0 + 16 < kend) fetch(k0 + 16);
+        if (k0 + KC < kend) fetch(k0 + KC);
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 2)
+        for (int kk = 0; kk < KC; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kk + lk][wm + li], sB[kk + lk][wn + li], acc, 0, 0, 0);
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // What the epilogue reads is requested ONCE, up front, from clamped addresses (the bias of this lane's column; for the tanh'
+    // mask all 16 values of Q): read per element under the row guard they were 16 dependent L2 round trips -- a load and a
+    // vmcnt(0) per element -- about 3 us per launch of a kernel that takes 12.
     const int n = n0 + wn + li;
     if (n >= g.N) return;
+    const int mb = m0 + wm + 4 * lk;
+    const bool raw = g.kchunk != 0;
+    float bv = 0.f;
+    if (!raw && (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH)) bv = g.bias[n];
+    float qv[16];
+    if (!raw && g.epi == SV_EPI_TANH_GRAD) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qv[e] = g.Q[(size_t)min(mb + (e & 3) + 8 * (e >> 2), g.M - 1) * g.ldq + n];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qv[e] = 0.f;
+    }
+    float* out = raw ? g.part + (size_t)blockIdx.z * g.M * g.N : g.C;
+    const size_t ldo = raw ? (size_t)g.N : (size_t)g.ldc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm + (e & 3) + 8 * (e >> 2) + 4 * lk;
-        if (m >= g.M) continue;
+        const int m = mb + (e & 3) + 8 * (e >> 2);
         float v = g.alpha * acc[e];
-        if (g.kchunk) {
-            g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = v;
-            continue;
+        if (!raw) {
+            v += bv;
+            if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
+            v *= (1.f - qv[e] * qv[e]);
         }
-        if (g.epi == SV_EPI_BIAS || g.epi == SV_EPI_BIAS_TANH) v += g.bias[n];
-        if (g.epi == SV_EPI_BIAS_TANH) v = tanhf(v);
-        if (g.epi == SV_EPI_TANH_GRAD) { const float q = g.Q[(size_t)m * g.ldq + n]; v *= (1.f - q * q); }
-        g.C[(size_t)m * g.ldc + n] = v;
+        if (m < g.M) out[(size_t)m * ldo + n] = v;
     }
 }
 
