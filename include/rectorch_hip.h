@@ -284,6 +284,11 @@ typedef struct {
 } rtx_svae_cfg;
 int rtx_svae_create(const rtx_svae_cfg* cfg, rtx_svae** out);
 int rtx_svae_destroy(rtx_svae* s);
+/* "gemm_bf16" (0 / 1, default 0): every matrix product of the model (input projection, encoder / decoder layers, their data and
+ * weight gradients) takes its operands rounded to bf16 and accumulates in float32 on the bf16 MFMA -- the dtype BASELINE.json
+ * configs[4] names; the GRU recurrences, the losses, the master weights and Adam stay float32.  Default: float32 products (the
+ * reference's arithmetic, ~1e-6 parity). */
+int rtx_svae_set_option(rtx_svae* s, const char* key, int32_t value);
 int32_t rtx_svae_n_tensors(const rtx_svae* s);
 int rtx_svae_tensor_shape(const rtx_svae* s, int32_t t, int32_t* rows, int32_t* cols);
 int rtx_svae_bind(rtx_svae* s, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq);

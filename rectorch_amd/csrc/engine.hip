@@ -624,7 +624,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 5; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step)
+int32_t rtx_abi_version(void) { return 6; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step); 6: rtx_svae_set_option
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,

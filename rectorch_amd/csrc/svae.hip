@@ -24,6 +24,7 @@
 #include "rtx_kernels.h"
 
 #include <math.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 
@@ -57,6 +58,7 @@ struct rtx_svae {
     float* WhhT = nullptr;           // [R][3R] transposed recurrent weights (refreshed per forward)
     size_t gru_fwd_lds = 0;          // > 0: the weight-resident forward recurrence runs, with this much dynamic LDS
     size_t gru_rows_lds = 0;         // > 0: ... its 512-thread whole-row form (round 3), preferred when it fits
+    int opt_gemm_bf16 = 0;           // rtx_svae_set_option "gemm_bf16": bf16 operands (f32 accumulate) in every k_sv_gemm product
     size_t gru_bwd_ks_lds = 0;       // > 0: the backward recurrence in the same K-sliced layout
     size_t gru_ks_lds = 0;           // > 0: ... its K-sliced form (round 3), for 8 SL >= R and 64 NR >= 3R
     int opt_gru_rows = 1;            // measurement knob (RTX_SVAE_GRU_ROWS=0 in the environment at create time)
@@ -93,12 +95,18 @@ typedef __attribute__((ext_vector_type(4))) float sv_f32x4;
 // A[l & 31][k = l >> 5] and B[k = l >> 5][l & 31], products and sums in float32).  Round 1 computed the tile with scalar FMAs
 // (8 LDS floats per 16 FMAs per thread: LDS-bound); with several users packed per step these products are [sum T, .] GEMMs of
 // tens of GFLOP and the matrix pipes carry them.  The operands are still read in place with two strides.
+// BF = true (rtx_svae_set_option "gemm_bf16", the dtype BASELINE.json configs[4] names): the operands are rounded to bf16
+// (round-to-nearest-even) on their way into LDS, stored row-major [m][16 k] so that a lane's eight k values are ONE 16-byte read,
+// and a chunk is ONE v_mfma_f32_32x32x16_bf16 per wave instead of eight float32 MFMAs; sums, outputs, master weights stay float32.
+typedef __attribute__((ext_vector_type(8))) __bf16 sv_bf16x8;
+template <bool BF>
 __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
 {
     // (K chunks of 32 instead of 16 -- twice the MFMA time per chunk over the next chunk's load latency -- measured slower per
     //  user, 1 164 vs 1 194 users/s: the per-user products are a handful of workgroups each, bound by their first loads and the launch)
     constexpr int KC = 16, NQ = KC / 4;
-    __shared__ float sA[KC][65], sB[KC][65];
+    __shared__ float sA[BF ? 1 : KC][65], sB[BF ? 1 : KC][65];
+    __shared__ __attribute__((aligned(16))) bf16_t hA[BF ? 64 : 1][24], hB[BF ? 64 : 1][24];   // rows of 48 bytes: 16 k + padding
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -129,13 +137,25 @@ __global__ __launch_bounds__(256) void k_sv_gemm(const SvGemm g)
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += KC) {
+        if constexpr (BF) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { sA[akk[q]][amm[q]] = ra[q]; sB[bkk[q]][bnn[q]] = rb[q]; }
+            for (int q = 0; q < NQ; ++q) { hA[amm[q]][akk[q]] = f32_to_bf16(ra[q]); hB[bnn[q]][bkk[q]] = f32_to_bf16(rb[q]); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { sA[akk[q]][amm[q]] = ra[q]; sB[bkk[q]][bnn[q]] = rb[q]; }
+        }
         __syncthreads();
         if (k0 + KC < kend) fetch(k0 + KC);
+        if constexpr (BF) {
+            // 32x32x16: lane l feeds row l & 31, k = 8 (l >> 5) .. + 7 of both operands
+            const sv_bf16x8 a = *(const sv_bf16x8*)&hA[wm + li][lk * 8];
+            const sv_bf16x8 b = *(const sv_bf16x8*)&hB[wn + li][lk * 8];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kk + lk][wm + li], sB[kk + lk][wn + li], acc, 0, 0, 0);
+            for (int kk = 0; kk < KC; kk += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kk + lk][wm + li], sB[kk + lk][wn + li], acc, 0, 0, 0);
+        }
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -1203,10 +1223,12 @@ static int sv_gemm(rtx_svae* s, hipStream_t st, const float* A, long sam, long s
         g.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
         splits = (K + g.kchunk - 1) / g.kchunk;
         g.part = lane ? s->part2 : s->part;   // the side stream sums into its own buffer
-        hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, g);
+        if (s->opt_gemm_bf16) hipLaunchKernelGGL(k_sv_gemm<true>, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(k_sv_gemm<false>, dim3((N + 63) / 64, (M + 63) / 64, splits), dim3(256), 0, st, g);
         hipLaunchKernelGGL(k_sv_splitk_reduce, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, st, g, splits);
     } else {
-        hipLaunchKernelGGL(k_sv_gemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+        if (s->opt_gemm_bf16) hipLaunchKernelGGL(k_sv_gemm<true>, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(k_sv_gemm<false>, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;
@@ -1430,6 +1452,17 @@ int rtx_svae_destroy(rtx_svae* s)
 }
 
 int32_t rtx_svae_n_tensors(const rtx_svae* s) { return s ? s->n_tensors : 0; }
+
+int rtx_svae_set_option(rtx_svae* s, const char* key, int32_t value)
+{
+    RTX_CHECK(s && key, RTX_EINVAL, "svae_set_option: NULL argument");
+    if (!strcmp(key, "gemm_bf16")) s->opt_gemm_bf16 = value != 0;
+    else {
+        rtx_set_error("svae_set_option: unknown key '%s' (gemm_bf16)", key);
+        return RTX_EINVAL;
+    }
+    return RTX_OK;
+}
 
 int rtx_svae_tensor_shape(const rtx_svae* s, int32_t t, int32_t* rows, int32_t* cols)
 {

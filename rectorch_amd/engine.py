@@ -539,6 +539,10 @@ class SvaeEngine:
         self.n_tensors = lib().rtx_svae_n_tensors(h)
         self._keep = []
 
+    def set_option(self, key, value):
+        """``"gemm_bf16"``: bf16 operands / float32 accumulate in every matrix product of the model (include/rectorch_hip.h)"""
+        check(lib().rtx_svae_set_option(self.handle, key.encode(), int(value)))
+
     def bind(self, params, grads=None, exp_avg=None, exp_avg_sq=None):
         n = self.n_tensors
         assert len(params) == n, "expected %d parameter tensors, got %d" % (n, len(params))

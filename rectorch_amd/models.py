@@ -768,12 +768,21 @@ class SVAE(MultiVAE):
     svae_net : :class:`rectorch_amd.nets.SVAE_net`
     beta, anneal_steps, learning_rate
         As in :class:`MultiVAE`.
+    numerics : "fp32" (default: the reference's arithmetic) or "bf16" -- every matrix product of the model with bf16 operands and
+        float32 accumulation on the bf16 MFMA (what ``BASELINE.json`` ``configs[4]`` names); the GRU recurrences, the losses,
+        the master weights and Adam stay float32.  Not in the reference's signature.
     """
     def __init__(self,
                  svae_net,
                  beta=1.,
                  anneal_steps=0,
-                 learning_rate=1e-3):
+                 learning_rate=1e-3,
+                 numerics="fp32"):
+        if numerics not in ("fp32", "bf16"):
+            raise ValueError("numerics must be 'fp32' or 'bf16', got %r" % (numerics,))
+        if getattr(svae_net, "_svae_engine", None) is not None and getattr(svae_net, "svae_numerics", "fp32") != numerics:
+            svae_net._svae_engine = None          # built for the other arithmetic: rebuilt on first use
+        svae_net.svae_numerics = numerics
         super(SVAE, self).__init__(svae_net,
                                    beta=beta,
                                    anneal_steps=anneal_steps,

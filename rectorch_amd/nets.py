@@ -323,6 +323,8 @@ class SVAE_net(VAE_net):
         if eng is None or eng.max_len < seq_len:
             eng = SvaeEngine(self.n_items, self.embed_size, self.rnn_size, self.enc_dims, self.dec_dims,
                              max_len=max(256, 2 * int(seq_len)))
+            if getattr(self, "svae_numerics", "fp32") == "bf16":     # set by SVAE(..., numerics="bf16")
+                eng.set_option("gemm_bf16", 1)
             self._svae_engine = eng
         params = [p.data for p in self._param_list()]
         pkey = tuple(t.data_ptr() for t in params)

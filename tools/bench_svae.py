@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--k", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--pack", type=int, default=1, help="users per optimizer step (SVAE_Sampler(pack=N); 1 = the reference's per-user step)")
+    ap.add_argument("--numerics", default="fp32", choices=["fp32", "bf16"], help="bf16: bf16 operands / f32 accumulate in the matrix products")
     a = ap.parse_args()
     rng = np.random.RandomState(1)
     lens = np.clip(rng.lognormal(np.log(a.mean_len) - 0.5, 1.0, size=a.users).astype(int), 5, a.max_len)
@@ -47,7 +48,7 @@ def main():
     torch.manual_seed(0)
     net = SVAE_net(n_items=a.items, embed_size=256, rnn_size=200, dec_dims=[64, 150, a.items], enc_dims=[200, 150, 64])
     sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
-    model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=20000)
+    model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=20000, numerics=a.numerics)
     np.random.seed(0)
     smp = SVAE_Sampler(a.items, seqs, None, pred_type="next_k", k=a.k, shuffle=True, sparse=True, pack=a.pack)
     batches = []
@@ -76,7 +77,8 @@ def main():
                                             "packs of up to %d users per Adam step (mean of the users' losses; not in the reference)" % a.pack),
            "pack": a.pack, "users_per_s": users_t / dt, "timesteps_per_s": steps_t / dt, "ms_per_user": dt / users_t * 1e3,
            "ms_per_optimizer_step": dt / (n - w) * 1e3, "mean_len": steps_t / users_t, "users_timed": users_t,
-           "optimizer_steps_timed": n - w, "dtype": "f32"}
+           "optimizer_steps_timed": n - w,
+           "dtype": "f32" if a.numerics == "fp32" else "bf16 operands / f32 accumulate in the matrix products, f32 recurrences + Adam"}
     # the recurrences (k_sv_gru_fwd_ks / k_sv_gru_bwd_ks: one persistent workgroup per sequence) keep W_hh resident -- 180 of 250
     # weights per thread in registers, the rest in LDS -- so what a time step moves is the LDS-resident part of the weights
     # (18 x 8 KB forward + 18 x 8 KB backward at R = 200) through one CU's LDS port (128 B/clk at 2.4 GHz = 307 GB/s per sequence in
