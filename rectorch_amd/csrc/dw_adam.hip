@@ -29,7 +29,8 @@
 // 72 us on the n_items x 600 matrix: the kernel is bound by HBM at the read / write mix of an Adam update (4.7 - 4.9 TB/s of
 // measured traffic, what the stand-alone k_adam reaches as well), not by operand delivery.
 // The gradient never reaches HBM (RTX_DW_ADAM).  RTX_DW_GRAD stores it instead (float32 and / or a bf16 image) for the
-// data-parallel path, rtx_engine_loss_grads and tensors whose rows are not 16-byte periodic.
+// data-parallel path and rtx_engine_loss_grads.  Rows that are not a multiple of 4 floats (n_items = 17 769 ...) take the same
+// fused epilogue through dword-aligned 16-byte accesses (AL = false, round 3).
 #include "rtx_gemm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
@@ -61,11 +62,18 @@ template <int NJ> struct DwFrag {
 // panels (D, activations) that every tile of a run re-reads from L2
 __device__ __forceinline__ dw_f32x4 dw_ld_nt(const float* p) { return __builtin_nontemporal_load((const dw_f32x4*)p); }
 __device__ __forceinline__ void dw_st_nt(float* p, dw_f32x4 v) { __builtin_nontemporal_store(v, (dw_f32x4*)p); }
+// Rows that are NOT a multiple of four floats (n_items = 17 769 ...: most item counts) start at any 4-byte offset.  gfx950 takes
+// a global dwordx4 at any dword-aligned address (hipcc emits it for a 4-byte-aligned vector type), so the epilogue keeps its
+// four-neighbours-per-thread layout and only the row's last, partial group goes element by element.  (Four elements 32 columns
+// apart per thread with 4-byte accesses -- whole 128-byte runs per wave instruction -- measured 1.6x slower: 4x the instructions.)
+typedef dw_f32x4 dw_f32x4_u __attribute__((aligned(4)));
+__device__ __forceinline__ dw_f32x4 dw_ld_nt_u(const float* p) { return __builtin_nontemporal_load((const dw_f32x4_u*)p); }
+__device__ __forceinline__ void dw_st_nt_u(float* p, dw_f32x4 v) { __builtin_nontemporal_store(v, (dw_f32x4_u*)p); }
 
 // One float4 of a gradient tile -- elements (row, col .. col + 3) of the [M_real][N_real] tensor -- goes where the epilogue
 // says: through Adam (pv / mv / vv = p, exp_avg, exp_avg_sq loaded from the same place, clamped when out of range) or to the
 // gradient buffers.  Column N_real is the bias gradient (ones-column of the activations).
-template <int EPI>
+template <int EPI, bool AL = true>
 __device__ __forceinline__ void dw_finish4(const RtxDw& p, int row, int col, const dw_f32x4& g4, const dw_f32x4& pv, const dw_f32x4& mv,
                                            const dw_f32x4& vv, float reg)
 {
@@ -110,10 +118,26 @@ __device__ __forceinline__ void dw_finish4(const RtxDw& p, int row, int col, con
             mn[k] = m1;
             vn[k] = v1;
         }
-        dw_st_nt(A.p + off, pn);
-        dw_st_nt(A.m + off, mn);
-        dw_st_nt(A.v + off, vn);
-        if (A.gkeep) *(dw_f32x4*)(A.gkeep + off) = g4;
+        if constexpr (!AL) {
+            if (col + 4 > p.N_real) {   // the row's last group: N_real - col of its elements exist
+                for (int k = 0; k < p.N_real - col; ++k) {
+                    A.p[off + k] = pn[k]; A.m[off + k] = mn[k]; A.v[off + k] = vn[k];
+                    if (A.gkeep) A.gkeep[off + k] = g4[k];
+                    if (A.sh) ((bf16_t*)A.sh)[(size_t)row * A.ld_sh + col + k] = f32_to_bf16(pn[k]);
+                    if (A.shT) ((bf16_t*)A.shT)[(size_t)(col + k) * A.ld_shT + row] = f32_to_bf16(pn[k]);
+                }
+                return;
+            }
+            dw_st_nt_u(A.p + off, pn);
+            dw_st_nt_u(A.m + off, mn);
+            dw_st_nt_u(A.v + off, vn);
+            if (A.gkeep) *(dw_f32x4_u*)(A.gkeep + off) = g4;
+        } else {
+            dw_st_nt(A.p + off, pn);
+            dw_st_nt(A.m + off, mn);
+            dw_st_nt(A.v + off, vn);
+            if (A.gkeep) *(dw_f32x4*)(A.gkeep + off) = g4;
+        }
         if (A.sh) store4<bf16_t>((bf16_t*)A.sh + (size_t)row * A.ld_sh + col, pn[0], pn[1], pn[2], pn[3]);
         if (A.shT) {   // hidden layers only (a few hundred thousand elements): the transposed compute copy of the backward chain
 #pragma unroll
@@ -145,7 +169,8 @@ __device__ __forceinline__ float dw_dae_reg(const RtxDw& p)
 }
 
 // WM x WN waves; a wave owns 32 x (128 / WN) of the tile (NJ = 4 / WN accumulators): tile = (32 WM) x 128
-template <int WM, int WN, int NS, int EPI>
+// AL = false (fused Adam only): rows of N_real % 4 != 0 floats (dw_f32x4_u above)
+template <int WM, int WN, int NS, int EPI, bool AL = true>
 __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   // bid: workgroup number within this problem's grid
 {
     constexpr int NW = WM * WN, NTH = NW * 64, TM = WM * 32, NJ = 4 / WN;
@@ -179,14 +204,28 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
     if constexpr (EPI == RTX_DW_ADAM) {
         // out-of-range threads load a clamped (valid) address instead of branching around the load: a branch per load
         // makes hipcc wait vmcnt(0) behind each one
-        const int colc = min(col, p.N_real - 4);
+        if constexpr (AL) {
+            const int colc = min(col, p.N_real - 4);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
-            const size_t off = (size_t)rowc * p.N_real + colc;
-            pv[q] = dw_ld_nt(p.adam.p + off);
-            mv[q] = dw_ld_nt(p.adam.m + off);
-            vv[q] = dw_ld_nt(p.adam.v + off);
+            for (int q = 0; q < NP; ++q) {
+                const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
+                const size_t off = (size_t)rowc * p.N_real + colc;
+                pv[q] = dw_ld_nt(p.adam.p + off);
+                mv[q] = dw_ld_nt(p.adam.m + off);
+                vv[q] = dw_ld_nt(p.adam.v + off);
+            }
+        } else {
+            // the row's last group is partial: its thread loads the row's LAST four elements (a valid address); its own are taken
+            // from them, shifted, where they are consumed (below)
+            const int colc = min(col, p.N_real - 4);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
+                const size_t off = (size_t)rowc * p.N_real + colc;
+                pv[q] = dw_ld_nt_u(p.adam.p + off);
+                mv[q] = dw_ld_nt_u(p.adam.m + off);
+                vv[q] = dw_ld_nt_u(p.adam.v + off);
+            }
         }
     }
 
@@ -304,18 +343,32 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
 
     float reg = 0.f;
     if constexpr (EPI == RTX_DW_ADAM) reg = dw_dae_reg(p);
+    int sh = 0;   // AL = false, the thread of the row's last (partial) group: its elements sit sh places up in what it loaded
+    if constexpr (EPI == RTX_DW_ADAM && !AL) sh = (col < p.N_real && col > p.N_real - 4) ? col - (p.N_real - 4) : 0;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int lr = q * RPP + rowl;
         const dw_f32x4 g4 = *(const dw_f32x4*)(tile + lr * 128 + col4);
-        dw_finish4<EPI>(p, tm * TM + lr, col, g4, pv[q], mv[q], vv[q], reg);
+        if constexpr (EPI == RTX_DW_ADAM && !AL) {
+            dw_f32x4 a, b, c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kk = min(k + sh, 3);
+                a[k] = kk == 0 ? pv[q][0] : kk == 1 ? pv[q][1] : kk == 2 ? pv[q][2] : pv[q][3];
+                b[k] = kk == 0 ? mv[q][0] : kk == 1 ? mv[q][1] : kk == 2 ? mv[q][2] : mv[q][3];
+                c[k] = kk == 0 ? vv[q][0] : kk == 1 ? vv[q][1] : kk == 2 ? vv[q][2] : vv[q][3];
+            }
+            dw_finish4<EPI, AL>(p, tm * TM + lr, col, g4, a, b, c, reg);
+        } else {
+            dw_finish4<EPI, AL>(p, tm * TM + lr, col, g4, pv[q], mv[q], vv[q], reg);
+        }
     }
 }
 
-template <int WM, int WN, int NS, int EPI>
+template <int WM, int WN, int NS, int EPI, bool AL = true>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn(const RtxDw p)
 {
-    dw_tile<WM, WN, NS, EPI>(p, blockIdx.x);
+    dw_tile<WM, WN, NS, EPI, AL>(p, blockIdx.x);
 }
 
 // Several matrices in ONE launch (same K, same tile configuration, same epilogue): problem k owns the workgroups
@@ -327,22 +380,22 @@ struct RtxDwGroup {
     unsigned first[RTX_DW_GROUP_MAX + 1];
     RtxDw p[RTX_DW_GROUP_MAX];
 };
-template <int WM, int WN, int NS, int EPI>
+template <int WM, int WN, int NS, int EPI, bool AL = true>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn_group(const RtxDwGroup g)
 {
     int k = 0;
 #pragma unroll
     for (int q = 1; q < RTX_DW_GROUP_MAX; ++q)
         if (q < g.n && blockIdx.x >= g.first[q]) k = q;
-    dw_tile<WM, WN, NS, EPI>(g.p[k], blockIdx.x - g.first[k]);
+    dw_tile<WM, WN, NS, EPI, AL>(g.p[k], blockIdx.x - g.first[k]);   // (AL = false serves the aligned problems of the group as well)
 }
 
-template <int WM, int WN, int NS, int EPI> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream)
+template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream)
 {
     constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn_group<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn_group<WM, WN, NS, EPI, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     RtxDwGroup g = {};
@@ -354,36 +407,36 @@ template <int WM, int WN, int NS, int EPI> static int dw_launch_group(const RtxD
         total += (unsigned)(8 * ((d[k].m_tiles * d[k].n_tiles + 7) / 8));
     }
     g.first[n] = total;
-    hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
+    hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI, AL>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
 
-template <int WM, int WN, int NS, int EPI> static int dw_launch(const RtxDw& d, hipStream_t stream)
+template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(const RtxDw& d, hipStream_t stream)
 {
     constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     const int total = d.m_tiles * d.n_tiles;
     const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
-    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI>), grid, dim3(WM * WN * 64), LDS, stream, d);
+    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI, AL>), grid, dim3(WM * WN * 64), LDS, stream, d);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
 
 int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : cfg == RTX_DW_128x128 ? 128 : 32; }
 
-template <int EPI> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
+template <int EPI, bool AL = true> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
 {
     switch (cfg) {
-    case RTX_DW_32x128: return dw_launch<1, 4, 3, EPI>(d, stream);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
-    case RTX_DW_32x128_S2: return dw_launch<1, 4, 2, EPI>(d, stream);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
-    case RTX_DW_128x128: return dw_launch<4, 2, 2, EPI>(d, stream);     // 8 waves, 2 stages (64 KB), 32 x 64 per wave: half the
-                                                                         //   operand bytes per parameter of the 64-row tile
-    default: return dw_launch<2, 4, 3, EPI>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
+    case RTX_DW_32x128: return dw_launch<1, 4, 3, EPI, AL>(d, stream);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
+    case RTX_DW_32x128_S2: return dw_launch<1, 4, 2, EPI, AL>(d, stream);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
+    case RTX_DW_128x128: return dw_launch<4, 2, 2, EPI, AL>(d, stream);     // 8 waves, 2 stages (64 KB), 32 x 64 per wave: half the
+                                                                             //   operand bytes per parameter of the 64-row tile
+    default: return dw_launch<2, 4, 3, EPI, AL>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
     }
 }
 
@@ -396,8 +449,9 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
     if (epilogue == RTX_DW_ADAM) {
-        RTX_CHECK((d.N_real & 3) == 0 && d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of a multiple of 4 floats (got %d)", d.N_real);
+        RTX_CHECK(d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of at least 4 floats (got %d)", d.N_real);
         RTX_CHECK(d.adam.p && d.adam.m && d.adam.v, RTX_EINVAL, "dw: Adam state is NULL");
+        if (d.N_real & 3) return dw_launch_cfg<RTX_DW_ADAM, false>(d, cfg, stream);   // rows at any 4-byte offset: dword-aligned 16-byte accesses
         RTX_CHECK((((uintptr_t)d.adam.p | (uintptr_t)d.adam.m | (uintptr_t)d.adam.v | (uintptr_t)d.adam.gkeep) & 15) == 0, RTX_EINVAL,
                   "dw: Adam buffers must be 16-byte aligned");
         return dw_launch_cfg<RTX_DW_ADAM>(d, cfg, stream);
@@ -408,13 +462,13 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
 
 // d[0..n): same d.k_slices; small problems first keeps the big one's tail free of stragglers.  RTX_DW_GRAD groups serve the
 // data-parallel step (gradients leave as the float32 / bf16 images the exchange sends).
-template <int EPI> static int dw_launch_group_cfg(const RtxDw* d, int n, int cfg, hipStream_t stream)
+template <int EPI, bool AL = true> static int dw_launch_group_cfg(const RtxDw* d, int n, int cfg, hipStream_t stream)
 {
     switch (cfg) {
-    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, EPI>(d, n, stream);
-    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, EPI>(d, n, stream);
-    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, EPI>(d, n, stream);
-    default: return dw_launch_group<2, 4, 3, EPI>(d, n, stream);
+    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, EPI, AL>(d, n, stream);
+    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, EPI, AL>(d, n, stream);
+    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, EPI, AL>(d, n, stream);
+    default: return dw_launch_group<2, 4, 3, EPI, AL>(d, n, stream);
     }
 }
 
@@ -424,19 +478,22 @@ int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_
     if (n == 1) return rtx_dw_launch(d[0], epilogue, cfg, stream);
     RTX_CHECK(epilogue == RTX_DW_ADAM || epilogue == RTX_DW_GRAD, RTX_EINVAL, "dw group: bad epilogue %d", epilogue);
     RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    bool any_unaligned = false;   // one matrix with rows of N_real % 4 != 0 floats: the whole launch takes the unaligned epilogue
     for (int k = 0; k < n; ++k) {
         const RtxDw& q = d[k];
         RTX_CHECK(q.A && q.B && q.m_tiles > 0 && q.n_tiles > 0 && q.k_slices >= 2 && q.k_slices == d[0].k_slices, RTX_EINVAL, "dw group: bad problem %d", k);
         RTX_CHECK(q.M_real >= 1 && q.N_real >= 1, RTX_EINVAL, "dw group: problem %d is empty", k);
         if (epilogue == RTX_DW_ADAM) {
-            RTX_CHECK((q.N_real & 3) == 0 && q.N_real >= 4 && q.adam.p && q.adam.m && q.adam.v, RTX_EINVAL, "dw group: problem %d is not fusable", k);
-            RTX_CHECK((((uintptr_t)q.adam.p | (uintptr_t)q.adam.m | (uintptr_t)q.adam.v | (uintptr_t)q.adam.gkeep) & 15) == 0, RTX_EINVAL,
-                      "dw: Adam buffers must be 16-byte aligned");
+            RTX_CHECK(q.N_real >= 4 && q.adam.p && q.adam.m && q.adam.v, RTX_EINVAL, "dw group: problem %d is not fusable", k);
+            if (q.N_real & 3) any_unaligned = true;
+            else
+                RTX_CHECK((((uintptr_t)q.adam.p | (uintptr_t)q.adam.m | (uintptr_t)q.adam.v | (uintptr_t)q.adam.gkeep) & 15) == 0, RTX_EINVAL,
+                          "dw: Adam buffers must be 16-byte aligned");
         } else {
             RTX_CHECK((q.N_real & 3) != 0 || ((((uintptr_t)q.gW) & 15) == 0 && (((uintptr_t)q.g16) & 7) == 0), RTX_EINVAL,
                       "dw: gradient buffers must be 16-byte aligned");
         }
     }
-    if (epilogue == RTX_DW_ADAM) return dw_launch_group_cfg<RTX_DW_ADAM>(d, n, cfg, stream);
+    if (epilogue == RTX_DW_ADAM) return any_unaligned ? dw_launch_group_cfg<RTX_DW_ADAM, false>(d, n, cfg, stream) : dw_launch_group_cfg<RTX_DW_ADAM>(d, n, cfg, stream);
     return dw_launch_group_cfg<RTX_DW_GRAD>(d, n, cfg, stream);
 }

@@ -884,7 +884,7 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 // a multiple of 4 floats runs INSIDE its weight-gradient kernel (dw_adam.hip: the gradient never reaches HBM and the
 // optimizer's HBM traffic overlaps the matrix work); biases and the remaining tensors follow in one small launch.
 // Otherwise the gradients land in the bound buffers (data-parallel exchange, p.grad, float32 parity mode).
-static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && (l.in & 3) == 0 && l.in >= 4; }
+static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && l.in >= 4; }   // (rows of in % 4 != 0 floats: the strided epilogue, dw_adam.hip)
 static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
 
 // ---- the second stream of the step ------------------------------------------------------------------------------------------

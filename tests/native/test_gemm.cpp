@@ -488,10 +488,10 @@ static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, 
 }
 
 // Several matrices in one launch (rtx_dw_launch_group) must produce, bit for bit, what one launch per matrix produces.
-static int run_dw_group_case(int cfg)
+static int run_dw_group_case(int cfg, int odd = 0)   // odd: one matrix with rows of N % 4 != 0 floats (the whole launch takes the strided epilogue)
 {
     const int K_real = 250, Kp = rtx_pad_batch(K_real);
-    const int shapes[3][2] = {{70, 132}, {300, 200}, {130, 600}};
+    const int shapes[3][2] = {{70, 132}, {300, odd ? 201 : 200}, {130, 600}};
     struct Buf { bf16_t *D, *X, *sh[2]; float *p[2], *m[2], *v[2], *bp[2], *bm[2], *bv[2]; int Mp, Np; size_t P; };
     Buf b[3];
     RtxDw d[2][3];
@@ -544,7 +544,7 @@ static int run_dw_group_case(int cfg)
         hipFree(b[k].D); hipFree(b[k].X);
         for (int s = 0; s < 2; ++s) { hipFree(b[k].p[s]); hipFree(b[k].m[s]); hipFree(b[k].v[s]); hipFree(b[k].bp[s]); hipFree(b[k].bm[s]); hipFree(b[k].bv[s]); hipFree(b[k].sh[s]); }
     }
-    printf("[dw group] cfg%d 3 matrices in one launch vs one launch each: %ld differing buffers -> %s\n", cfg, diff, diff ? "FAIL" : "ok");
+    printf("[dw group%s] cfg%d 3 matrices in one launch vs one launch each: %ld differing buffers -> %s\n", odd ? " odd" : "", cfg, diff, diff ? "FAIL" : "ok");
     return diff ? 1 : 0;
 }
 
@@ -606,6 +606,26 @@ static int run_f32_case(const char* name, int form, int M, int N, int K, int spl
     return bad != 0;
 }
 
+static int run_dw_cases()
+{
+    int fails = 0;
+    for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
+        fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
+        fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
+        fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
+        fails += run_dw_case("adam-tall", cfg, RTX_DW_ADAM, 1000, 24, 128, 0.f, 0.f, 1);
+        fails += run_dw_case("adam-oddcols", cfg, RTX_DW_ADAM, 130, 301, 190, 0.f, 0.f, 1);        // rows of N % 4 != 0 floats: the strided epilogue
+        fails += run_dw_case("adam-odd-dae", cfg, RTX_DW_ADAM, 70, 133, 100, 0.2f, 0.001f, 1);
+        fails += run_dw_case("adam-odd-tall", cfg, RTX_DW_ADAM, 1000, 27, 128, 0.f, 0.f, 0);
+        fails += run_dw_case("grad", cfg, RTX_DW_GRAD, 300, 200, 250, 0.f, 0.f, 1);
+        fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
+        fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
+        fails += run_dw_group_case(cfg);
+        fails += run_dw_group_case(cfg, 1);
+    }
+    return fails;
+}
+
 int main(int argc, char** argv)
 {
     int fails = 0;
@@ -663,6 +683,11 @@ int main(int argc, char** argv)
             for (int K : {4096, 4160, 4032, 8192, 8256}) perf_dma("chan", RTX_FORM_NT, cfg, 4096, 4096, K, 1, RTX_EPI_STORE);
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "dw")) {   // only the weight-gradient (+ Adam) kernels
+        fails = run_dw_cases();
+        printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
+        return fails ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "big")) {   // only the big-tile GEMM lines (round 3)
         for (int cfg : {RTX_DMA_256x256, RTX_DMA_256x256_W4, RTX_DMA_512x128}) {
             for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
@@ -706,16 +731,7 @@ int main(int argc, char** argv)
         }
         fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
     }
-    for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
-        fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
-        fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
-        fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
-        fails += run_dw_case("adam-tall", cfg, RTX_DW_ADAM, 1000, 24, 128, 0.f, 0.f, 1);
-        fails += run_dw_case("grad", cfg, RTX_DW_GRAD, 300, 200, 250, 0.f, 0.f, 1);
-        fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
-        fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
-        fails += run_dw_group_case(cfg);
-    }
+    fails += run_dw_cases();
     for (int form : {RTX_FORM_NN, RTX_FORM_TN}) {
         fails += run_f32_case("store", form, 256, 384, 352, 1, RTX_EPI_STORE, 256, 384);
         fails += run_f32_case("splitk3", form, 256, 384, 352, 3, RTX_EPI_STORE, 256, 384);

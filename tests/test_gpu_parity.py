@@ -1187,8 +1187,9 @@ def test_custom_op_train_step_dense_equals_train_batch():
 @pytest.mark.parametrize("numerics", ["fp32", "bf16"])
 def test_config3_netflix_shape_two_steps_vs_oracle(numerics):
     """BASELINE.json configs[3] shape, one GPU's share (I = 17769, 512 users): two steps with injected masks / noise against the
-    C oracle, parameters of all 8 tensors.  W1 is [600, 17769]: rows that are not a multiple of 4 floats take the
-    gradient-store + flat multi-tensor Adam path, W4 [17769, 600] the fused weight-gradient + Adam kernel (bf16)."""
+    C oracle, parameters of all 8 tensors.  W1 is [600, 17769]: rows that are not a multiple of 4 floats -- the fused
+    weight-gradient + Adam kernel takes them with dword-aligned 16-byte accesses and an element-wise last group (round 3;
+    before: gradient store + flat multi-tensor Adam); W4 [17769, 600] the aligned form (bf16)."""
     from oracle import c_oracle
     from rectorch_amd.utils import synth_interactions, hash_state_dict
     from rectorch_amd.samplers import DataSampler
