@@ -938,13 +938,15 @@ def test_svae_reference_api_train_save_load():
     np.testing.assert_allclose(losses[True], losses[False], rtol=1e-6)
 
 
-def test_svae_vs_oracle_longer_sequences():
-    """ml-1m-like widths (embedding 64, GRU 96, latent 32) and sequences of 1..300 steps against the numpy oracle"""
+@pytest.mark.parametrize("R", [96, 163])
+def test_svae_vs_oracle_longer_sequences(R):
+    """ml-1m-like widths (embedding 64, latent 32) and sequences of 1..300 steps against the numpy oracle: GRU 96 (the whole-row
+    recurrence kernel) and GRU 163 -- the K-sliced kernels with a last K slice and last row groups that are only partly real"""
     from oracle.svae_oracle import SvaeOracle
     from rectorch_amd.nets import SVAE_net
     from rectorch_amd.models import SVAE
     torch.manual_seed(3)
-    I, E, R, H, L, D = 500, 64, 96, 80, 32, 72
+    I, E, H, L, D = 500, 64, 80, 32, 72
     net = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
     sd = {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
     model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=0)
