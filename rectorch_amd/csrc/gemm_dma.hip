@@ -35,6 +35,9 @@
 // 885-906 vs 811-849 TF/s on four waves, 831-864 vs 784-808 on eight); the step's tiles keep 0 (its data-gradient GEMM shares the
 // device with the weight kernel, where an earlier DMA burst cost more than it gained -- DESIGN 4.4)
 #define GD_SCHED_BIG (GD_SCHED == 0 ? 3 : GD_SCHED)
+#ifndef GD_SCHED_S2
+#define GD_SCHED_S2 GD_SCHED   // the step's data-gradient tile (128x128, two stages); -DGD_SCHED_S2=3 builds the A/B variant
+#endif
 // measurement: shader-clock stamps of K slices 8..15 taken by wave 0 of workgroup 0 (tests/native/test_gemm.cpp "stamps"):
 // [slice][0] top of the iteration, [1] my DMA pieces have landed (vmcnt), [2] past the barrier, [3] compute done; entries 32..63 the same
 // for a loader wave; [64] kernel entry, [65] the 100-MHz clock there, [66] main loop done, [67] epilogue stored, [68] the 100-MHz clock there
@@ -511,7 +514,7 @@ template <int FORM, int EPI> static int gd_launch_cfg(const RtxGemm& g, dim3 gri
     switch (g.tile_shape) {
     case RTX_DMA_512x128: return gd_launch<FORM, EPI, 4, 2, 4, 2, 2>(g, grid, stream);
     case RTX_DMA_256x256: return gd_launch<FORM, EPI, 2, 4, 4, 2, 2, 0, GD_SCHED_BIG>(g, grid, stream);
-    case RTX_DMA_128x128_S2: return gd_launch<FORM, EPI, 2, 2, 2, 2, 2>(g, grid, stream);
+    case RTX_DMA_128x128_S2: return gd_launch<FORM, EPI, 2, 2, 2, 2, 2, 0, GD_SCHED_S2>(g, grid, stream);
     case RTX_DMA_256x256_W4: return gd_launch<FORM, EPI, 2, 2, 4, 4, 2, 0, GD_SCHED_BIG>(g, grid, stream);
     case RTX_DMA_256x256_LW: return gd_launch<FORM, EPI, 2, 4, 4, 2, 2, 4>(g, grid, stream);
     default: return gd_launch<FORM, EPI, 2, 2, 2, 2, 3>(g, grid, stream);
