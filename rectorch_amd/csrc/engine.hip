@@ -114,8 +114,15 @@ struct rtx_engine {
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
+    int opt_dw_persistent = 1;  // fused weight-gradient + Adam launches behind the chain run as a persistent grid (dw_adam.hip rtx_dw_tn_pers)
+    int opt_dw_side_persistent = 0;   // ... the one BESIDE the chain (side stream) does not: resident workgroups would hold the LDS the
+                                //   chain's data-gradient product needs until the whole matrix is done (measured: the chain then runs behind it)
     int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
+    int opt_logits16 = 1;       // bf16 training step: the logits leave their product as IEEE half, written where d loss / d logits
+                                //   (bf16, same size) goes, and the loss kernel turns them into it IN PLACE: 41 + 41 MB of float32
+                                //   logits traffic per ml-20m step become 21 + 21 MB (the log-sum-exp still comes from the float32
+                                //   accumulators; half keeps 11 significant bits -- the bf16 products' own error level)
     int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
     int opt_side_low_prio = 0;  // ... created with the lowest stream priority (1).  Round 3: OFF.  Neutral for the single-GPU step
                                 //   (307.1 / 308.0 vs 308.2 / 308.5 us, A/B in one call), and with a live RCCL communicator in the process
@@ -388,6 +395,10 @@ static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxC
 // writes logits to `logits` (ld = ldlog); with want_lse it also leaves the log-sum-exp partials (training).
 // The first layer as a sparse product (spmm_in.hip): bf16 numerics, a batch that names rows of a resident CSR matrix (its
 // longest row bounds the chunk stream), a first layer followed by an ordinary activation, weight rows that fit the LDS.
+// the training step's logits as half precision in the delta buffer (opt_logits16): needs the epilogue's log-sum-exp partials and
+// the register-staged product that writes them
+static bool logits16_on(const rtx_engine* e) { return e->bf16 && e->opt_logits16 && e->opt_lse_fuse && e->opt_nt_regstage; }
+
 static bool sparse_in_ok(const rtx_engine* e, const RtxCsrView* in, int Bp, int64_t* chunks)
 {
     if (!e->bf16 || !e->opt_sparse_in || e->NL < 2 || (e->vae && e->cfg.n_enc == 1)) return false;
@@ -460,6 +471,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
                 g.tile_shape = RTX_TILE_128x128;
                 g.m_tiles = Bp / 128; g.n_tiles = l.outp / 128;
                 if (want_lse && e->opt_lse_fuse) { g.lse_part = e->lse_part; g.lse_ld = e->lse_strips; }
+                if (want_lse && logits16_on(e)) { g.C16 = l.D; g.ldc16 = l.outp; }
                 RTX_TRY(rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_BIAS_ROWS, st));
             }
             break;
@@ -1003,6 +1015,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->opt_lse_fuse) { a.loss.part = e->lse_part; a.loss.n_strips = e->lse_strips; a.loss.part_ld = e->lse_strips; }
         if (e->vae) { a.loss.mu32 = e->mu32; a.loss.lv32 = e->lv32; a.loss.Z = e->Z; a.loss.beta = step->beta; }
         a.Bp = Bp; a.D = e->L[NL - 1].D; a.ldd = e->Ip;
+        if (logits16_on(e)) a.Y16 = a.D;   // run_forward left half-precision logits there
         TIMED("dlogits_loss");
         RTX_TRY(rtx_launch_dlogits(a, e->bf16, st));
     }
@@ -1090,7 +1103,8 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d;
             make_dw(li, d);
-            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, dw_cfg, ws);
+            const bool pers = (two && ws == e->side) ? e->opt_dw_side_persistent : e->opt_dw_persistent;
+            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, dw_cfg | (pers ? 0 : RTX_DW_ONE_PER_TILE), ws);
         }
         RtxGemm g = {};
         g.form = RTX_FORM_TN;
@@ -1290,7 +1304,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         make_dw(main_li, grp[ng++]);
         {
             ScopedTimer tm(e, "dW_adam_in", st);
-            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, dw_cfg, st));
+            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, dw_cfg | (e->opt_dw_persistent ? 0 : RTX_DW_ONE_PER_TILE), st));
         }
         RTX_TRY(reduce_loss(e->side));
         if (rest.n > 0) {   // gradients from both streams feed the leftover Adam launch: the side stream waits for this one, then runs it
@@ -1608,6 +1622,9 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     const std::string k(key);
     if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
+    else if (k == "logits16") e->opt_logits16 = value != 0;
+    else if (k == "dw_persistent") e->opt_dw_persistent = value != 0;
+    else if (k == "dw_side_persistent") e->opt_dw_side_persistent = value != 0;
     else if (k == "two_stream") e->opt_two_stream = value != 0;
     else if (k == "side_low_prio") {
         RTX_CHECK(!e->side, RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
@@ -1651,6 +1668,9 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     const std::string k(key);
     if (k == "fuse_adam") *value = e->opt_fuse_adam;
     else if (k == "lse_fuse") *value = e->opt_lse_fuse;
+    else if (k == "logits16") *value = e->opt_logits16;
+    else if (k == "dw_persistent") *value = e->opt_dw_persistent;
+    else if (k == "dw_side_persistent") *value = e->opt_dw_side_persistent;
     else if (k == "two_stream") *value = e->opt_two_stream;
     else if (k == "side_low_prio") *value = e->opt_side_low_prio;
     else if (k == "nt_regstage") *value = e->opt_nt_regstage;

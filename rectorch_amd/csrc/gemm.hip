@@ -283,6 +283,22 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) w[it] = *(const f32x4_t*)(wreg + (it * RPI + srow) * WLD + scol);
             __builtin_amdgcn_wave_barrier();
+            if (p.C16) {
+                // half-precision logits (the training step): 8 bytes per lane, LPR lanes = one row's WCOLS * 2 bytes (whole 128-byte
+                // lines); padding columns (>= N_real, < ldc16) receive don't-care values -- the loss kernel masks and zeroes them
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+#pragma unroll
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int orow = tm * BM + wm * 64 + i * 32 + it * RPI + srow;
+                    if (orow < p.M_real) {
+                        f16x4_t h;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) h[k] = (_Float16)__builtin_amdgcn_fmed3f(w[it][k], -65504.f, 65504.f);
+                        *(f16x4_t*)((_Float16*)p.C16 + (size_t)orow * p.ldc16 + col0 + scol) = h;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int orow = tm * BM + wm * 64 + i * 32 + it * RPI + srow;
@@ -369,6 +385,13 @@ int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t strea
     RTX_CHECK(g.m_tiles > 0 && g.n_tiles > 0 && g.k_slices > 0 && g.splits > 0, RTX_EINVAL, "gemm: empty problem");
     RTX_CHECK(epilogue == RTX_EPI_STORE || g.splits == 1, RTX_EINVAL, "gemm: split-K only with EPI_STORE");
     RTX_CHECK(epilogue >= RTX_EPI_STORE && epilogue <= RTX_EPI_GRAD, RTX_EINVAL, "gemm: bad epilogue %d", epilogue);
+    if (g.C16) {
+        int bm16, bn16;
+        rtx_gemm_tile_dims(g.tile_shape, &bm16, &bn16);
+        RTX_CHECK(epilogue == RTX_EPI_BIAS_ROWS && dtype == RTX_DT_BF16 && (g.ldc16 & 3) == 0 && (((uintptr_t)g.C16) & 7) == 0 &&
+                      g.ldc16 >= (long)g.n_tiles * bn16,
+                  RTX_EINVAL, "gemm: half-precision logits need the bias epilogue, bf16 operands and an 8-byte aligned [M][ldc16 >= N_pad] image");
+    }
     RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x256, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
     // 1-D grid laid out for the XCD-aware mapping in the kernel: 8 * ceil(groups / 8) * group_size workgroups
     const int tiles = g.m_tiles * g.n_tiles;

@@ -481,6 +481,32 @@ __global__ __launch_bounds__(256) void k_dlogits(const RtxDlogitsArgs a)
     }
     __syncthreads();
     float dot = 0.f;
+    if (sizeof(T) == 2 && a.Y16) {
+        // half-precision logits, possibly in place (Y16 == D): 8 elements = 16 bytes in, 16 bytes out per thread and pass
+        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+        const _Float16* y16 = (const _Float16*)a.Y16 + (size_t)b * a.ldd + c0;
+#pragma unroll 2
+        for (int i = tid * 8; i < cn; i += 256 * 8) {
+            const int col = c0 + i;
+            const f16x8_t yy = *(const f16x8_t*)(y16 + i);
+            const float4 t0 = *(const float4*)(timg + i), t1 = *(const float4*)(timg + i + 4);
+            const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool valid = col + e < L.I;
+                const float yv = (float)yy[e];
+                d[e] = valid ? sc * __expf(yv - lse) - tv[e] * L.inv_batch : 0.f;
+                if (valid) dot += tv[e] * yv;
+            }
+            uint4 o;
+            o.x = pack_bf16x2(d[0], d[1]);
+            o.y = pack_bf16x2(d[2], d[3]);
+            o.z = pack_bf16x2(d[4], d[5]);
+            o.w = pack_bf16x2(d[6], d[7]);
+            *(uint4*)((bf16_t*)Drow + i) = o;
+        }
+    } else
 #pragma unroll 4
     for (int i = tid * 4; i < cn; i += 256 * 4) {
         const int col = c0 + i;
@@ -524,6 +550,8 @@ int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream)
 {
     if (a.Bp <= 0) return RTX_OK;
     RTX_CHECK(a.loss.ldy % 4 == 0 && a.ldd % 8 == 0 && a.ldd >= a.loss.I, RTX_EINVAL, "dlogits: bad leading dimensions");
+    RTX_CHECK(!a.Y16 || (is_bf16 && a.loss.part && (((uintptr_t)a.Y16 | (uintptr_t)a.D) & 15) == 0), RTX_EINVAL,
+              "dlogits: half-precision logits need bf16 deltas, the log-sum-exp partials of the logits product and 16-byte aligned images");
     if (!a.loss.part && a.loss.B > 0) {
         hipLaunchKernelGGL(k_row_lse, dim3(a.loss.B), dim3(256), 0, stream, a.loss.Y, a.loss.ldy, a.loss.I, a.loss.lse);
         RTX_HIP(hipGetLastError());

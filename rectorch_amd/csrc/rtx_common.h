@@ -89,11 +89,20 @@ template <> __device__ __forceinline__ void store4<float>(float* dst, float a, f
 {
     *(float4*)dst = make_float4(a, b, c, d);
 }
+// two floats -> two bf16 in one dword: gfx950's v_cvt_pk_bf16_f32 (round to nearest even, as f32_to_bf16 above)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    typedef __attribute__((ext_vector_type(2))) __bf16 rtx_bf16x2;
+    rtx_bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a, float b, float c, float d)
 {
     uint2 u;
-    u.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-    u.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+    u.x = pack_bf16x2(a, b);
+    u.y = pack_bf16x2(c, d);
     *(uint2*)dst = u;
 }
 #endif

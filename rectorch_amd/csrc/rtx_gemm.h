@@ -70,6 +70,10 @@ struct RtxGemm {
     int M_real, N_real;
     float2* lse_part;    // RTX_EPI_BIAS_ROWS (nullable): per row, per 64-column strip (running max, sum exp) of the
     int lse_ld;          //   biased logits -> the row log-sum-exp needs no second pass over the [B, n_items] logits
+    void* C16;           // RTX_EPI_BIAS_ROWS, bf16 operands, rtx_gemm_launch (nullable): the biased logits leave as IEEE HALF [M][ldc16]
+    long ldc16;          //   (clamped to +-65504) INSTEAD of the float32 C -- the training step's logits, whose only reader is the
+                         //   loss kernel (it overwrites them in place with the bf16 d loss / d logits); the log-sum-exp partials are
+                         //   still taken from the float32 accumulators
     int xcd_block;       // gemm_dma, splits == 1: 1 = every XCD works on 8 x 4 blocks of tiles (12 operand panels per 32 tiles in its
                          //   L2 instead of the strip order's 18 or 33)
 };
@@ -88,6 +92,10 @@ int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream);
 // ---- weight gradient in TN form, optionally fused with the Adam update (dw_adam.hip; bf16 operands) ------------------
 enum RtxDwEpilogue { RTX_DW_GRAD = 0, RTX_DW_ADAM = 1 };
 enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2, RTX_DW_128x128 = 3 };
+// or-ed into the tile configuration: one workgroup per tile even where the fused-Adam launch would use its persistent grid
+// (rtx_dw_tn_pers) -- for a launch that shares the device with another stream's kernels, whose workgroups need the slots that
+// retiring workgroups leave
+#define RTX_DW_ONE_PER_TILE 0x100
 struct RtxDw {
     const void* A;       // delta      bf16 [K_pad][lda]: k = batch row, m = output feature (contiguous)
     const void* B;       // activation bf16 [K_pad][ldb]: n = input feature (contiguous); column N_real holds ones
@@ -104,9 +112,15 @@ struct RtxDw {
     float* bias_m;       //   with the scalars of `adam`
     float* bias_v;
     const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
+    int dbg_skip;                    // measurement (rtx_dw_set_skip / rtx_dw_set_stamps fill them at launch; 0 / null otherwise)
+    unsigned long long* dbg_stamps;
 };
 void rtx_gemm_dma_set_skip(int v);   // measurement only (gemm_dma.hip g_gd_skip)
 void rtx_gemm_dma_set_stamps(unsigned long long* dev);   // measurement hook: 32 device entries (gemm_dma.hip)
+void rtx_dw_set_stamps(unsigned long long* dev);   // measurement hooks (dw_adam.hip g_dw_stamps / g_dw_skip): 8 entries per workgroup
+void rtx_dw_set_skip(int mask);
+void rtx_dw_set_stagger(int ticks);    // measurement: persistent grid's start-up stagger (100-MHz ticks per tile time)
+void rtx_dw_set_persistent(int on);   // measurement switch: 0 = one workgroup per tile (rounds 2-3), 1 = persistent grid (default)
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6

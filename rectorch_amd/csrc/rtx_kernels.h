@@ -201,6 +201,8 @@ struct RtxDlogitsArgs {
     int Bp;             // rows [B, Bp) of D are written as zeros
     void* D;            // T [Bp][ldd]
     int ldd;            // >= I, multiple of 8; columns [I, ldd) are written as zeros
+    const void* Y16;    // T = bf16 only (nullable): the logits as IEEE half [Bp][ldd] INSTEAD of loss.Y (rtx_gemm_launch's C16);
+                        //   may be the same buffer as D -- every thread reads its 16 bytes before it writes them
 };
 int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream);
 // one workgroup per (user, 4096-column chunk): loss.row_loss receives [B][rtx_dlogits_chunks(ldd)] partial sums

@@ -307,6 +307,58 @@ static void perf_dma(const char* name, int form, int cfg, int M, int N, int K, i
     hipFree(A); hipFree(B); hipFree(C); hipFree(bias); hipFree(part);
 }
 
+// The training step's logits as IEEE half (RtxGemm::C16, round 4): the same launch with the float32 and with the half output must
+// agree bit for bit after rounding -- half(clamp(C)) -- and leave identical log-sum-exp partials.
+static int run_logits16_case(int M, int N, int K, int M_real, int N_real, int shape, float scale)
+{
+    std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto& x : hA) x = f32_to_bf16(frand() * scale);
+    for (auto& x : hB) x = f32_to_bf16(frand());
+    std::vector<float> hbias(N);
+    for (auto& x : hbias) x = frand();
+    bf16_t *A, *B;
+    float *C, *bias;
+    _Float16* C16;
+    float2 *p0, *p1;
+    const int strips = N / 64;
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&C16, (size_t)M * N * 2));
+    CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&p0, (size_t)M * strips * 8)); CK(hipMalloc(&p1, (size_t)M * strips * 8));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(bias, hbias.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0, (size_t)M * N * 4)); CK(hipMemset(C16, 0xff, (size_t)M * N * 2));
+    CK(hipMemset(p0, 0, (size_t)M * strips * 8)); CK(hipMemset(p1, 0xff, (size_t)M * strips * 8));
+    RtxGemm g = {};
+    g.A = A; g.B = B; g.lda = K; g.ldb = K;
+    int bm, bn;
+    rtx_gemm_tile_dims(shape, &bm, &bn);
+    g.tile_shape = shape; g.m_tiles = M / bm; g.n_tiles = N / bn; g.k_slices = K * 2 / 128; g.splits = 1;
+    g.C = C; g.ldc = N; g.bias = bias; g.M_real = M_real; g.N_real = N_real; g.lse_part = p0; g.lse_ld = strips;
+    int rc = rtx_gemm_launch(g, RTX_DT_BF16, RTX_EPI_BIAS_ROWS, 0);
+    g.C16 = C16; g.ldc16 = N; g.lse_part = p1;
+    rc |= rtx_gemm_launch(g, RTX_DT_BF16, RTX_EPI_BIAS_ROWS, 0);
+    if (rc) { printf("[logits16] launch failed: %s\n", rtx_last_error_str()); return 1; }
+    CK(hipDeviceSynchronize());
+    std::vector<float> hC((size_t)M * N);
+    std::vector<_Float16> h16((size_t)M * N);
+    std::vector<float2> q0((size_t)M * strips), q1((size_t)M * strips);
+    CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h16.data(), C16, h16.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(q0.data(), p0, q0.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(q1.data(), p1, q1.size() * 8, hipMemcpyDeviceToHost));
+    long bad = 0, clamped = 0;
+    for (int m = 0; m < M_real; ++m) {
+        for (int n = 0; n < N_real; ++n) {
+            float c = hC[(size_t)m * N + n];
+            if (fabsf(c) > 65504.f) { c = c > 0 ? 65504.f : -65504.f; ++clamped; }
+            const _Float16 want = (_Float16)c, got = h16[(size_t)m * N + n];
+            if (memcmp(&want, &got, 2)) { if (bad++ < 5) printf("   logits16 (%d,%d): f32 %.6f half %.6f\n", m, n, c, (float)got); }
+        }
+        for (int k = 0; k < (N_real + 63) / 64; ++k)
+            if (memcmp(&q0[(size_t)m * strips + k], &q1[(size_t)m * strips + k], 8)) { if (bad++ < 5) printf("   lse partial (%d,%d) differs\n", m, k); }
+    }
+    printf("[logits16] tile%d M=%d N=%d K=%d (%d x %d real) scale %.0f: %ld clamped, bad=%ld -> %s\n", shape, M, N, K, M_real, N_real, scale, clamped, bad, bad ? "FAIL" : "ok");
+    hipFree(A); hipFree(B); hipFree(C); hipFree(C16); hipFree(bias); hipFree(p0); hipFree(p1);
+    return bad != 0;
+}
+
 // ---- weight gradient in TN form, fused with Adam (dw_adam.hip) -------------------------------------------------------------------
 static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_real, int K_real, float lam, float wd, int keep)
 {
@@ -606,6 +658,55 @@ static int run_f32_case(const char* name, int form, int M, int N, int K, int spl
     return bad != 0;
 }
 
+// The persistent grid's tile counters are zeroed by the last workgroup of a launch and reused 16 launches later: 40 launches on
+// the same state must equal 40 launches of the one-workgroup-per-tile kernel, bit for bit (a stale counter would skip tiles).
+static int run_dw_persistent_repeat()
+{
+    const int M_real = 4000, N_real = 1100, K_real = 100, cfg = 0;
+    const int Mp = rtx_pad(M_real), Np = rtx_pad(N_real), Kp = rtx_pad_batch(K_real);
+    std::vector<bf16_t> hD((size_t)Kp * Mp, 0), hX((size_t)Kp * Np, 0);
+    for (int k = 0; k < K_real; ++k) {
+        for (int m = 0; m < M_real; ++m) hD[(size_t)k * Mp + m] = f32_to_bf16(frand() * 0.05f);
+        for (int n = 0; n < N_real; ++n) hX[(size_t)k * Np + n] = f32_to_bf16(frand());
+        hX[(size_t)k * Np + N_real] = f32_to_bf16(1.f);
+    }
+    const size_t P = (size_t)M_real * N_real;
+    std::vector<float> hp(P), hm(P), hv(P);
+    for (size_t i = 0; i < P; ++i) { hp[i] = frand(); hm[i] = frand() * 0.01f; hv[i] = fabsf(frand()) * 1e-4f; }
+    bf16_t *D, *X;
+    CK(hipMalloc(&D, hD.size() * 2)); CK(hipMalloc(&X, hX.size() * 2));
+    CK(hipMemcpy(D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> res[2];
+    for (int pers = 0; pers < 2; ++pers) {
+        float *p, *m, *v, *bp, *bm, *bv;
+        bf16_t* sh;
+        CK(hipMalloc(&p, P * 4)); CK(hipMalloc(&m, P * 4)); CK(hipMalloc(&v, P * 4)); CK(hipMalloc(&sh, (size_t)Mp * Np * 2));
+        CK(hipMalloc(&bp, Mp * 4)); CK(hipMalloc(&bm, Mp * 4)); CK(hipMalloc(&bv, Mp * 4));
+        CK(hipMemcpy(p, hp.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(m, hm.data(), P * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(v, hv.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemset(sh, 0, (size_t)Mp * Np * 2));
+        CK(hipMemset(bp, 0, Mp * 4)); CK(hipMemset(bm, 0, Mp * 4)); CK(hipMemset(bv, 0, Mp * 4));
+        RtxDw d = {};
+        d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
+        d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+        d.M_real = M_real; d.N_real = N_real;
+        d.bias_p = bp; d.bias_m = bm; d.bias_v = bv;
+        d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.sh = sh; d.adam.ld_sh = Np;
+        d.adam.step_size = 1e-3f; d.adam.bc2_sqrt = 0.5f; d.adam.beta1 = 0.9f; d.adam.beta2 = 0.999f; d.adam.eps = 1e-8f;
+        for (int it = 0; it < 40; ++it)
+            if (rtx_dw_launch(d, RTX_DW_ADAM, cfg | (pers ? 0 : RTX_DW_ONE_PER_TILE), 0)) { printf("[dw persistent-repeat] launch failed: %s\n", rtx_last_error_str()); return 1; }
+        CK(hipDeviceSynchronize());
+        res[pers].resize(3 * P);
+        CK(hipMemcpy(res[pers].data(), p, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(res[pers].data() + P, m, P * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(res[pers].data() + 2 * P, v, P * 4, hipMemcpyDeviceToHost));
+        hipFree(p); hipFree(m); hipFree(v); hipFree(sh); hipFree(bp); hipFree(bm); hipFree(bv);
+    }
+    hipFree(D); hipFree(X);
+    const bool same = memcmp(res[0].data(), res[1].data(), 3 * P * 4) == 0;
+    printf("[dw persistent-repeat] 40 launches, %d x %d (%d tiles): persistent grid %s one workgroup per tile -> %s\n", M_real, N_real,
+           (Mp / 64) * (Np / 128), same ? "==" : "!=", same ? "ok" : "FAIL");
+    return !same;
+}
+
 static int run_dw_cases()
 {
     int fails = 0;
@@ -617,11 +718,14 @@ static int run_dw_cases()
         fails += run_dw_case("adam-oddcols", cfg, RTX_DW_ADAM, 130, 301, 190, 0.f, 0.f, 1);        // rows of N % 4 != 0 floats: the strided epilogue
         fails += run_dw_case("adam-odd-dae", cfg, RTX_DW_ADAM, 70, 133, 100, 0.2f, 0.001f, 1);
         fails += run_dw_case("adam-odd-tall", cfg, RTX_DW_ADAM, 1000, 27, 128, 0.f, 0.f, 0);
+        fails += run_dw_case("adam-persistent", cfg, RTX_DW_ADAM, 5000, 1100, 100, 0.f, 0.f, 1);       // more tiles than resident workgroups: the persistent grid
+        fails += run_dw_case("adam-persistent-odd", cfg, RTX_DW_ADAM, 1101, 5003, 70, 0.1f, 0.001f, 0);
         fails += run_dw_case("grad", cfg, RTX_DW_GRAD, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
         fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
         fails += run_dw_group_case(cfg);
         fails += run_dw_group_case(cfg, 1);
+        if (cfg == 0) fails += run_dw_persistent_repeat();
     }
     return fails;
 }
@@ -683,6 +787,98 @@ int main(int argc, char** argv)
             for (int K : {4096, 4160, 4032, 8192, 8256}) perf_dma("chan", RTX_FORM_NT, cfg, 4096, 4096, K, 1, RTX_EPI_STORE);
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "dwx")) {   // where a weight-gradient + Adam workgroup spends its life (round 4)
+        const int cfg = argc > 2 ? atoi(argv[2]) : 0;
+        const bool base_only = argc > 3 && !strcmp(argv[3], "base");   // (the counter passes: one kernel variant per kernel name)
+        const bool quick = argc > 3 && !strcmp(argv[3], "quick");      // masks 0 and 6, persistent and per-tile grids
+        if (argc > 4) rtx_dw_set_persistent(atoi(argv[4]));
+        if (argc > 3 && !strcmp(argv[3], "stagger")) {   // persistent grid with a start-up stagger of 0 .. 24 us per tile time
+            for (int rep = 0; rep < 2; ++rep) {
+                rtx_dw_set_persistent(0);
+                printf("one workgroup per tile\n");
+                perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
+                perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
+                rtx_dw_set_persistent(1);
+                for (int ticks : {0, 800, 1600, 2400}) {
+                    rtx_dw_set_stagger(ticks);
+                    printf("persistent grid, stagger %d ticks\n", ticks);
+                    perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
+                    perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
+                }
+            }
+            rtx_dw_set_stagger(1600);
+        }
+        if (quick) {
+            for (int pers : {0, 1, 0, 1}) {
+                rtx_dw_set_persistent(pers);
+                for (int mask : {0, 6, 7}) {
+                    rtx_dw_set_skip(mask);
+                    printf("persistent %d, skip mask %d\n", pers, mask);
+                    perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
+                    perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
+                }
+            }
+            rtx_dw_set_skip(0);
+        }
+        const bool stamps_only = argc > 3 && (!strcmp(argv[3], "stamps") || !strcmp(argv[3], "stagger"));
+        for (int mask : {0, 16, 1, 2, 4, 3, 5, 6, 7}) {
+            if (quick || stamps_only) break;
+            if (base_only && mask) break;
+            rtx_dw_set_skip(mask);
+            printf("skip mask %d (1 = no K walk, 2 = no p/m/v loads, 4 = no stores, 16 = DMA issued first)\n", mask);
+            perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
+            perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
+        }
+        rtx_dw_set_skip(0);
+        for (int shape = 0; shape < 2 && !base_only; ++shape) {
+            const int M = shape ? 600 : 20108, N = shape ? 20108 : 600;
+            const int wgs = 8 * (((rtx_pad(M) / rtx_dw_tile_rows(cfg)) * (rtx_pad(N) / 128) + 7) / 8);
+            unsigned long long* dst;
+            CK(hipMalloc(&dst, (size_t)wgs * 64));
+            CK(hipMemset(dst, 0, (size_t)wgs * 64));
+            rtx_dw_set_stamps(dst);
+            perf_dw(shape ? "dW1+adam stamped" : "dW4+adam stamped", cfg, RTX_DW_ADAM, M, N, 500, 3);
+            rtx_dw_set_stamps(nullptr);
+            std::vector<unsigned long long> h((size_t)wgs * 8);
+            CK(hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost));
+            hipFree(dst);
+            if (const char* dump = getenv("DWX_DUMP")) {   // raw stamps of the last launch: [workgroup][8] u64 (tools/dw_stamps.py)
+                char path[512];
+                snprintf(path, sizeof(path), "%s_%d.bin", dump, shape);
+                if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            }
+            // the LAST launch's stamps: phases averaged over workgroups, and the launch's profile in time
+            unsigned long long t0 = ~0ull, t1 = 0;
+            int n = 0;
+            for (int w = 0; w < wgs; ++w)
+                if (h[w * 8]) { t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 6]); ++n; }
+            double ph[6] = {0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < wgs; ++w)
+                if (h[w * 8])
+                    for (int k = 0; k < 6; ++k) ph[k] += (double)(h[w * 8 + k + 1] - h[w * 8 + k]) * 0.01 / n;
+            printf("  %d workgroups, launch span %.1f us; mean us per phase: issue %.2f | p/m/v + slice 0 landed %.2f | K walk %.2f | drain + park %.2f | Adam + store issue %.2f | "
+                   "stores acknowledged %.2f | life %.2f\n", n, (t1 - t0) * 0.01, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]);
+            // resident workgroups and phase census every 5 us
+            for (double t = 2.5; t < (t1 - t0) * 0.01; t += 5.0) {
+                const unsigned long long tt = t0 + (unsigned long long)(t * 100);
+                int c[6] = {0, 0, 0, 0, 0, 0};
+                for (int w = 0; w < wgs; ++w)
+                    if (h[w * 8] && h[w * 8] <= tt && tt < h[w * 8 + 6])
+                        for (int k = 5; k >= 0; --k)
+                            if (tt >= h[w * 8 + k]) { ++c[k]; break; }
+                printf("    t = %5.1f us: resident %4d | issue %3d wait-first %4d K-walk %4d park %3d adam %4d store-ack %4d\n", t, c[0] + c[1] + c[2] + c[3] + c[4] + c[5], c[0], c[1],
+                       c[2], c[3], c[4], c[5]);
+            }
+            // per-XCD workgroup counts and mean life
+            double life[8] = {0}; int cnt[8] = {0};
+            for (int w = 0; w < wgs; ++w)
+                if (h[w * 8]) { const int x = (int)(h[w * 8 + 7] >> 32) & 7; life[x] += (h[w * 8 + 6] - h[w * 8]) * 0.01; ++cnt[x]; }
+            printf("    per XCC_ID: ");
+            for (int x = 0; x < 8; ++x) printf("%d: %d wgs, life %.1f us | ", x, cnt[x], cnt[x] ? life[x] / cnt[x] : 0.0);
+            printf("\n");
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "dw")) {   // only the weight-gradient (+ Adam) kernels
         fails = run_dw_cases();
         printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
@@ -714,6 +910,8 @@ int main(int argc, char** argv)
         fails += run_case<bf16_t>("grad", 768, 512, 512, 1, RTX_EPI_GRAD, 700, 300, shape);
         fails += run_case<bf16_t>("grad-tall", 2304, 256, 128, 1, RTX_EPI_GRAD, 2300, 200, shape);
         fails += run_case<bf16_t>("bias-wide", 256, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 250, 2300, shape);
+        fails += run_logits16_case(512, 768, 640, 410, 701, shape, 1.f);
+        fails += run_logits16_case(256, 2304, 128, 250, 2300, shape, 4000.f);   // products beyond the half range: clamped to +-65504
         fails += run_case<float>("store", 512, 768, 352, 1, RTX_EPI_STORE, 512, 768, shape);
         fails += run_case<float>("splitk3", 512, 768, 352, 3, RTX_EPI_STORE, 512, 768, shape);
         fails += run_case<float>("bias", 512, 768, 320, 1, RTX_EPI_BIAS_ROWS, 410, 701, shape);
