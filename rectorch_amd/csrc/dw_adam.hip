@@ -43,8 +43,7 @@ typedef __attribute__((address_space(3))) unsigned char dw_lds_byte;
 // measurement hooks (tests/native/test_gemm.cpp "dwx"): per-workgroup 100-MHz stamps of the tile's phases, and a mask that takes
 // phases out of the kernel (1 = no K walk, 2 = no p / m / v loads, 4 = no p / m / v / compute-copy stores, 16 = the first DMA
 // slices are issued BEFORE the optimizer-state loads).  They travel in the kernel arguments (RtxDw::dbg_*, null / 0 in the
-// product: scalar registers) -- as device globals they cost every tile of the persistent grid a dependent vector load behind
-// a vmcnt(0), i.e. behind the previous tile's stores.
+// product: two scalar registers, no memory access of their own).
 static unsigned long long* g_dw_stamps = nullptr;
 static int g_dw_skip = 0;
 void rtx_dw_set_stamps(unsigned long long* dev) { g_dw_stamps = dev; }
@@ -193,12 +192,8 @@ __device__ __forceinline__ float dw_dae_reg(const RtxDw& p)
 
 // WM x WN waves; a wave owns 32 x (128 / WN) of the tile (NJ = 4 / WN accumulators): tile = (32 WM) x 128
 // AL = false (fused Adam only): rows of N_real % 4 != 0 floats (dw_f32x4_u above)
-struct DwNoHook { __device__ __forceinline__ void operator()() const {} };
-// after_k(): called by every thread right behind the wait that ends the K walk (every vector-memory operation the wave has issued
-// for this tile, and anything older, has completed there) -- the persistent grid publishes its prefetched next tile number at
-// that point, where the wait costs nothing
-template <int WM, int WN, int NS, int EPI, bool AL = true, typename Hook = DwNoHook>
-__device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid, const Hook& after_k = Hook())   // bid: workgroup number within this problem's grid
+template <int WM, int WN, int NS, int EPI, bool AL = true>
+__device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   // bid: workgroup number within this problem's grid
 {
     constexpr int NW = WM * WN, NTH = NW * 64, TM = WM * 32, NJ = 4 / WN;
     constexpr int SA = TM * 2, SBB = 256;                       // bytes of one k-row of the A / B slice images
@@ -219,10 +214,7 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid, cons
         const int total = p.m_tiles * p.n_tiles;
         const int per_xcd = (total + 7) / 8;
         const int id = (int)(bid & 7) * per_xcd + (int)(bid >> 3);
-        if (id >= total) {   // a padding workgroup (grids are rounded up to 8): nothing to do, but the hook still runs
-            after_k();
-            return;
-        }
+        if (id >= total) return;
         if (p.n_tiles <= p.m_tiles) { tm = id / p.n_tiles; tn = id % p.n_tiles; }
         else { tn = id / p.m_tiles; tm = id % p.m_tiles; }
     }
@@ -382,7 +374,6 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid, cons
     if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
     dw_wait_vm<0>();
     __builtin_amdgcn_s_barrier();   // every fragment read is done: the stages become the gradient tile's parking space
-    after_k();                      // (behind a barrier every wave reaches only after it has entered this tile)
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* tile = (float*)smem;
@@ -435,7 +426,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 
 // a 35-workgroup launch of its own waits for slots and crawls (53 + 33 us measured for two kernels that take 12 us each alone).
 struct RtxDwGroup {
     int n;
-    unsigned stagger_ticks;   // persistent grid: start-up stagger, 100-MHz ticks per tile time (0 = none)
     unsigned first[RTX_DW_GROUP_MAX + 1];
     RtxDw p[RTX_DW_GROUP_MAX];
 };
@@ -449,101 +439,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 
     dw_tile<WM, WN, NS, EPI, AL>(g.p[k], blockIdx.x - g.first[k]);   // (AL = false serves the aligned problems of the group as well)
 }
 
-// The same launch as a PERSISTENT grid (round 4): `slots` workgroups (two per CU) pull tiles until none is left.
-// Why: per-workgroup stamps (profiles/r4_dw_phase_probe.txt) show a 64 x 128 tile's workgroup alive for 20 us and its slot EMPTY
-// for another 5 us before the next workgroup's first instruction (dispatch, LDS allocation, kernel-argument fetch through a
-// saturated memory system) -- a quarter of the kernel's 76-84 us.  A resident workgroup starts its next tile at once.
-// Tiles are handed out DYNAMICALLY, one counter per XCD: virtual workgroup numbers v = xcd + 8 j keep the tile -> XCD mapping
-// (and with it the L2 locality) of the launch above; workgroup b starts on j = b / 8 and then takes j = 64, 65, ... of its XCD in
-// the order it asks.  (A static round-robin was no faster than one workgroup per tile: tiles take 14-26 us depending on what
-// the memory system hands a workgroup, and the slowest chain of 3-4 tiles set the kernel's time -- profiles/r4_dw_persistent.txt.)
-// The request for the NEXT tile leaves at the start of a tile (first in the wave's memory queue: every later wait covers it).
-// ctr[32 x]: next j of XCD x; ctr[256]: workgroups that have left -- the last one zeroes the set for the launch that uses it next.
-// Every counter has a 128-byte line of its own: eight XCDs' device-scope atomics on ONE line serialised the whole launch (113 us).
-#define RTX_DW_CTR_SETS 16
-#define RTX_DW_CTR_WORDS (9 * 32)
-__device__ unsigned g_dw_ctr[RTX_DW_CTR_SETS][RTX_DW_CTR_WORDS];
-
-template <int WM, int WN, int NS, int EPI, bool AL = true>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn_pers(const RtxDwGroup g, int ctr_set)
-{
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
-    unsigned* next_slot = (unsigned*)(smem + LDS);   // 16 bytes behind the stages
-    unsigned* ctr = g_dw_ctr[ctr_set];
-    const unsigned total = g.first[g.n], xcd = blockIdx.x & 7u, per = gridDim.x >> 3;   // total and gridDim.x are multiples of 8
-    const unsigned j_end = total >> 3;
-    unsigned j = blockIdx.x >> 3;
-    // The problem descriptor lives in SCALAR REGISTERS across tiles.  Read from the kernel-argument segment tile after tile (the
-    // compiler re-loads such loop invariants rather than keep 58 registers) it cost every tile two or three DEPENDENT scalar-load
-    // round trips through a saturated memory system -- about 10 us per 20-us tile: the persistent grid was 1.5x SLOWER than one
-    // workgroup per tile (105 vs 70 us, profiles/r4_dw_persistent.txt), and the same loads are the "refill gap" of the latter.
-    union { RtxDw d; unsigned w[sizeof(RtxDw) / 4]; } cur;
-    static_assert(sizeof(RtxDw) % 4 == 0, "RtxDw is a whole number of dwords");
-    int cur_k = -1;
-    unsigned first_k = 0, first_n[RTX_DW_GROUP_MAX];
-#pragma unroll
-    for (int q = 0; q < RTX_DW_GROUP_MAX; ++q) {
-        first_n[q] = q < g.n ? g.first[q] : 0xffffffffu;
-        asm volatile("" : "+s"(first_n[q]));
-    }
-    // Stagger: workgroups that start together stay in lock step -- all of them load, then multiply, then store -- and HBM serves
-    // pure read bursts at 4.6 and pure write bursts at 4.3 TB/s against 6.3 for a mix.  Workgroup j of an XCD (CU mates are
-    // j and j + 32) waits j / 64 of one tile time before its first tile.
-    if (g.stagger_ticks) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), wait = (unsigned long long)g.stagger_ticks * j / per;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-    while (j < j_end) {
-        unsigned nxt = 0;   // (raw counter value: nothing may touch it before the tile is done, or the wave waits for the atomic right here)
-        if (threadIdx.x == 0) nxt = __hip_atomic_fetch_add(&ctr[32 * xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned v = xcd + 8u * j;
-        int k = 0;
-#pragma unroll
-        for (int q = 1; q < RTX_DW_GROUP_MAX; ++q)
-            if (v >= first_n[q]) k = q;
-        if (k != cur_k) {   // (a handful of times per launch: the small problems come first)
-            cur.d = g.p[k];
-#pragma unroll
-            for (unsigned q = 0; q < sizeof(RtxDw) / 4; ++q) asm volatile("" : "+s"(cur.w[q]));
-            first_k = g.first[k];
-            asm volatile("" : "+s"(first_k));
-            cur_k = k;
-        }
-        dw_tile<WM, WN, NS, EPI, AL>(cur.d, v - first_k, [&]() { if (threadIdx.x == 0) *next_slot = per + nxt; });
-        __syncthreads();   // the parked gradient tile has been consumed: the stages are free for the next tile's slices
-        j = *next_slot;
-        __syncthreads();   // read by every wave before thread 0 can write it again (a padding tile has no barrier of its own)
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&ctr[256], 1u) == gridDim.x - 1) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) ctr[32 * q] = 0;
-            __threadfence();
-        }
-    }
-}
-
-static int dw_cu_count()
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        cus = prop.multiProcessorCount;
-    }
-    return cus;
-}
-
-static int g_dw_persistent = 1;   // measurement switch (rtx_dw_set_persistent): 0 = one workgroup per tile, as in rounds 2-3
-void rtx_dw_set_persistent(int on) { g_dw_persistent = on; }
-static int g_dw_stagger = 0;      // measurement: start-up stagger of the persistent grid in 100-MHz ticks (rtx_dw_set_stagger)
-void rtx_dw_set_stagger(int ticks) { g_dw_stagger = ticks; }
-static int g_dw_next_set = 0;     // launches that may overlap (two streams) never share a counter set: 16 sets, far fewer launches in flight
-
-template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream, bool pers = true)
+// (Round 4 ran this launch as a PERSISTENT grid -- 512 resident workgroups pulling tiles from per-XCD counters, to close the ~5 us a
+// slot stays empty between two workgroups.  It was 1.5x SLOWER (104-115 vs 70-76 us): resident workgroups fall into lock step -- all
+// load, all multiply, all store -- and HBM serves pure read / pure write bursts at 4.6 / 4.3 TB/s against 6.3 for the mix that the
+// per-tile launch's dispatch jitter maintains; in the step it also held the LDS the chain's kernels need.  profiles/r4_dw_persistent.txt.)
+template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream)
 {
     constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
@@ -561,25 +461,12 @@ template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch_
         total += (unsigned)(8 * ((d[k].m_tiles * d[k].n_tiles + 7) / 8));
     }
     g.first[n] = total;
-    g.stagger_ticks = (unsigned)g_dw_stagger;
-    const unsigned slots = (unsigned)(dw_cu_count() * (WM >= 4 ? 1 : 2)) & ~7u;
-    if (pers && g_dw_persistent && EPI == RTX_DW_ADAM && slots >= 8 && total > slots) {
-        static bool configured_p = false;
-        if (!configured_p) {
-            RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn_pers<WM, WN, NS, EPI, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 16));
-            configured_p = true;
-        }
-        const int set = g_dw_next_set;
-        g_dw_next_set = (g_dw_next_set + 1) % RTX_DW_CTR_SETS;
-        hipLaunchKernelGGL((rtx_dw_tn_pers<WM, WN, NS, EPI, AL>), dim3(slots), dim3(WM * WN * 64), LDS + 16, stream, g, set);
-    } else {
-        hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI, AL>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
-    }
+    hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI, AL>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
 
-template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(const RtxDw& d, hipStream_t stream, bool pers = true)
+template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(const RtxDw& d, hipStream_t stream)
 {
     constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
     static bool configured = false;
@@ -589,8 +476,6 @@ template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(
     }
     const int total = d.m_tiles * d.n_tiles;
     const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
-    if (pers && g_dw_persistent && EPI == RTX_DW_ADAM && grid.x > ((unsigned)(dw_cu_count() * (WM >= 4 ? 1 : 2)) & ~7u) && dw_cu_count() >= 4)
-        return dw_launch_group<WM, WN, NS, EPI, AL>(&d, 1, stream);   // more tiles than resident workgroups: the persistent grid
     RtxDw dd = d;
     dd.dbg_skip = g_dw_skip; dd.dbg_stamps = g_dw_stamps;
     hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI, AL>), grid, dim3(WM * WN * 64), LDS, stream, dd);
@@ -598,17 +483,16 @@ template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(
     return RTX_OK;
 }
 
-int rtx_dw_tile_rows(int cfg) { cfg &= 0xff; return cfg == RTX_DW_64x128 ? 64 : cfg == RTX_DW_128x128 ? 128 : 32; }
+int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : cfg == RTX_DW_128x128 ? 128 : 32; }
 
 template <int EPI, bool AL = true> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
 {
-    const bool pers = !(cfg & RTX_DW_ONE_PER_TILE);
-    switch (cfg & 0xff) {
-    case RTX_DW_32x128: return dw_launch<1, 4, 3, EPI, AL>(d, stream, pers);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
-    case RTX_DW_32x128_S2: return dw_launch<1, 4, 2, EPI, AL>(d, stream, pers);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
-    case RTX_DW_128x128: return dw_launch<4, 2, 2, EPI, AL>(d, stream, pers);     // 8 waves, 2 stages (64 KB), 32 x 64 per wave: half the
-                                                                                   //   operand bytes per parameter of the 64-row tile
-    default: return dw_launch<2, 4, 3, EPI, AL>(d, stream, pers);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
+    switch (cfg) {
+    case RTX_DW_32x128: return dw_launch<1, 4, 3, EPI, AL>(d, stream);      // 4 waves, 3 stages (60 KB): 2 workgroups per CU
+    case RTX_DW_32x128_S2: return dw_launch<1, 4, 2, EPI, AL>(d, stream);   // 4 waves, 2 stages (40 KB): 4 workgroups per CU
+    case RTX_DW_128x128: return dw_launch<4, 2, 2, EPI, AL>(d, stream);     // 8 waves, 2 stages (64 KB), 32 x 64 per wave: half the
+                                                                             //   operand bytes per parameter of the 64-row tile
+    default: return dw_launch<2, 4, 3, EPI, AL>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
     }
 }
 
@@ -618,7 +502,7 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     RTX_CHECK(d.A && d.B && d.m_tiles > 0 && d.n_tiles > 0 && d.k_slices >= 2, RTX_EINVAL, "dw: bad problem (%d x %d tiles, %d K slices)", d.m_tiles, d.n_tiles,
               d.k_slices);
     RTX_CHECK(epilogue == RTX_DW_GRAD || epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw: bad epilogue %d", epilogue);
-    RTX_CHECK((cfg & 0xff) >= RTX_DW_64x128 && (cfg & 0xff) <= RTX_DW_128x128 && !(cfg & ~(0xff | RTX_DW_ONE_PER_TILE)), RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
     if (epilogue == RTX_DW_ADAM) {
         RTX_CHECK(d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of at least 4 floats (got %d)", d.N_real);
@@ -636,12 +520,11 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
 // data-parallel step (gradients leave as the float32 / bf16 images the exchange sends).
 template <int EPI, bool AL = true> static int dw_launch_group_cfg(const RtxDw* d, int n, int cfg, hipStream_t stream)
 {
-    const bool pers = !(cfg & RTX_DW_ONE_PER_TILE);
-    switch (cfg & 0xff) {
-    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, EPI, AL>(d, n, stream, pers);
-    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, EPI, AL>(d, n, stream, pers);
-    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, EPI, AL>(d, n, stream, pers);
-    default: return dw_launch_group<2, 4, 3, EPI, AL>(d, n, stream, pers);
+    switch (cfg) {
+    case RTX_DW_32x128: return dw_launch_group<1, 4, 3, EPI, AL>(d, n, stream);
+    case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, EPI, AL>(d, n, stream);
+    case RTX_DW_128x128: return dw_launch_group<4, 2, 2, EPI, AL>(d, n, stream);
+    default: return dw_launch_group<2, 4, 3, EPI, AL>(d, n, stream);
     }
 }
 
@@ -650,7 +533,7 @@ int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_
     RTX_CHECK(d && n >= 1 && n <= RTX_DW_GROUP_MAX, RTX_EINVAL, "dw group: 1..%d problems (got %d)", RTX_DW_GROUP_MAX, n);
     if (n == 1) return rtx_dw_launch(d[0], epilogue, cfg, stream);
     RTX_CHECK(epilogue == RTX_DW_ADAM || epilogue == RTX_DW_GRAD, RTX_EINVAL, "dw group: bad epilogue %d", epilogue);
-    RTX_CHECK((cfg & 0xff) >= RTX_DW_64x128 && (cfg & 0xff) <= RTX_DW_128x128 && !(cfg & ~(0xff | RTX_DW_ONE_PER_TILE)), RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     bool any_unaligned = false;   // one matrix with rows of N_real % 4 != 0 floats: the whole launch takes the unaligned epilogue
     for (int k = 0; k < n; ++k) {
         const RtxDw& q = d[k];

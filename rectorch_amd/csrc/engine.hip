@@ -114,9 +114,6 @@ struct rtx_engine {
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
-    int opt_dw_persistent = 1;  // fused weight-gradient + Adam launches behind the chain run as a persistent grid (dw_adam.hip rtx_dw_tn_pers)
-    int opt_dw_side_persistent = 0;   // ... the one BESIDE the chain (side stream) does not: resident workgroups would hold the LDS the
-                                //   chain's data-gradient product needs until the whole matrix is done (measured: the chain then runs behind it)
     int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_logits16 = 1;       // bf16 training step: the logits leave their product as IEEE half, written where d loss / d logits
@@ -1103,8 +1100,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d;
             make_dw(li, d);
-            const bool pers = (two && ws == e->side) ? e->opt_dw_side_persistent : e->opt_dw_persistent;
-            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, dw_cfg | (pers ? 0 : RTX_DW_ONE_PER_TILE), ws);
+            return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, dw_cfg, ws);
         }
         RtxGemm g = {};
         g.form = RTX_FORM_TN;
@@ -1304,7 +1300,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         make_dw(main_li, grp[ng++]);
         {
             ScopedTimer tm(e, "dW_adam_in", st);
-            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, dw_cfg | (e->opt_dw_persistent ? 0 : RTX_DW_ONE_PER_TILE), st));
+            RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, dw_cfg, st));
         }
         RTX_TRY(reduce_loss(e->side));
         if (rest.n > 0) {   // gradients from both streams feed the leftover Adam launch: the side stream waits for this one, then runs it
@@ -1623,8 +1619,6 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
-    else if (k == "dw_persistent") e->opt_dw_persistent = value != 0;
-    else if (k == "dw_side_persistent") e->opt_dw_side_persistent = value != 0;
     else if (k == "two_stream") e->opt_two_stream = value != 0;
     else if (k == "side_low_prio") {
         RTX_CHECK(!e->side, RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
@@ -1669,8 +1663,6 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     if (k == "fuse_adam") *value = e->opt_fuse_adam;
     else if (k == "lse_fuse") *value = e->opt_lse_fuse;
     else if (k == "logits16") *value = e->opt_logits16;
-    else if (k == "dw_persistent") *value = e->opt_dw_persistent;
-    else if (k == "dw_side_persistent") *value = e->opt_dw_side_persistent;
     else if (k == "two_stream") *value = e->opt_two_stream;
     else if (k == "side_low_prio") *value = e->opt_side_low_prio;
     else if (k == "nt_regstage") *value = e->opt_nt_regstage;

@@ -92,10 +92,6 @@ int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream);
 // ---- weight gradient in TN form, optionally fused with the Adam update (dw_adam.hip; bf16 operands) ------------------
 enum RtxDwEpilogue { RTX_DW_GRAD = 0, RTX_DW_ADAM = 1 };
 enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2, RTX_DW_128x128 = 3 };
-// or-ed into the tile configuration: one workgroup per tile even where the fused-Adam launch would use its persistent grid
-// (rtx_dw_tn_pers) -- for a launch that shares the device with another stream's kernels, whose workgroups need the slots that
-// retiring workgroups leave
-#define RTX_DW_ONE_PER_TILE 0x100
 struct RtxDw {
     const void* A;       // delta      bf16 [K_pad][lda]: k = batch row, m = output feature (contiguous)
     const void* B;       // activation bf16 [K_pad][ldb]: n = input feature (contiguous); column N_real holds ones
@@ -119,8 +115,6 @@ void rtx_gemm_dma_set_skip(int v);   // measurement only (gemm_dma.hip g_gd_skip
 void rtx_gemm_dma_set_stamps(unsigned long long* dev);   // measurement hook: 32 device entries (gemm_dma.hip)
 void rtx_dw_set_stamps(unsigned long long* dev);   // measurement hooks (dw_adam.hip g_dw_stamps / g_dw_skip): 8 entries per workgroup
 void rtx_dw_set_skip(int mask);
-void rtx_dw_set_stagger(int ticks);    // measurement: persistent grid's start-up stagger (100-MHz ticks per tile time)
-void rtx_dw_set_persistent(int on);   // measurement switch: 0 = one workgroup per tile (rounds 2-3), 1 = persistent grid (default)
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6

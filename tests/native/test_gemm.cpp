@@ -658,55 +658,6 @@ static int run_f32_case(const char* name, int form, int M, int N, int K, int spl
     return bad != 0;
 }
 
-// The persistent grid's tile counters are zeroed by the last workgroup of a launch and reused 16 launches later: 40 launches on
-// the same state must equal 40 launches of the one-workgroup-per-tile kernel, bit for bit (a stale counter would skip tiles).
-static int run_dw_persistent_repeat()
-{
-    const int M_real = 4000, N_real = 1100, K_real = 100, cfg = 0;
-    const int Mp = rtx_pad(M_real), Np = rtx_pad(N_real), Kp = rtx_pad_batch(K_real);
-    std::vector<bf16_t> hD((size_t)Kp * Mp, 0), hX((size_t)Kp * Np, 0);
-    for (int k = 0; k < K_real; ++k) {
-        for (int m = 0; m < M_real; ++m) hD[(size_t)k * Mp + m] = f32_to_bf16(frand() * 0.05f);
-        for (int n = 0; n < N_real; ++n) hX[(size_t)k * Np + n] = f32_to_bf16(frand());
-        hX[(size_t)k * Np + N_real] = f32_to_bf16(1.f);
-    }
-    const size_t P = (size_t)M_real * N_real;
-    std::vector<float> hp(P), hm(P), hv(P);
-    for (size_t i = 0; i < P; ++i) { hp[i] = frand(); hm[i] = frand() * 0.01f; hv[i] = fabsf(frand()) * 1e-4f; }
-    bf16_t *D, *X;
-    CK(hipMalloc(&D, hD.size() * 2)); CK(hipMalloc(&X, hX.size() * 2));
-    CK(hipMemcpy(D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
-    std::vector<float> res[2];
-    for (int pers = 0; pers < 2; ++pers) {
-        float *p, *m, *v, *bp, *bm, *bv;
-        bf16_t* sh;
-        CK(hipMalloc(&p, P * 4)); CK(hipMalloc(&m, P * 4)); CK(hipMalloc(&v, P * 4)); CK(hipMalloc(&sh, (size_t)Mp * Np * 2));
-        CK(hipMalloc(&bp, Mp * 4)); CK(hipMalloc(&bm, Mp * 4)); CK(hipMalloc(&bv, Mp * 4));
-        CK(hipMemcpy(p, hp.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(m, hm.data(), P * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(v, hv.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemset(sh, 0, (size_t)Mp * Np * 2));
-        CK(hipMemset(bp, 0, Mp * 4)); CK(hipMemset(bm, 0, Mp * 4)); CK(hipMemset(bv, 0, Mp * 4));
-        RtxDw d = {};
-        d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
-        d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
-        d.M_real = M_real; d.N_real = N_real;
-        d.bias_p = bp; d.bias_m = bm; d.bias_v = bv;
-        d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.sh = sh; d.adam.ld_sh = Np;
-        d.adam.step_size = 1e-3f; d.adam.bc2_sqrt = 0.5f; d.adam.beta1 = 0.9f; d.adam.beta2 = 0.999f; d.adam.eps = 1e-8f;
-        for (int it = 0; it < 40; ++it)
-            if (rtx_dw_launch(d, RTX_DW_ADAM, cfg | (pers ? 0 : RTX_DW_ONE_PER_TILE), 0)) { printf("[dw persistent-repeat] launch failed: %s\n", rtx_last_error_str()); return 1; }
-        CK(hipDeviceSynchronize());
-        res[pers].resize(3 * P);
-        CK(hipMemcpy(res[pers].data(), p, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(res[pers].data() + P, m, P * 4, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(res[pers].data() + 2 * P, v, P * 4, hipMemcpyDeviceToHost));
-        hipFree(p); hipFree(m); hipFree(v); hipFree(sh); hipFree(bp); hipFree(bm); hipFree(bv);
-    }
-    hipFree(D); hipFree(X);
-    const bool same = memcmp(res[0].data(), res[1].data(), 3 * P * 4) == 0;
-    printf("[dw persistent-repeat] 40 launches, %d x %d (%d tiles): persistent grid %s one workgroup per tile -> %s\n", M_real, N_real,
-           (Mp / 64) * (Np / 128), same ? "==" : "!=", same ? "ok" : "FAIL");
-    return !same;
-}
-
 static int run_dw_cases()
 {
     int fails = 0;
@@ -718,14 +669,13 @@ static int run_dw_cases()
         fails += run_dw_case("adam-oddcols", cfg, RTX_DW_ADAM, 130, 301, 190, 0.f, 0.f, 1);        // rows of N % 4 != 0 floats: the strided epilogue
         fails += run_dw_case("adam-odd-dae", cfg, RTX_DW_ADAM, 70, 133, 100, 0.2f, 0.001f, 1);
         fails += run_dw_case("adam-odd-tall", cfg, RTX_DW_ADAM, 1000, 27, 128, 0.f, 0.f, 0);
-        fails += run_dw_case("adam-persistent", cfg, RTX_DW_ADAM, 5000, 1100, 100, 0.f, 0.f, 1);       // more tiles than resident workgroups: the persistent grid
-        fails += run_dw_case("adam-persistent-odd", cfg, RTX_DW_ADAM, 1101, 5003, 70, 0.1f, 0.001f, 0);
+        fails += run_dw_case("adam-many-tiles", cfg, RTX_DW_ADAM, 5000, 1100, 100, 0.f, 0.f, 1);       // several workgroups per slot
+        fails += run_dw_case("adam-many-tiles-odd", cfg, RTX_DW_ADAM, 1101, 5003, 70, 0.1f, 0.001f, 0);
         fails += run_dw_case("grad", cfg, RTX_DW_GRAD, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("grad-oddcols", cfg, RTX_DW_GRAD, 77, 301, 190, 0.f, 0.f, 1);
         fails += run_dw_case("grad-tiny", cfg, RTX_DW_GRAD, 2, 1, 3, 0.f, 0.f, 0);
         fails += run_dw_group_case(cfg);
         fails += run_dw_group_case(cfg, 1);
-        if (cfg == 0) fails += run_dw_persistent_repeat();
     }
     return fails;
 }
@@ -790,39 +740,9 @@ int main(int argc, char** argv)
     if (argc > 1 && !strcmp(argv[1], "dwx")) {   // where a weight-gradient + Adam workgroup spends its life (round 4)
         const int cfg = argc > 2 ? atoi(argv[2]) : 0;
         const bool base_only = argc > 3 && !strcmp(argv[3], "base");   // (the counter passes: one kernel variant per kernel name)
-        const bool quick = argc > 3 && !strcmp(argv[3], "quick");      // masks 0 and 6, persistent and per-tile grids
-        if (argc > 4) rtx_dw_set_persistent(atoi(argv[4]));
-        if (argc > 3 && !strcmp(argv[3], "stagger")) {   // persistent grid with a start-up stagger of 0 .. 24 us per tile time
-            for (int rep = 0; rep < 2; ++rep) {
-                rtx_dw_set_persistent(0);
-                printf("one workgroup per tile\n");
-                perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
-                perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
-                rtx_dw_set_persistent(1);
-                for (int ticks : {0, 800, 1600, 2400}) {
-                    rtx_dw_set_stagger(ticks);
-                    printf("persistent grid, stagger %d ticks\n", ticks);
-                    perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
-                    perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
-                }
-            }
-            rtx_dw_set_stagger(1600);
-        }
-        if (quick) {
-            for (int pers : {0, 1, 0, 1}) {
-                rtx_dw_set_persistent(pers);
-                for (int mask : {0, 6, 7}) {
-                    rtx_dw_set_skip(mask);
-                    printf("persistent %d, skip mask %d\n", pers, mask);
-                    perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
-                    perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
-                }
-            }
-            rtx_dw_set_skip(0);
-        }
-        const bool stamps_only = argc > 3 && (!strcmp(argv[3], "stamps") || !strcmp(argv[3], "stagger"));
+        const bool stamps_only = argc > 3 && !strcmp(argv[3], "stamps");
         for (int mask : {0, 16, 1, 2, 4, 3, 5, 6, 7}) {
-            if (quick || stamps_only) break;
+            if (stamps_only) break;
             if (base_only && mask) break;
             rtx_dw_set_skip(mask);
             printf("skip mask %d (1 = no K walk, 2 = no p/m/v loads, 4 = no stores, 16 = DMA issued first)\n", mask);

@@ -1,17 +1,14 @@
 #!/bin/bash
-# Round 4, call 1: where the fused weight-gradient + Adam kernel spends its time.
-#   (1) phase ablations + per-workgroup phase stamps (tests/native/test_gemm dwx), tile configurations 0 / 1 / 2
-#   (2) stall / occupancy / L2 counters of the unmodified kernel (separate --pmc passes)
-#   (3) the baseline bench line of this box
-# usage: tools/gpu.sh --timeout 900 -- 'bash tools/experiments/r4_dw_probe.sh r4a'
+# Where the fused weight-gradient + Adam kernel (dw_adam.hip) spends its time -> profiles/r4_dw_phase_probe.txt, r4_pmc_dw_adam_stalls.txt
+#   (1) phase ablations + per-workgroup phase stamps (tests/native/test_gemm dwx; raw stamps: DWX_DUMP + tools/dw_stamps.py)
+#   (2) stall / occupancy / L2 counters of the unmodified kernel (separate --pmc passes, counters + kernel trace only)
+# usage: tools/gpu.sh --timeout 600 -- 'bash tools/dw_probe.sh OUT'
 OUT=$PWD/gpurun_out/${1:-r4a}
 mkdir -p $OUT
 R=$PWD
 T=$R/build/native/test_gemm
-timeout 200 $T dwx 0 > $OUT/dwx_cfg0.txt 2>&1; echo "dwx0 rc=$?"
-timeout 120 $T dwx 1 > $OUT/dwx_cfg1.txt 2>&1; echo "dwx1 rc=$?"
-timeout 120 $T dwx 3 > $OUT/dwx_cfg3.txt 2>&1; echo "dwx3 rc=$?"
-[ -x ${T}_plain ] && { timeout 120 ${T}_plain dwx 0 base > $OUT/dwx_cfg0_plain_ldst.txt 2>&1; echo "plain rc=$?"; }
+DWX_DUMP=$OUT/stamps timeout 100 $T dwx 0 > $OUT/dwx_cfg0.txt 2>&1; echo "dwx0 rc=$?"
+timeout 60 $T dwx 1 > $OUT/dwx_cfg1.txt 2>&1; echo "dwx1 rc=$?"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
@@ -27,5 +24,3 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST
   [ -n "$DB" ] && python $R/tools/rocprof_summary.py pmc $DB > $OUT/pmc_pass$i.txt
   echo "pmc pass $i ($pass): rc=$? $(wc -l < $OUT/pmc_pass$i.txt 2>/dev/null) lines"
 done
-cd $R
-timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-fp32-parity --no-extras > $OUT/bench_fused.json 2> $OUT/bench_fused.err; echo "bench rc=$?"; tail -1 $OUT/bench_fused.json | cut -c1-200
