@@ -84,7 +84,11 @@ def parse():
     ap.add_argument("--pmc-json", default=None,
                     help="JSON written by tools/pmc_bench.sh for THIS build (field hbm_bytes_per_launch): reported as roofline.traffic "
                          "with its file name; without it traffic is null (counters need their own rocprofv3 --pmc passes)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the train_batch-API and dense-first-layer side measurements")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements (train_batch API, sparse first layer; N > 1: the replicated all-reduce A/B)")
+    ap.add_argument("--first-layer", default="dense", choices=["dense", "sparse"],
+                    help="dense (default, BASELINE.json's north star): [batch, n_items] x [n_items, hidden] on MFMA (k_gather -> split-K "
+                         "rtx_gemm_nt -> k_post); sparse: the VALU product over the stored entries (k_in_chunks -> k_spmm_in)")
     a = ap.parse_args()
     if a.workload == "netflix":
         a.users = a.users or 480000
@@ -137,6 +141,9 @@ def cpu_baseline(X, dims, batch, seconds):
     per8, smp8, n8 = _cpu_run(X, dims, batch, seconds * 0.6, 8)
     best = min(per, per8)
     return {"value": batch / best, "unit": "users/s", "cores": int(cores if per <= per8 else 8), "kind": "port",
+            # `cores` = the threads of the run whose rate is `value` (the faster of the two); the box itself has:
+            "cores_physical": int(cores), "cores_logical": int(os.cpu_count() or cores), "threads_tried": [int(cores), 8],
+            "users_per_s_all_physical_cores": batch / per, "users_per_s_8_threads": batch / per8,
             "sample": "%d steps (all %d physical cores) + %d steps (8 threads) of B=%d, sampler densify + train_batch, "
                       "2 warm-up, median; torch %s CPU; faster of the two reported" % (n, cores, n8, batch, torch.__version__),
             "all_cores": {"threads": int(cores), "users_per_s": batch / per, "ms_sampler_plus_step": per * 1e3,
@@ -261,8 +268,8 @@ def main():
     for rb in smp.iter_rows():
         if len(rb) < global_batch:
             break
-        s, e = parallel.shard_rows(len(rb), 0 if emu else rank, emu if emu else world)
-        batches.append(RowBatch(rb.tr, rb.te if Cd else None, rb.rows[s:e].contiguous()))
+        sb = parallel.shard_batch(rb, 0 if emu else rank, emu if emu else world)    # (knows the global batch: no per-step collective)
+        batches.append(RowBatch(sb.tr, sb.te if Cd else None, sb.rows, global_len=sb.global_len if dp else None))
     B = len(batches[0])                                        # users per GPU per step (this rank)
     torch.manual_seed(1000 + rank)
 
@@ -270,17 +277,19 @@ def main():
         for i in range(n):
             model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
 
-    if args.opt:
-        st_, _, m_, v_ = model._ensure_train_state()    # the engine exists before its first step: some knobs must be set by then
-        eng0 = net.rtx_engine(args.numerics, B, train_buffers=(st_.grads, m_, v_))
-        for kv in args.opt:                             # measurement knobs (rtx_engine_set_option), e.g. --opt two_stream=0
-            k, v = kv.split("=")
-            eng0.set_option(k, int(v))
+    st_, _, m_, v_ = model._ensure_train_state()        # the engine exists before its first step: some knobs must be set by then
+    eng0 = net.rtx_engine(args.numerics, B, train_buffers=(st_.grads, m_, v_))
+    eng0.set_option("sparse_in", int(args.first_layer == "sparse"))
+    for kv in args.opt:                                 # measurement knobs (rtx_engine_set_option), e.g. --opt two_stream=0
+        k, v = kv.split("=")
+        eng0.set_option(k, int(v))
     run(args.warmup, 0)
     torch.cuda.synchronize()
     _flush_c_stdio()
     eng = net._rtx_engines[args.numerics]
     sites = ("adam",) if (dp or args.numerics != "bf16") else ("dW_adam_out", "dW_adam_in")
+    if dp:   # the exchange of each bucket, on the stream it runs on (caller's stream = the end of the step's critical path)
+        sites += ("dp_exchange_main", "dp_exchange_side", "dp_allgather_main", "dp_allgather_side")
     for sname in (() if args.no_kernel_timing else sites):
         # HIP events around the dominant kernel, on the stream it runs on, inside the timed region; every 8th launch is
         # bracketed (the two records of a timed launch cost the step ~5 us each on its critical stream: 322 vs 313 us measured)
@@ -291,11 +300,64 @@ def main():
     n_steps_total = args.warmup + args.steps * args.windows
     loss_mean = model._read_loss_sum() / n_steps_total
 
+    comm = None
+    replica_check = None
+    if dp:
+        G = emu or world
+        ar, rs_, ag = (eng.get_option("dp_bytes_" + k) for k in ("all_reduce", "reduce_scatter", "all_gather"))
+        every = 1 if args.no_kernel_timing else args.kernel_timing_every
+
+        def site_us(name):       # mean duration of one timed bracket of this site
+            ms_, n_ = timings.get(name, (0.0, 0))
+            return (ms_ * 1e3 / n_) if n_ else None
+        comm = {"collectives_per_step": eng.get_option("dp_collectives"),
+                "bytes_per_step_per_rank": {"all_reduce": ar, "reduce_scatter": rs_, "all_gather": ag, "total": ar + rs_ + ag,
+                                            "what": "buffer bytes handed to the collectives (gradient images in comm dtype, compute copies)"},
+                "ring_wire_bytes_per_step_per_rank": (2.0 * ar + rs_ + ag) * (G - 1) / G,
+                "exchange_us": {"main_stream_reduce": site_us("dp_exchange_main"), "main_stream_all_gather": site_us("dp_allgather_main"),
+                                "side_stream_reduce": site_us("dp_exchange_side"), "side_stream_all_gather": site_us("dp_allgather_side"),
+                                "timed_every": every},
+                # what sits on the step's critical path: the caller's stream runs bucket B's collectives behind the last
+                # weight-gradient launch, nothing can hide them; bucket A's (side stream) run beside the data-gradient chain
+                "exposed_us": sum(x or 0.0 for x in (site_us("dp_exchange_main"), site_us("dp_allgather_main"))),
+                "emulated": bool(emu)}
+    if dp and not emu:
+        # every rank checksums its parameters after the timed region: replicated -> bit-identical; sharded -> consolidate()
+        # (collective) first, then bit-identical.  MIN == MAX over the ranks of a per-tensor bit-pattern checksum.
+        if args.sharded:
+            model.consolidate()
+        chk = torch.stack([(p.detach().view(torch.int32).to(torch.int64) % 1000003).sum() for p in net.parameters()]).to(torch.float64)
+        lo_, hi_ = chk.clone(), chk.clone()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        replica_check = {"mode": "sharded optimizer, consolidate() then compare" if args.sharded else "replicated optimizer",
+                         "tensors": int(chk.numel()), "ranks": world, "identical": bool(torch.equal(lo_, hi_)),
+                         "finite": bool(all(torch.isfinite(p).all().item() for p in net.parameters()))}
+    # N > 1: the north star names the ALL-REDUCE schedule; the default is the sharded optimizer -- time the other one beside it
+    replicated_ab = None
+    if world > 1 and args.sharded and not args.no_extras:
+        eng.dp_attach(None)
+        net_r, model_r = build_model(args, I, H, L, args.numerics)
+        plan_r = parallel.attach(model_r, fixed_global_batch=global_batch, sharded=False, engine=args.dp_engine, transport=args.dp_transport)
+        st_r, _, m_r, v_r = model_r._ensure_train_state()
+        net_r.rtx_engine(args.numerics, B, train_buffers=(st_r.grads, m_r, v_r)).set_option("sparse_in", int(args.first_layer == "sparse"))
+
+        def run_r(n, start):
+            for i in range(n):
+                model_r._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
+        k_r = max(10, min(args.steps, 50))
+        run_r(5, 0)
+        w_r = timed_windows(run_r, k_r, 2, world, 5)
+        replicated_ab = {"ms_per_step": float(np.median(w_r)) / k_r * 1e3, "value": global_batch * k_r / float(np.median(w_r)), "unit": "users/s",
+                         "steps": k_r, "what": "the same job with all-reduce + the whole Adam update on every rank (--replicated)"}
+        if hasattr(plan_r, "close"):
+            plan_r.close()
+        del net_r, model_r
     if world > 1:
         dist.barrier()
     if plan is not None and hasattr(plan, "close"):
-        eng.dp_attach(None)
-        plan.close()                 # the engine's own RCCL communicator goes while every rank is still here
+        plan.close()                 # detaches the engine; the engine's own RCCL communicator goes while every rank is still here
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -363,6 +425,9 @@ def main():
                                else "f32 MFMA (parity mode)"},
         "windows": {"n": args.windows, "steps_each": args.steps, "seconds": wins, "reported": "median"},
         "rccl_ranks": rccl_ranks,
+        "comm": comm,
+        "replica_check": replica_check,
+        "replicated_allreduce": replicated_ab,
         "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_TBS * 1000.0, "unit": "GB/s",
                      "frac": (achieved / (HBM_PEAK_TBS * 1000.0)) if achieved else None,
@@ -386,14 +451,21 @@ def main():
         e_api = time.perf_counter() - t0
         out["train_batch_api"] = {"value": global_batch * k_api / e_api, "unit": "users/s", "ms_per_step": e_api / k_api * 1e3, "steps": k_api,
                                   "what": "MultiVAE.train_batch(rows) per step, returning loss.item() like the reference (models.py:835)"}
-        # (b) A/B of the first layer: the dense MFMA split-K product instead of the sparse VALU product
+        # (b) A/B of the first layer: the other product (headline = dense MFMA contraction; alternative = sparse VALU product)
+        eng.set_option("sparse_in", int(not sparse_first))
+        run(5, 0)
+        wd = timed_windows(run, k_api, 2, 1, 5)
+        eng.set_option("sparse_in", int(sparse_first))
+        ms_other = float(np.median(wd)) / k_api * 1e3
         if sparse_first:
-            eng.set_option("sparse_in", 0)
-            run(5, 0)
-            wd = timed_windows(run, k_api, 2, 1, 5)
-            eng.set_option("sparse_in", 1)
-            out["first_layer_dense_mfma"] = {"ms_per_step": float(np.median(wd)) / k_api * 1e3, "steps": k_api,
-                                             "frac_of_bf16_mfma_peak": step_flops / (float(np.median(wd)) / k_api) / 1e12 / MFMA_BF16_PEAK_TF}
+            out["first_layer_dense_mfma"] = {"ms_per_step": ms_other, "steps": k_api,
+                                             "frac_of_bf16_mfma_peak": step_flops / (ms_other * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF}
+        else:
+            nnz_b = float(X.nnz) / X.shape[0] * B
+            out["first_layer_sparse_valu"] = {"ms_per_step": ms_other, "steps": k_api, "value": global_batch / (ms_other * 1e-3), "unit": "users/s",
+                                              "executed_flops_per_step": step_flops - 2.0 * B * (I + Cd) * H + 2.0 * nnz_b * H,
+                                              "what": "the same step with the first layer as a sparse VALU product over the stored entries "
+                                                      "(k_in_chunks -> k_spmm_in): 12 GFLOP of dense product replaced by 2 nnz H"}
     if world == 1 and not dp and args.numerics == "bf16" and not args.no_fp32_parity and not Cd:
         # the float32 parity mode (exact-f32 MFMA, the arithmetic the 1e-5 logits criterion is met in): same workload, a
         # shorter sample; bound by the f32 MFMA rate ("two numerics modes ... report both")

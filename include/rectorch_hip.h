@@ -320,13 +320,19 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * data-gradient chain), "side_low_prio" (0/1: that stream at the lowest priority; before the first step), "lse_fuse" (0/1:
  * log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the big NT contractions on the register-staged GEMM
  * instead of the LDS-DMA one), "dw_cfg" (0..3: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic), "in_on_main" (0/1: the encoder matrix's weight kernel on
- * the caller's stream behind the chain), "sparse_in" (0/1, bf16: the first encoder layer as a sparse product over the batch's
- * stored entries -- spmm_in.hip -- instead of the dense split-K GEMM; needs a CSR batch, n_items + cond_dim <= 20 480 and at most
- * ~4000 expected 64-entry chunks per batch), "small_fwd" / "small_bwd" (0/1, bf16: hidden layers and the VAE head of the forward
- * pass / of the data-gradient chain as one register-resident launch each -- small_layers.hip -- for padded widths <= 1024).
+ * the caller's stream behind the chain), "sparse_in" (0/1, default 0 since round 4, bf16: the first encoder layer as a sparse VALU
+ * product over the batch's stored entries -- spmm_in.hip -- instead of the dense MFMA split-K GEMM; needs a CSR batch,
+ * n_items + cond_dim <= 20 480 and at most ~4000 expected 64-entry chunks per batch), "small_fwd" / "small_bwd" (0/1, bf16: hidden
+ * layers and the VAE head of the forward pass / of the data-gradient chain as one register-resident launch each --
+ * small_layers.hip -- for padded widths <= 1024), "logits16" (0/1, bf16 training step: the logits leave their product as IEEE half
+ * in the buffer of d loss / d logits and the loss kernel converts them in place), "dp_shard_min_elems" (>= 1, before
+ * rtx_engine_dp_attach: smallest weight matrix the sharded optimizer shards; default 2^20 elements).
  * Replaces round 1's RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
-/* the current value of a knob; also "last_sparse_in": 1 when the last forward pass ran the first layer as the sparse product */
+/* the current value of a knob; also "last_sparse_in": 1 when the last forward pass ran the first layer as the sparse product;
+ * "side_concurrent": 1 when the step's second stream was seen to run beside the caller's; data parallel, the LAST step's exchange
+ * per rank: "dp_bytes_all_reduce", "dp_bytes_reduce_scatter", "dp_bytes_all_gather" (buffer bytes handed to the collectives,
+ * saturating at INT32_MAX) and "dp_collectives" (their number) */
 int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value);
 
 /* ---- instrumentation: per-kernel HIP-event timing on the engine's stream ------------------------- */

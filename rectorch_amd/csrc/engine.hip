@@ -71,6 +71,10 @@ struct DpState {
     size_t xbytes = 0, xesz = 4;
     size_t xoff[2 * 2 * RTX_MAX_LAYERS] = {};   // element offset of tensor t
     bool shard[2 * RTX_MAX_LAYERS] = {};        // per layer: weight matrix reduce-scattered / updated by rows / all-gathered
+    bool broken = false;                      // a collective failed inside a group: no further step until the plan is attached again
+    // what the LAST step's exchange moved, per rank (buffer bytes handed to the collectives; rtx_engine_get_option "dp_*")
+    int64_t st_all_reduce = 0, st_reduce_scatter = 0, st_all_gather = 0;
+    int st_collectives = 0;
     void* emu_scratch = nullptr;              // emulate: where the stand-in copies go
     size_t emu_bytes = 0;
     // emulate: the collectives of one group become ONE copy launch (as RCCL fuses a group into one kernel)
@@ -108,12 +112,17 @@ struct rtx_engine {
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipStream_t side_for = nullptr;   // the caller's stream the side stream was probed against (make_side_stream)
+    std::map<hipStream_t, std::pair<hipStream_t, int>> side_cache;   // caller's stream -> (probed side stream, concurrent): a caller that
+                                      //   alternates streams pays the ~1.5 ms probe once per stream, not on every change
     int side_concurrent = 0;          // 1: the probe saw the two streams run at the same time
     hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
     hipEvent_t ev_done = nullptr;      // everything the step put on the side stream is complete
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
+    int opt_dp_shard_min_elems = 1 << 20;   // sharded optimizer: weight matrices of at least this many elements are reduce-scattered /
+                                //   updated by rows / all-gathered, smaller ones all-reduced and replicated (tests lower it so that
+                                //   small golden networks exercise the sharded path with real data)
     int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_logits16 = 1;       // bf16 training step: the logits leave their product as IEEE half, written where d loss / d logits
@@ -126,7 +135,10 @@ struct rtx_engine {
                                 //   -- any data-parallel job -- a lowest-priority queue beside RCCL's makes EVERY kernel of the step run 2-3x
                                 //   slower (769 vs 343 us/step, profiles/r3_dp_priority_experiment.txt)
     int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
-    int opt_sparse_in = 1;      // bf16: the first encoder layer as a sparse product over the stored entries (spmm_in.hip)
+    int opt_sparse_in = 0;      // bf16, 1: the first encoder layer as a sparse VALU product over the stored entries (spmm_in.hip).
+                                //   Default since round 4: the dense [batch, n_items] x [n_items, hidden] contraction on MFMA
+                                //   (k_gather -> split-K rtx_gemm_nt -> k_post), the configuration BASELINE.json's north star names;
+                                //   the sparse product is the measured alternative (2-6 us per ml-20m step faster at B = 500)
     int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_layers.hip)
     int opt_small_bwd = 1;      // ... and of the data-gradient chain (reads the transposed compute copies of the hidden layers)
     int opt_big_batch_tiles = 1;   // batches of >= 1024 rows: 512 x 128 data-gradient tiles (configs[3] on one GPU: 1486 -> 1343 us/step)
@@ -764,7 +776,8 @@ int rtx_engine_destroy(rtx_engine* e)
     for (hipEvent_t ev : e->ev_d)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
-    if (e->side) (void)hipStreamDestroy(e->side);
+    for (auto& kv : e->side_cache)
+        if (kv.second.first) (void)hipStreamDestroy(kv.second.first);
     delete e;
     return RTX_OK;
 }
@@ -915,17 +928,21 @@ __global__ void k_probe_nop() {}
 static int make_side_stream(rtx_engine* e, hipStream_t st)
 {
     RTX_HIP(hipStreamSynchronize(st));
-    if (e->side) {
-        RTX_HIP(hipStreamSynchronize(e->side));
-        (void)hipStreamDestroy(e->side);
-        e->side = nullptr;
-    }
+    if (e->side) RTX_HIP(hipStreamSynchronize(e->side));   // (the previous caller's stream keeps its side stream in the cache)
+    e->side = nullptr;
     e->side_for = st;
+    auto hit = e->side_cache.find(st);
+    if (hit != e->side_cache.end()) {
+        e->side = hit->second.first;
+        e->side_concurrent = hit->second.second;
+        return RTX_OK;
+    }
     int prio_least = 0, prio_greatest = 0;
     RTX_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     if (e->opt_side_low_prio) {   // measurement knob: no probing
         RTX_HIP(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_least));
         e->side_concurrent = 1;
+        e->side_cache[st] = {e->side, 1};
         return RTX_OK;
     }
     hipEvent_t ev_spin = nullptr, ev_cand = nullptr;
@@ -951,8 +968,14 @@ static int make_side_stream(rtx_engine* e, hipStream_t st)
     (void)hipEventDestroy(ev_spin);
     (void)hipEventDestroy(ev_cand);
     e->side_concurrent = found != nullptr;
-    if (!found) RTX_HIP(hipStreamCreateWithFlags(&found, hipStreamNonBlocking));   // (keeps the code paths alive; the step still orders everything by events)
+    if (!found) {
+        static bool said = false;   // once per process: the step silently losing its second stream costs ~20 %
+        if (!said) fprintf(stderr, "rectorch_hip: no HIP stream runs beside the caller's (all candidates share its hardware queue): the training step uses ONE stream\n");
+        said = true;
+        RTX_HIP(hipStreamCreateWithFlags(&found, hipStreamNonBlocking));   // (keeps the code paths alive; the step still orders everything by events)
+    }
     e->side = found;
+    e->side_cache[st] = {found, e->side_concurrent};
     return RTX_OK;
 }
 
@@ -977,6 +1000,11 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
+    if (dp) {
+        RTX_CHECK(!dp->broken, RTX_ESTATE, "data parallel: a collective of an earlier step failed; attach the plan again (rtx_engine_dp_attach)");
+        dp->st_all_reduce = dp->st_reduce_scatter = dp->st_all_gather = 0;
+        dp->st_collectives = 0;
+    }
     const bool dae_reg = !e->vae && step->lam != 0.f;
     if (dp && dae_reg)   // lam * W / ||W|| needs the norm of the WHOLE matrix; a rank of the sharded optimizer holds current rows of its shard only
         for (int li = 0; li < e->NL; ++li)
@@ -1128,33 +1156,53 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             if (!e->bf16 && cdt == RTX_BF16) RTX_TRY(rtx_launch_cast_f32_bf16(e->grads[t], xg16(t), (long)n, ws));
             else if (keep_grads && cdt == RTX_FP32) RTX_HIP(hipMemcpyAsync(e->grads[t], xg32(t), n * sizeof(float), hipMemcpyDeviceToDevice, ws));
         }
-        // (2) exchange: reduce-scatter of every sharded matrix, one all-reduce per contiguous run of replicated tensors
+        // (2) exchange: reduce-scatter of every sharded matrix, one all-reduce per contiguous run of replicated tensors.
+        //     A failure between group_start and group_end still closes the group (an open RCCL group would swallow every later
+        //     collective of the communicator) and marks the plan unusable until it is attached again.
         {
-            ScopedTimer tm(e, "dp_exchange", ws);
+            ScopedTimer tm(e, ws == e->side && two ? "dp_exchange_side" : "dp_exchange_main", ws);
             if (d.ops.group_start) RTX_CHECK(d.ops.group_start(d.ops.ctx) == 0, RTX_EHIP, "data parallel: group_start failed: %s", rtx_last_error_str());
-            long run_lo = -1, run_hi = -1;
-            auto flush = [&]() -> int {
-                if (run_lo >= 0 && run_hi > run_lo)
-                    RTX_CHECK(d.ops.all_reduce(d.ops.ctx, (char*)d.xg + (size_t)run_lo * d.xesz, run_hi - run_lo, cdt, ws) == 0, RTX_EHIP,
-                              "data parallel: all_reduce failed: %s", rtx_last_error_str());
-                run_lo = run_hi = -1;
-                return RTX_OK;
-            };
-            for (int q = 0; q < n_order; ++q) {
-                const int t = order[q];
-                const bool sharded_w = !(t & 1) && d.shard[t / 2];
-                if (!in_bucket(t) || sharded_w) {
-                    RTX_TRY(flush());
-                    if (in_bucket(t))
-                        RTX_CHECK(d.ops.reduce_scatter(d.ops.ctx, (char*)d.xg + d.xoff[t] * d.xesz, (int64_t)dp_region_elems(e, d, t), cdt, ws) == 0,
-                                  RTX_EHIP, "data parallel: reduce_scatter failed: %s", rtx_last_error_str());
-                    continue;
+            auto in_group = [&]() -> int {
+                long run_lo = -1, run_hi = -1;
+                auto flush = [&]() -> int {
+                    if (run_lo >= 0 && run_hi > run_lo) {
+                        RTX_CHECK(d.ops.all_reduce(d.ops.ctx, (char*)d.xg + (size_t)run_lo * d.xesz, run_hi - run_lo, cdt, ws) == 0, RTX_EHIP,
+                                  "data parallel: all_reduce failed: %s", rtx_last_error_str());
+                        d.st_all_reduce += (int64_t)(run_hi - run_lo) * (int64_t)d.xesz;
+                        d.st_collectives += 1;
+                    }
+                    run_lo = run_hi = -1;
+                    return RTX_OK;
+                };
+                for (int q = 0; q < n_order; ++q) {
+                    const int t = order[q];
+                    const bool sharded_w = !(t & 1) && d.shard[t / 2];
+                    if (!in_bucket(t) || sharded_w) {
+                        RTX_TRY(flush());
+                        if (in_bucket(t)) {
+                            RTX_CHECK(d.ops.reduce_scatter(d.ops.ctx, (char*)d.xg + d.xoff[t] * d.xesz, (int64_t)dp_region_elems(e, d, t), cdt, ws) == 0,
+                                      RTX_EHIP, "data parallel: reduce_scatter failed: %s", rtx_last_error_str());
+                            d.st_reduce_scatter += (int64_t)dp_region_elems(e, d, t) * (int64_t)d.xesz;
+                            d.st_collectives += 1;
+                        }
+                        continue;
+                    }
+                    if (run_lo < 0) run_lo = (long)d.xoff[t];
+                    run_hi = (long)(d.xoff[t] + dp_region_elems(e, d, t));
                 }
-                if (run_lo < 0) run_lo = (long)d.xoff[t];
-                run_hi = (long)(d.xoff[t] + dp_region_elems(e, d, t));
+                return flush();
+            };
+            const int rc = in_group();
+            if (rc != RTX_OK) {
+                d.broken = true;
+                std::string msg = rtx_last_error_str();           // group_end may overwrite the thread's error slot
+                if (d.ops.group_end) (void)d.ops.group_end(d.ops.ctx);
+                RTX_CHECK(false, rc, "%s", msg.c_str());
             }
-            RTX_TRY(flush());
-            if (d.ops.group_end) RTX_CHECK(d.ops.group_end(d.ops.ctx) == 0, RTX_EHIP, "data parallel: group_end failed: %s", rtx_last_error_str());
+            if (d.ops.group_end && d.ops.group_end(d.ops.ctx) != 0) {
+                d.broken = true;
+                RTX_CHECK(false, RTX_EHIP, "data parallel: group_end failed: %s", rtx_last_error_str());
+            }
         }
         // (3) Adam: replicated tensors in full, a sharded matrix on this rank's rows
         RtxAdamArgs a = {};
@@ -1190,9 +1238,13 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         for (int li = l_lo; li < l_hi; ++li)
             if (d.shard[li]) {
                 Layer& l = e->L[li];
-                ScopedTimer tm(e, "dp_allgather", ws);
-                RTX_CHECK(d.ops.all_gather(d.ops.ctx, (alt && l.Wsh_alt) ? l.Wsh_alt : l.Wsh, (int64_t)((size_t)l.outp * l.inp * e->esz), ws) == 0,
-                          RTX_EHIP, "data parallel: all_gather failed: %s", rtx_last_error_str());
+                ScopedTimer tm(e, ws == e->side && two ? "dp_allgather_side" : "dp_allgather_main", ws);
+                if (d.ops.all_gather(d.ops.ctx, (alt && l.Wsh_alt) ? l.Wsh_alt : l.Wsh, (int64_t)((size_t)l.outp * l.inp * e->esz), ws) != 0) {
+                    d.broken = true;
+                    RTX_CHECK(false, RTX_EHIP, "data parallel: all_gather failed: %s", rtx_last_error_str());
+                }
+                d.st_all_gather += (int64_t)((size_t)l.outp * l.inp * e->esz);
+                d.st_collectives += 1;
             }
         return RTX_OK;
     };
@@ -1551,7 +1603,7 @@ int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
     for (int li = 0; li < e->NL; ++li) {
         const Layer& l = e->L[li];
         // a hidden layer that keeps a transposed compute copy (WshT) is never sharded: that copy is a column-block layout
-        d.shard[li] = cfg->sharded && layer_is_big(l) && !l.WshT && l.outp % cfg->world == 0;
+        d.shard[li] = cfg->sharded && (long)l.out * l.in >= (long)e->opt_dp_shard_min_elems && !l.WshT && l.outp % cfg->world == 0;
         biggest = std::max(biggest, (size_t)l.outp * l.inp * std::max(e->esz, d.xesz));
     }
     int order[2 * 2 * RTX_MAX_LAYERS];
@@ -1619,9 +1671,13 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
+    else if (k == "dp_shard_min_elems") {
+        RTX_CHECK(!e->dp.on && value >= 1, RTX_ESTATE, "set_option: dp_shard_min_elems (>= 1) must be set before rtx_engine_dp_attach");
+        e->opt_dp_shard_min_elems = value;
+    }
     else if (k == "two_stream") e->opt_two_stream = value != 0;
     else if (k == "side_low_prio") {
-        RTX_CHECK(!e->side, RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
+        RTX_CHECK(e->side_cache.empty(), RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
         e->opt_side_low_prio = value != 0;
     }
     else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
@@ -1663,6 +1719,11 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     if (k == "fuse_adam") *value = e->opt_fuse_adam;
     else if (k == "lse_fuse") *value = e->opt_lse_fuse;
     else if (k == "logits16") *value = e->opt_logits16;
+    else if (k == "dp_shard_min_elems") *value = e->opt_dp_shard_min_elems;
+    else if (k == "dp_bytes_all_reduce") *value = (int32_t)std::min<int64_t>(e->dp.st_all_reduce, INT32_MAX);       // per rank, last step
+    else if (k == "dp_bytes_reduce_scatter") *value = (int32_t)std::min<int64_t>(e->dp.st_reduce_scatter, INT32_MAX);
+    else if (k == "dp_bytes_all_gather") *value = (int32_t)std::min<int64_t>(e->dp.st_all_gather, INT32_MAX);
+    else if (k == "dp_collectives") *value = e->dp.st_collectives;
     else if (k == "two_stream") *value = e->opt_two_stream;
     else if (k == "side_low_prio") *value = e->opt_side_low_prio;
     else if (k == "nt_regstage") *value = e->opt_nt_regstage;

@@ -66,10 +66,13 @@ class CsrMatrix:
 
 class RowBatch:
     """What the resident DataSampler hands to the trainer on the fast path: row numbers only."""
-    __slots__ = ("tr", "te", "rows")
+    __slots__ = ("tr", "te", "rows", "global_len")
 
-    def __init__(self, tr, te, rows):
+    def __init__(self, tr, te, rows, global_len=None):
         self.tr, self.te, self.rows = tr, te, rows
+        # data parallel: users in the GLOBAL batch this one is a rank's slice of (rectorch_amd.parallel.shard_batch): the step's
+        # 1 / global-batch scale then needs no collective and no host sync
+        self.global_len = global_len
 
     def __len__(self):
         return int(self.rows.numel())
@@ -295,11 +298,19 @@ class Engine:
         communicator, caller-supplied collectives, or emulation), or None to detach."""
         if plan is None:
             check(lib().rtx_engine_dp_attach(self.handle, None))
-            self._dp_plan = None
+            old, self._dp_plan, self._dp_any_sharded = getattr(self, "_dp_plan", None), None, False
+            if old is not None and hasattr(old, "_forget"):
+                old._forget(self)
             return
         cfg = plan.c_cfg()
+        if getattr(plan, "shard_min_elems", None):
+            self.set_option("dp_shard_min_elems", int(plan.shard_min_elems))
         check(lib().rtx_engine_dp_attach(self.handle, C.byref(cfg)))
         self._dp_plan = plan          # keeps the communicator / callback objects alive as long as the engine uses them
+        # what the ENGINE decided to shard (a plan that asks for the sharded optimizer on a network of small matrices shards nothing)
+        self._dp_any_sharded = any(self.dp_owned_rows(l)[2] for l in range(self.n_tensors // 2))
+        if hasattr(plan, "_remember"):
+            plan._remember(self)
 
     def train_step_dp(self, x, target, step, loss_out, loss_accum=None):
         """one rank's train_batch of a data-parallel job: forward + loss + backward on this rank's users, the gradient exchange

@@ -296,7 +296,8 @@ class AETrainer(TorchNNTrainer):
         inj = self._rtx.inject or (None, None)     # (keep-mask uint8 [B, n_items], eps [B, latent]) for parity tests
         step = eng._step(seed=draw_seed(), offset=0 if red is None else red.rank, mask=inj[0], noise=inj[1],
                          beta=float(beta), lam=float(lam),
-                         inv_batch=1.0 / (B if red is None else red.global_batch(B)),
+                         # (a rank's slice made by parallel.shard_batch knows the global batch: no collective, no host sync)
+                         inv_batch=1.0 / (B if red is None else (getattr(x, "global_len", None) or red.global_batch(B))),
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
                          eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
                          flags=(_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0) |
@@ -310,13 +311,14 @@ class AETrainer(TorchNNTrainer):
             # the engine schedules the whole data-parallel step (rectorch_amd/parallel.py NativePlan): ONE call
             if getattr(eng, "_dp_plan", None) is not red:
                 eng.dp_attach(red)                   # (a rebuilt engine -- a larger batch arrived -- attaches again)
+            red.error = None                         # (a stale failure of an earlier step must not be re-raised for this one)
             try:
                 eng.train_step_dp(x, target, step, loss_out, loss_acc)
             except _lib.RtxError:
                 if getattr(red, "error", None) is not None:
                     raise red.error                  # a collective issued through torch.distributed failed: its own message
                 raise
-            if red.sharded and red.transport != "emulate":
+            if eng._dp_any_sharded and red.transport != "emulate":   # what the ENGINE shards, not what the plan asked for
                 st.masters_sharded = True
                 self.network._rtx_masters_stale = True
         else:

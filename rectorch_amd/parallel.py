@@ -41,6 +41,15 @@ def shard_rows(n_rows, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def shard_batch(rb, rank, world):
+    """rank ``rank``'s slice of the resident sampler's global batch ``rb`` (a :class:`rectorch_amd.engine.RowBatch`).  The slice
+    remembers the global batch size, so the data-parallel step scales its gradients by 1 / global batch without a collective or a
+    host sync per step (``NativePlan.global_batch`` is the fallback for batches that do not say)."""
+    from .engine import RowBatch
+    s, e = shard_rows(len(rb), rank, world)
+    return RowBatch(rb.tr, rb.te, rb.rows[s:e].contiguous(), global_len=len(rb))
+
+
 class GradAllReducer:
     """Bucketed all-reduce of a flat gradient buffer, overlapped with the backward pass and -- when the trainer hands
     over an ``adam`` callable -- followed bucket by bucket by that bucket's optimizer pass on a third stream.
@@ -298,13 +307,16 @@ class NativePlan:
     ``world`` would move and Adam on 1/world of the rows (``bench.py --emulate-world``: the HBM cost of a G-rank step on one GPU)."""
     native = True
 
-    def __init__(self, rank, world, sharded, comm_dtype, group=None, transport="rccl"):
+    def __init__(self, rank, world, sharded, comm_dtype, group=None, transport="rccl", shard_min_elems=None):
         from . import _lib
+        import weakref
         self.rank, self.world, self.sharded, self.group, self.transport = int(rank), int(world), bool(sharded), group, transport
         self.comm_dtype = comm_dtype
+        self.shard_min_elems = shard_min_elems     # None: the engine's default (2^20 elements); tests lower it
         self.comm = None
         self._ops = None
         self.error = None
+        self._engines = weakref.WeakSet()          # engines attached to this plan: close() detaches them first
         if transport == "rccl":
             import ctypes as C
             ident = [None]
@@ -384,7 +396,15 @@ class NativePlan:
     def wait(self):
         pass            # the step call orders everything on the caller's stream itself
 
+    def _remember(self, eng):
+        self._engines.add(eng)
+
+    def _forget(self, eng):
+        self._engines.discard(eng)
+
     def global_batch(self, local_batch):
+        """FALLBACK for batches that do not know their global size (``parallel.shard_batch`` slices and
+        ``attach(..., fixed_global_batch=)`` do): one blocking all-reduce + host read per step."""
         if self.world == 1 or self.transport == "emulate":
             return local_batch * (self.world if self.transport == "emulate" else 1)
         t = torch.tensor([float(local_batch)], device="cuda")
@@ -418,8 +438,13 @@ class NativePlan:
                 t.view(-1).copy_(buf[:rows * cols])
 
     def close(self):
-        """destroy the engine's RCCL communicator (every rank, while its peers are still alive: before
-        ``dist.destroy_process_group()`` / interpreter exit).  The engines that were attached to this plan must not step again."""
+        """detach the engines that use this plan, then destroy the engine's RCCL communicator (every rank, while its peers are
+        still alive: before ``dist.destroy_process_group()`` / interpreter exit)."""
+        for eng in list(getattr(self, "_engines", ())):
+            try:
+                eng.dp_attach(None)                  # no engine keeps a pointer to the communicator that goes now
+            except Exception:
+                pass
         h = getattr(self, "comm", None)
         if h is not None and h.value:
             try:
@@ -430,8 +455,8 @@ class NativePlan:
                 pass
             self.comm = None
 
-    def __del__(self):
-        self.close()
+    # (no __del__: destroying an RCCL communicator from the garbage collector / at interpreter exit can block for ever once a
+    #  peer rank has gone; a plan that was never closed leaks its communicator instead)
 
 
 def _all_gather_blocks(flat, rank, world, group, native):
@@ -469,7 +494,7 @@ def init_from_env(backend=None):
 
 
 def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None, comm_dtype=None, bucket_adam=True, sharded=False,
-           engine=None, emulate_world=0, transport=None):
+           engine=None, emulate_world=0, transport=None, shard_min_elems=None):
     """Turn a :class:`rectorch_amd.models.AETrainer` into a data-parallel replica: broadcasts rank 0's
     parameters, then every ``train_batch`` exchanges the gradients as described above.  Each rank must feed
     ITS slice of the global batch (see ``shard_rows``).
@@ -486,6 +511,8 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
     change).
     ``transport`` (native engine): None -> "rccl" (the engine's own communicator) when the process group is nccl, else "torch"
     (``torch.distributed`` calls on the engine's streams).
+    ``shard_min_elems`` (native engine): weight matrices of at least this many elements are sharded (None: the engine's default,
+    2^20; the tests lower it so that small golden networks run the sharded path with real data).
     ``bucket_adam`` / ``min_bucket_bytes`` steer the python engine only."""
     st, params, m, v = model._ensure_train_state()
     if comm_dtype is None:
@@ -515,7 +542,7 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
             # issue different collectives than its peers)
             ok = torch.ones(1, device="cuda")
             try:
-                plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "rccl")
+                plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "rccl", shard_min_elems)
             except Exception as ex:                 # pragma: no cover (needs a broken RCCL)
                 import logging
                 logging.getLogger(__name__).warning("rtx_comm over RCCL did not come up (%s): collectives through torch.distributed", ex)
@@ -524,7 +551,7 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
             if float(ok.item()) < 1.0:
                 plan, transport = None, "torch"
         if plan is None:
-            plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "torch")
+            plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "torch", shard_min_elems)
         if fixed_global_batch is not None:
             plan.global_batch = lambda local, _g=int(fixed_global_batch): _g
         st.reducer = plan

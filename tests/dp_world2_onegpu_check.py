@@ -47,7 +47,10 @@ def main():
         net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
         net.to("cuda")
         model = MultiVAE(net, beta=beta, anneal_steps=int(anneal), learning_rate=lr, numerics="fp32")
-        red = parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam, sharded=sharded, engine=engine)
+        # shard_min_elems = 1: the golden networks are tiny (64 x 16, 77 x 21 ...); with the engine's default threshold (2^20
+        # elements) the "sharded" plan would shard NOTHING and reduce-scatter / row-range Adam / all-gather would never see data
+        red = parallel.attach(model, min_bucket_bytes=256, comm_dtype=comm, bucket_adam=bucket_adam, sharded=sharded, engine=engine,
+                              shard_min_elems=1)
         if engine == "native":
             assert red.native and red.transport == "torch" and red.sharded == sharded
         else:
@@ -64,6 +67,14 @@ def main():
             sd_t, _ = params_in_order(sd_from(g, "sd_%d__" % t))
             if sharded:
                 assert model._rtx.masters_sharded
+                if engine == "native":              # the ENGINE really shards: first and last layer, this rank's half of the rows
+                    eng = net._rtx_engines["fp32"]
+                    n_l = eng.n_tensors // 2
+                    owned = [eng.dp_owned_rows(l) for l in range(n_l)]
+                    assert owned[0][2] and owned[n_l - 1][2], owned
+                    lo, hi, _ = owned[n_l - 1]
+                    assert (lo == 0) == (rank == 0) and 0 < hi - lo < net._param_list()[2 * (n_l - 1)].shape[0], (rank, owned)
+                    assert eng.get_option("dp_bytes_reduce_scatter") > 0 and eng.get_option("dp_bytes_all_gather") > 0
                 model._gather_sharded_state()       # collective: every rank completes its float32 rows
             for k, prm, want in zip(keys, net._param_list(), sd_t):
                 dl = np.abs(prm.detach().cpu().numpy() - want)

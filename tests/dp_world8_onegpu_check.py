@@ -1,0 +1,105 @@
+"""Run by test_gpu_parity.py::test_dp_world8_on_one_gpu under torch.distributed.run with EIGHT ranks sharing the one MI355X of the
+test box (gloo carries the device tensors; RCCL refuses several ranks on one device): the numerics of the 8-GPU job the metric
+is quoted on -- bf16 operands, bf16 gradient images, an 8-way sum of bf16 partial gradients -- which no other test reaches.
+
+MultiVAE [3000, 600, 200] (both 3000 x 600 matrices are above the engine's sharding threshold), global batch 8 x 16 users,
+engine-scheduled step, {sharded (reduce-scatter -> Adam on this rank's rows -> all-gather), replicated (all-reduce)}: every rank
+feeds ITS 16 rows (parallel.shard_batch) with its rows of one set of dropout masks / noise; after three steps every rank must
+hold what ONE GPU computes on the whole 128-user batch, within the bound below.
+
+Bound (stated, bf16 exchange): the eight partial gradients are rounded to bf16 (2^-9 relative) BEFORE they are summed, the
+single-GPU step sums in float32.  Adam normalises the gradient, so a parameter whose summed gradient is rounding noise can move
+by +-lr the other way: |dp| <= 2 lr per step on a few elements, while the mean |dp| stays two orders below lr."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from rectorch_amd import parallel                                   # noqa: E402
+from rectorch_amd.models import MultiVAE                            # noqa: E402
+from rectorch_amd.nets import MultiVAE_net                          # noqa: E402
+from rectorch_amd.samplers import DataSampler                       # noqa: E402
+from rectorch_amd.utils import hash_state_dict, synth_interactions  # noqa: E402
+
+I, H, L, B_LOCAL, STEPS, LR = 3000, 600, 200, 16, 3, 1e-3
+
+
+def build(sd):
+    net = MultiVAE_net([L, H, I], dropout=0.5)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to("cuda")
+    return net, MultiVAE(net, beta=0.2, anneal_steps=0, learning_rate=LR, numerics="bf16")
+
+
+def main():
+    rank, world, _ = parallel.init_from_env(backend="gloo")
+    assert world == 8
+    Bg = B_LOCAL * world
+    X = synth_interactions(STEPS * Bg, I, mu=3.5, sigma=0.9, dmax=I // 2, seed=5)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 31, bias_std=0.05)
+    gen = torch.Generator().manual_seed(77)
+    masks = [(torch.rand(Bg, I, generator=gen) >= 0.5).to(torch.uint8) for _ in range(STEPS)]
+    noise = [torch.randn(Bg, L, generator=gen) for _ in range(STEPS)]
+    batches = list(DataSampler(X, batch_size=Bg, shuffle=False).iter_rows())
+    # what one GPU computes on the whole batch (every rank computes it for itself: no communication in the reference leg)
+    net1, one = build(sd)
+    losses1 = []
+    for t in range(STEPS):
+        one._rtx.inject = (masks[t].cuda(), noise[t].cuda())
+        losses1.append(one._fused_step(batches[t], None, want_loss=True))
+    want = [p.detach().cpu().numpy().copy() for p in net1._param_list()]
+    init = [sd[k] for k in ("enc_layers.0.weight", "enc_layers.0.bias", "enc_layers.1.weight", "enc_layers.1.bias",
+                            "dec_layers.0.weight", "dec_layers.0.bias", "dec_layers.1.weight", "dec_layers.1.bias")]
+    worst = {}
+    for sharded in (True, False):
+        net, model = build(sd)
+        plan = parallel.attach(model, sharded=sharded, engine="native")
+        assert plan.native and plan.transport == "torch" and plan.comm_dtype == torch.bfloat16
+        for t in range(STEPS):
+            rb = parallel.shard_batch(batches[t], rank, world)
+            assert len(rb) == B_LOCAL and rb.global_len == Bg
+            s, e = parallel.shard_rows(Bg, rank, world)
+            model._rtx.inject = (masks[t][s:e].cuda(), noise[t][s:e].cuda())
+            loss = model._fused_step(rb, None, want_loss=True)      # (the summed loss of the eight ranks)
+            assert abs(loss - losses1[t]) < 2e-3 * abs(losses1[t]), (sharded, t, loss, losses1[t])
+        eng = net._rtx_engines["bf16"]
+        owned = [eng.dp_owned_rows(l) for l in range(4)]
+        assert [o[2] for o in owned] == ([True, False, False, True] if sharded else [False] * 4), owned
+        if sharded:
+            assert model._rtx.masters_sharded
+            # two reduce-scattered matrices, rows padded to multiples of 128 (+ the ones column): 640 x 3000 and 3072 x 600 bf16
+            assert eng.get_option("dp_bytes_reduce_scatter") == 2 * (640 * 3000 + 3072 * 600)
+            assert eng.get_option("dp_bytes_all_gather") == 2 * (640 * 3072 + 3072 * 640)      # the padded compute copies
+            model.consolidate()                  # collective: the float32 rows of the other ranks
+        else:
+            assert eng.get_option("dp_bytes_reduce_scatter") == 0 and eng.get_option("dp_bytes_all_reduce") > 2 * 2 * 3000 * 600
+        got = [p.detach().cpu().numpy() for p in net._param_list()]
+        # every rank holds the SAME parameters (bit for bit): checksum of the bit patterns, min == max over the ranks
+        chk = torch.tensor([float(np.sum(g.view(np.int32).astype(np.int64) % 1000003)) for g in got], dtype=torch.float64)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), ("replicas differ", sharded, lo, hi)
+        for k, (g, w, p0) in enumerate(zip(got, want, init)):
+            d = np.abs(g - w)
+            moved = float(np.mean(np.abs(w - p0)))      # how far three steps moved this tensor on average (~lr per step)
+            worst[(sharded, k)] = (float(d.max()), float(d.mean()), moved)
+            assert float(d.max()) <= STEPS * 2.1 * LR, (sharded, k, float(d.max()))
+            assert float(d.mean()) < 0.15 * max(moved, 1e-6), (sharded, k, float(d.mean()), moved)
+        plan.close()
+    dist.barrier()
+    if rank == 0:
+        for (sharded, k), (mx, mean, moved) in sorted(worst.items()):
+            print("%s tensor %d: |dp| max %.2e mean %.2e (mean |move| of three steps %.2e)" % ("sharded   " if sharded else "replicated", k, mx, mean, moved))
+        print("DP_WORLD8_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -376,10 +376,19 @@ def test_ndcg_recall_parity_vs_oracle_ml20m_items(numerics):
     d_rec = abs(np.mean(res["recall@50"]) - np.mean(ro["recall@50"]))
     print("%s: nDCG@100 hip %.5f oracle %.5f | Recall@50 hip %.5f oracle %.5f" % (
         numerics, np.mean(res["ndcg@100"]), np.mean(ro["ndcg@100"]), np.mean(res["recall@50"]), np.mean(ro["recall@50"])))
-    tol = 1e-4 if numerics == "fp32" else 5e-3
-    assert d_ndcg < tol and d_rec < tol
+    # RELATIVE bounds (the means are ~2.5e-3 at these random weights: chance level, where bf16 rounding reorders near-ties)
+    tol = 1e-3 if numerics == "fp32" else 5e-2
+    assert d_ndcg < tol * np.mean(ro["ndcg@100"]) and d_rec < tol * np.mean(ro["recall@50"])
     if numerics == "fp32":
         assert np.max(np.abs(res["ndcg@100"] - ro["ndcg@100"])) < 1e-3
+    else:
+        # what bf16 must preserve is the ranking itself: overlap of the two top-100 lists per user
+        hip = np.concatenate([model.predict(torch.from_numpy(xo[i:i + 64]).cuda())[0].cpu().numpy() for i in range(0, 192, 64)])
+        top_h = np.argpartition(-hip, 100, axis=1)[:, :100]
+        top_o = np.argpartition(-lo, 100, axis=1)[:, :100]
+        overlap = np.array([len(set(a) & set(b)) for a, b in zip(top_h, top_o)]) / 100.0
+        print("bf16 top-100 overlap with the oracle: mean %.3f min %.2f" % (overlap.mean(), overlap.min()))
+        assert overlap.mean() > 0.85 and overlap.min() > 0.60
 
 
 # ---------------------------------------------------------------------------------------------- properties at the full shape
@@ -1045,6 +1054,23 @@ def test_dp_world2_on_one_gpu():
     assert out.returncode == 0 and "DP_WORLD2_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+def test_dp_world8_on_one_gpu():
+    """EIGHT data-parallel ranks (gloo over device tensors) on the one GPU of the box, bf16 numerics and bf16 gradient images,
+    engine-scheduled step, sharded and replicated optimizer: three steps land on the single-GPU result of the 8x batch within the
+    bound stated in tests/dp_world8_onegpu_check.py, every rank holds bit-identical parameters, the engine's exchange
+    statistics name the bytes (the metric's 8-GPU numerics, which the two-rank tests do not reach)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [os.sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dp_world8_onegpu_check.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    print(out.stdout[-1500:])
+    assert out.returncode == 0 and "DP_WORLD8_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_architectures_vs_oracle(seed):
     """randomly drawn networks (depths 1..3 per side, widths that are not multiples of anything, VAE / DAE / conditioned,
@@ -1452,7 +1478,7 @@ def test_bf16_fast_paths_match_the_generic_kernels(case):
         pred = model.predict(smp._csr_tr.gather_dense(rbs[0].rows))[0].cpu().numpy()
         return losses, [q.detach().cpu().numpy().copy() for q in net._param_list()], pred
 
-    fast = run({})
+    fast = run({"sparse_in": 1})
     slow = run({"sparse_in": 0, "small_fwd": 0, "small_bwd": 0})
     for a, b in zip(fast[0], slow[0]):
         assert abs(a - b) < 2e-4 * abs(b), (case, fast[0], slow[0])
@@ -1466,13 +1492,16 @@ def test_bf16_fast_paths_match_the_generic_kernels(case):
 
 
 # ---------------------------------------------------------------------------------------------- round 3: the benchmarked shape
-@pytest.mark.parametrize("numerics", ["fp32", "bf16"])
+@pytest.mark.parametrize("numerics", ["fp32", "bf16", "bf16-sparse-in"])
 def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
-    """BASELINE.json configs[1] exactly as bench.py times it -- I = 20108, B = 500, the DEFAULT step configuration (bf16: sparse
-    first layer, one-launch hidden layers, the 1580 + 60-tile grouped weight-gradient + Adam launch with the encoder matrix and the
-    transposed hidden copies, the decoder matrix's kernel on the side stream; gradients never stored) -- two steps with injected
-    dropout masks / noise against oracle/mvae_oracle.c: loss, all eight parameter tensors, exp_avg and exp_avg_sq
-    (reference models.py:817-835).  Prints the achieved errors."""
+    """BASELINE.json configs[1] exactly as bench.py times it -- I = 20108, B = 500, the DEFAULT step configuration (bf16: dense MFMA
+    first layer, half-precision logits, one-launch hidden layers, the 1580 + 60-tile grouped weight-gradient + Adam launch with the
+    encoder matrix and the transposed hidden copies, the decoder matrix's kernel on the side stream; gradients never stored) -- two
+    steps with injected dropout masks / noise against oracle/mvae_oracle.c: loss, all eight parameter tensors, exp_avg and
+    exp_avg_sq (reference models.py:817-835).  "bf16-sparse-in": the same with the first layer as the sparse VALU product
+    (bench.py's `first_layer_sparse_valu` line).  Prints the achieved errors."""
+    sparse_in = numerics.endswith("sparse-in")
+    numerics = numerics.split("-")[0]
     from oracle import c_oracle
     from rectorch_amd.utils import synth_interactions, hash_state_dict
     from rectorch_amd.samplers import DataSampler
@@ -1482,6 +1511,9 @@ def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
     params, keys = params_in_order(sd)
     net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, numerics=numerics)
     assert model.keep_grads is False
+    if sparse_in:
+        st_, _, m_, v_ = model._ensure_train_state()
+        net.rtx_engine(numerics, B, train_buffers=(st_.grads, m_, v_)).set_option("sparse_in", 1)
     ref = c_oracle.OracleTrainer([I, H, L], [L, H, I], params, "vae", 0.5, beta=0.2, anneal_steps=0, lr=1e-3)
     gen = torch.Generator().manual_seed(11)
     fp32 = numerics == "fp32"
@@ -1517,6 +1549,8 @@ def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
             assert frac < 5e-3 and float(d.mean()) < 1.2e-5, (k, frac, float(d.mean()))
             assert em < 2.5e-2 and ev < 2.5e-2, (k, em, ev)
     assert model._rtx.adam_step == 2
+    if not fp32:
+        assert bool(net._rtx_engines[numerics].get_option("last_sparse_in")) == sparse_in
 
 
 def _grouped_interactions(n_users, n_items, n_groups, seed):
