@@ -906,6 +906,9 @@ int rtx_engine_decode(rtx_engine* e, const float* z, int32_t batch, float* logit
 // a multiple of 4 floats runs INSIDE its weight-gradient kernel (dw_adam.hip: the gradient never reaches HBM and the
 // optimizer's HBM traffic overlaps the matrix work); biases and the remaining tensors follow in one small launch.
 // Otherwise the gradients land in the bound buffers (data-parallel exchange, p.grad, float32 parity mode).
+// (the float32 parity mode stores its gradients and runs one multi-tensor k_adam launch.  Round 4 measured Adam as an epilogue of its
+//  TN product too -- IEEE sqrt / divisions on 64 accumulators per lane, 4-byte accesses in the MFMA layout: 1.130 ms per ml-20m step
+//  against 1.052 with the separate launch, whose 110 us of streaming it replaced by ~190 us of epilogues: dropped)
 static bool layer_fusable(const rtx_engine* e, const Layer& l) { return e->bf16 && l.in >= 4; }   // (rows of in % 4 != 0 floats: the strided epilogue, dw_adam.hip)
 static bool layer_is_big(const Layer& l) { return (long)l.out * l.in >= (1L << 20); }
 

@@ -10,6 +10,7 @@ import inspect
 import random
 
 import numpy as np
+import torch
 
 from .metrics import Metrics
 
@@ -113,10 +114,14 @@ def evaluate_device(model, test_loader, metric_list):
         return evaluate(model, test_loader, metric_list)
     ks = sorted({k for _, _, k in parsed})
     out = _PerUserResults(metric_list)
+    per_batch = []
     for rb in test_loader.iter_rows():
         scores = model.predict(rb)[0]                    # HIP forward on the sparse rows, -inf at the train items
-        ndcg, recall = topk_metrics(scores, rb.te, rb.rows, ks)
-        ndcg, recall = ndcg.cpu().numpy(), recall.cpu().numpy()
+        per_batch.append(topk_metrics(scores, rb.te, rb.rows, ks))
+    # ONE device -> host copy for the whole loader (the per-batch .cpu() of round 3 was a host sync per 500 users)
+    if per_batch:
+        ndcg = torch.cat([n for n, _ in per_batch], dim=1).cpu().numpy()
+        recall = torch.cat([r for _, r in per_batch], dim=1).cpu().numpy()
         out.add({m: (ndcg if name == "ndcg" else recall)[ks.index(k)] for m, name, k in parsed})
     return out.finish()
 
