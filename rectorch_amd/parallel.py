@@ -364,8 +364,21 @@ class NativePlan:
                     return -1
             return call
 
+        import contextlib
+
+        @contextlib.contextmanager
         def on(stream):
-            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0)))
+            # gloo (the tests' transport: several ranks on one GPU) stages device tensors through the host on streams of its own.
+            # Its ordering against the engine's streams is not relied upon: the DEVICE is drained before the collective and after it
+            # (a sync of the engine's stream alone was not enough: the sharded bf16 exchange read gradient images that were still
+            # zero or half written on ~half of the runs, profiles/r4_dp_gloo_race.txt).  RCCL ("nccl") is given the stream and
+            # orders itself on it.
+            if not native:
+                torch.cuda.synchronize()
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0))):
+                yield
+                if not native:
+                    torch.cuda.synchronize()
 
         def all_reduce(_ctx, buf, n, dtype, stream):
             t = _alias(buf, n * (2 if dtype == _lib.RTX_BF16 else 4), dts[dtype])

@@ -91,7 +91,7 @@ def main():
             moved = float(np.mean(np.abs(w - p0)))      # how far three steps moved this tensor on average (~lr per step)
             worst[(sharded, k)] = (float(d.max()), float(d.mean()), moved)
             assert float(d.max()) <= STEPS * 2.1 * LR, (sharded, k, float(d.max()))
-            assert float(d.mean()) < 0.15 * max(moved, 1e-6), (sharded, k, float(d.mean()), moved)
+            assert float(d.mean()) < 0.02 * max(moved, 1e-6)      # achieved on MI355X: 0.001 - 0.004, (sharded, k, float(d.mean()), moved)
         plan.close()
     dist.barrier()
     if rank == 0:

@@ -1,8 +1,6 @@
-OUT=gpurun_out/r4k; mkdir -p $OUT
-timeout 200 build/native/test_gemm > $OUT/test_gemm.txt 2>&1; echo "test_gemm rc=$?"; grep -E "f32 adam|FAIL|PASSED|FAILED" $OUT/test_gemm.txt | head
-timeout 400 build/native/test_engine > $OUT/test_engine.txt 2>&1; echo "test_engine rc=$?"; tail -1 $OUT/test_engine.txt
-timeout 600 python -m pytest tests -q -x -m gpu -k "dp_world or ml20m_shape or test_g1 or test_g2 or test_g3 or test_g4 or config0 or config3 or random_arch or g8_epoch or g9 or custom_op or reference_test" > $OUT/pytest_subset.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_subset.log
-timeout 200 python bench.py --steps 100 --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"; python -c "
-import json; d=json.loads(open('$OUT/bench_default.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['fp32_parity'])"
-timeout 100 python bench.py --steps 50 --numerics fp32 --no-cpu-baseline --no-extras --opt fuse_adam_f32=0 > $OUT/bench_fp32_unfused.json 2> $OUT/bench_fp32_unfused.err; echo "bench rc=$?"; python -c "
-import json; d=json.loads(open('$OUT/bench_fp32_unfused.json').read().strip().splitlines()[-1]); print('fp32 unfused', d['ms_per_step'])"
+OUT=gpurun_out/r4r; mkdir -p $OUT
+for i in 1 2 3 4 5 6; do
+timeout 100 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29530+i)) tests/dp_world2_onegpu_check.py > $OUT/w2_$i.out 2> $OUT/w2_$i.err; rc=$?; echo "w2 run $i rc=$rc"
+if [ $rc -ne 0 ]; then grep -E "AssertionError" $OUT/w2_$i.err | head -1 | cut -c1-250; fi
+done
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29522 tests/dp_world8_onegpu_check.py > $OUT/w8.out 2> $OUT/w8.err; echo "w8 rc=$?"; grep -E "AssertionError|Error" $OUT/w8.err | grep -v elastic | head -3 | cut -c1-600; grep -v Gloo $OUT/w8.out | tail -20
