@@ -109,6 +109,11 @@ struct rtx_engine {
     uint32_t* in_ent = nullptr;
     int32_t *in_desc = nullptr, *in_wsplit = nullptr;
     int64_t in_cap_chunks = 0;
+    // batch image A[0] written by scatter (k_gather_scatter): per row slot, the columns the last launch wrote
+    int32_t *img_written = nullptr, *img_nwritten = nullptr;
+    int img_cap = 0;
+    bool img_exact = false;           // A[0] is zero except the listed columns (any other writer of A[0] clears this flag)
+    int opt_gather_scatter = 1;       // 0: k_gather rewrites the whole image every batch (rounds 1-3)
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
     hipStream_t side_for = nullptr;   // the caller's stream the side stream was probed against (make_side_stream)
@@ -454,6 +459,34 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
         a.X = l.A; a.tsum = e->tsum;
         a.training = training; a.dropout_p = e->cfg.dropout_p;
         a.mask = step->dropout_mask; a.seed = step->seed; a.offset = step->offset;
+        // The image is all zeros but for ~75 entries per user: with a resident matrix (its longest row is known) only those are
+        // touched -- cleared, rewritten, listed (k_gather_scatter).  First use, a longer matrix, or another writer of A[0] in
+        // between (the sparse first layer's k_in_chunks, a densified batch through k_gather): one full reset of image and lists.
+        if (e->opt_gather_scatter && in->max_row_len > 0 && ((int64_t)in->max_row_len + 66) * e->Bp_alloc * 4 <= ((int64_t)256 << 20)) {
+            const int need = (in->max_row_len + 2 + 63) / 64 * 64;
+            if (need > e->img_cap) {
+                if (e->img_written) {
+                    RTX_HIP(hipStreamSynchronize(st));
+                    for (void* q : {(void*)e->img_written, (void*)e->img_nwritten}) {
+                        e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), q));
+                        (void)hipFree(q);
+                    }
+                    e->img_written = nullptr; e->img_nwritten = nullptr;
+                }
+                RTX_TRY(dev_alloc(e, (void**)&e->img_written, (size_t)e->Bp_alloc * need * sizeof(int32_t), false));
+                RTX_TRY(dev_alloc(e, (void**)&e->img_nwritten, (size_t)e->Bp_alloc * sizeof(int32_t)));
+                e->img_cap = need;
+                e->img_exact = false;
+            }
+            if (!e->img_exact) {
+                RTX_HIP(hipMemsetAsync(l.A, 0, (size_t)e->Bp_alloc * l.inp * e->esz, st));
+                RTX_HIP(hipMemsetAsync(e->img_nwritten, 0, (size_t)e->Bp_alloc * sizeof(int32_t), st));
+                e->img_exact = true;
+            }
+            a.written = e->img_written; a.n_written = e->img_nwritten; a.written_cap = e->img_cap;
+        } else {
+            e->img_exact = false;
+        }
         TIMED("gather");
         RTX_TRY(rtx_launch_gather(a, e->bf16, st));
     }
@@ -494,7 +527,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
             c.training = training; c.dropout_p = e->cfg.dropout_p;
             c.mask = step->dropout_mask; c.seed = step->seed; c.offset = step->offset;
             c.ent = e->in_ent; c.desc = e->in_desc; c.wsplit = e->in_wsplit; c.cap_chunks = e->in_cap_chunks;
-            if (training) { c.target = *tg; c.tsum = e->tsum; c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; }
+            if (training) { c.target = *tg; c.tsum = e->tsum; c.X = (bf16_t*)l.A; c.ldx = l.inp; c.Bp = Bp; e->img_exact = false; }
             {
                 TIMED("in_chunks");
                 RTX_TRY(rtx_launch_in_chunks(c, st));
@@ -1674,6 +1707,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
+    else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
     else if (k == "dp_shard_min_elems") {
         RTX_CHECK(!e->dp.on && value >= 1, RTX_ESTATE, "set_option: dp_shard_min_elems (>= 1) must be set before rtx_engine_dp_attach");
         e->opt_dp_shard_min_elems = value;
@@ -1722,6 +1756,7 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     if (k == "fuse_adam") *value = e->opt_fuse_adam;
     else if (k == "lse_fuse") *value = e->opt_lse_fuse;
     else if (k == "logits16") *value = e->opt_logits16;
+    else if (k == "gather_scatter") *value = e->opt_gather_scatter;
     else if (k == "dp_shard_min_elems") *value = e->opt_dp_shard_min_elems;
     else if (k == "dp_bytes_all_reduce") *value = (int32_t)std::min<int64_t>(e->dp.st_all_reduce, INT32_MAX);       // per rank, last step
     else if (k == "dp_bytes_reduce_scatter") *value = (int32_t)std::min<int64_t>(e->dp.st_reduce_scatter, INT32_MAX);

@@ -123,9 +123,87 @@ __global__ __launch_bounds__(256) void k_gather(const RtxGatherArgs a)
     }
 }
 
+// The same batch image by SCATTER (RtxGatherArgs::written): one workgroup per row slot clears what the previous launch wrote
+// there, then writes this user's stored entries.  Everything k_gather computes (norm, target sum, dropout, ones column) is
+// computed the same way; only the zeros are not written again.  Reference: samplers.py:99-100 (.toarray()) + nets.py:395-399.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_scatter(const RtxGatherArgs a)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    T* X = (T*)a.X + (size_t)b * a.ldx;
+    int32_t* wr = a.written + (size_t)b * a.written_cap;
+    const int n_old = a.n_written[b];
+    for (int k = tid; k < n_old; k += 256) X[wr[k]] = Elem<T>::from(0.f);
+    __syncthreads();   // (a workgroup-scope fence: the clears are ordered before this launch's writes of the same columns)
+    if (b >= a.B) {    // padding row of the batch: all zero, ones column included
+        if (tid == 0) { a.n_written[b] = 0; a.tsum[b] = 0.f; }
+        return;
+    }
+    const int64_t u = csr_row(a.in, b);
+    const int64_t beg = a.in.indptr[u], end = a.in.indptr[u + 1];
+    const bool cond = a.Iin > a.I;
+    float ss;
+    if (!a.in.values && !cond) {
+        ss = (float)(end - beg);
+    } else {
+        ss = 0.f;
+        for (int64_t k = beg + tid; k < end; k += 256) {
+            const float v = a.in.values ? a.in.values[k] : 1.f;
+            if (!cond || a.in.indices[k] < a.I) ss += v * v;
+        }
+        ss = block_sum(ss, red);
+    }
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    {
+        const int64_t ut = csr_row(a.target, b);
+        const int64_t tb = a.target.indptr[ut], te = a.target.indptr[ut + 1];
+        float ts;
+        if (!a.target.values && !cond) {
+            ts = (float)(te - tb);
+        } else {
+            ts = 0.f;
+            for (int64_t k = tb + tid; k < te; k += 256)
+                if (!cond || a.target.indices[k] < a.I) ts += a.target.values ? a.target.values[k] : 1.f;
+            ts = block_sum(ts, red);
+        }
+        if (tid == 0) a.tsum[b] = ts;
+    }
+    const bool drop = a.training && a.dropout_p > 0.f;
+    const float scale = drop ? (a.dropout_p < 1.f ? 1.f / (1.f - a.dropout_p) : 0.f) : 1.f;
+    const int n = (int)(end - beg);   // < written_cap (the launcher checked the matrix's longest row)
+    for (int k = tid; k < n; k += 256) {
+        const int i = a.in.indices[beg + k];
+        float v = a.in.values ? a.in.values[beg + k] : 1.f;
+        if (i < a.I) v *= inv;
+        if (drop && i < a.I) {
+            const uint64_t e = (uint64_t)b * (uint64_t)a.I + (uint64_t)i;
+            const bool keep = a.mask ? (a.mask[e] != 0) : rtx_dropout_keep(a.seed, a.offset, e, a.dropout_p);
+            v = keep ? v * scale : 0.f;
+        }
+        if (i < a.ldx) X[i] = Elem<T>::from(v);
+        wr[k] = i < a.ldx ? i : 0;
+    }
+    if (tid == 0) {
+        X[a.Iin] = Elem<T>::from(1.f);   // ones column -> bias gradient
+        wr[n] = a.Iin;
+        a.n_written[b] = n + 1;
+    }
+}
+
 int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream)
 {
     RTX_CHECK(a.ldx % 8 == 0, RTX_EINVAL, "gather: ldx must be a multiple of 8");
+    if (a.written) {
+        RTX_CHECK(a.n_written && a.in.max_row_len > 0 && a.in.max_row_len < a.written_cap && a.Iin < a.ldx, RTX_EINVAL,
+                  "gather: the scatter form needs the matrix's longest row (%d) below the list capacity (%d)", a.in.max_row_len, a.written_cap);
+        if (is_bf16)
+            hipLaunchKernelGGL(k_gather_scatter<bf16_t>, dim3(a.Bp), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL(k_gather_scatter<float>, dim3(a.Bp), dim3(256), 0, stream, a);
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
+    }
     if (is_bf16)
         hipLaunchKernelGGL(k_gather<bf16_t>, dim3(a.Bp), dim3(256), 0, stream, a);
     else

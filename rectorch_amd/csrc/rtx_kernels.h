@@ -39,6 +39,14 @@ struct RtxGatherArgs {
     float dropout_p;
     const uint8_t* mask;  // [B][I] injected keep-mask (nullable -> Philox)
     uint64_t seed, offset;
+    // Scatter form (round 4, nullable): the image is ALL ZERO except the columns the previous launch wrote, which it listed per row
+    // slot (written[b * written_cap ..], n_written[b]).  The launch clears those, writes this batch's stored entries and the ones
+    // column (2- / 4-byte scattered stores) and lists them again: ~150 stores per user instead of a 40-KB row of zeros.  The
+    // caller guarantees the invariant (engine.hip: any other writer of the image, or a row longer than written_cap - 1, makes the
+    // next launch a full rewrite) and in.max_row_len < written_cap.
+    int32_t* written;
+    int32_t* n_written;
+    int written_cap;
 };
 int rtx_launch_gather(const RtxGatherArgs& a, int is_bf16, hipStream_t stream);
 

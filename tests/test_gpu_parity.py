@@ -1491,6 +1491,39 @@ def test_bf16_fast_paths_match_the_generic_kernels(case):
     assert rel(fast[2][fin], slow[2][fin]) < 5e-3
 
 
+def test_batch_image_by_scatter_equals_the_full_rewrite():
+    """round 4: with a resident matrix the dense batch image is kept all-zero between batches and only the stored entries are
+    cleared / rewritten (k_gather_scatter).  A sequence of batches through ONE engine -- different users, a smaller batch (fewer
+    padded rows), a DENSE tensor batch in between (full rewrite: the lists go stale and the next sparse batch resets the image),
+    training steps with dropout in between -- must give bit-identical predictions and parameters with the scatter form on and off."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L = 1500, 96, 24
+    X = synth_interactions(700, I, mu=3.0, sigma=1.0, dmax=I // 3, seed=3)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 9, bias_std=0.1)
+    outs = []
+    for scatter in (1, 0):
+        net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, numerics="bf16", predict_numerics="bf16")
+        st, _, m, v = model._ensure_train_state()
+        eng = net.rtx_engine("bf16", 130, train_buffers=(st.grads, m, v))
+        eng.set_option("gather_scatter", scatter)
+        smp = DataSampler(X, batch_size=130, shuffle=False)
+        rbs = list(smp.iter_rows())            # 5 batches of 130 + one of 50
+        res = []
+        torch.manual_seed(5)
+        res.append(model.predict(rbs[0])[0].cpu().numpy())
+        res.append(model.predict(rbs[5])[0].cpu().numpy())                       # 50 users: fewer padded rows
+        model._fused_step(rbs[1], None, want_loss=True)                          # training batches (dropout) in between
+        res.append(model.predict(smp._csr_tr.gather_dense(rbs[2].rows))[0].cpu().numpy())   # dense tensor: the full-rewrite kernel
+        model._fused_step(rbs[3], None, want_loss=True)
+        res.append(model.predict(rbs[4])[0].cpu().numpy())
+        res.append(model.predict(rbs[0])[0].cpu().numpy())
+        res += [q.detach().cpu().numpy().copy() for q in net._param_list()]
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------- round 3: the benchmarked shape
 @pytest.mark.parametrize("numerics", ["fp32", "bf16", "bf16-sparse-in"])
 def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
