@@ -325,7 +325,8 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * n_items + cond_dim <= 20 480 and at most ~4000 expected 64-entry chunks per batch), "small_fwd" / "small_bwd" (0/1, bf16: hidden
  * layers and the VAE head of the forward pass / of the data-gradient chain as one register-resident launch each --
  * small_layers.hip -- for padded widths <= 1024), "logits16" (0/1, bf16 training step: the logits leave their product as IEEE half
- * in the buffer of d loss / d logits and the loss kernel converts them in place), "dp_shard_min_elems" (>= 1, before
+ * in the buffer of d loss / d logits and the loss kernel converts them in place), "gather_scatter" (0/1: the dense batch image stays
+ * all-zero between batches and only the stored entries are cleared / written -- resident CSR batches), "dp_shard_min_elems" (>= 1, before
  * rtx_engine_dp_attach: smallest weight matrix the sharded optimizer shards; default 2^20 elements).
  * Replaces round 1's RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
