@@ -32,6 +32,11 @@
 // data-parallel path and rtx_engine_loss_grads.  Rows that are not a multiple of 4 floats (n_items = 17 769 ...) take the same
 // fused epilogue through dword-aligned 16-byte accesses (AL = false, round 3).
 #include "rtx_gemm.h"
+#include <type_traits>
+
+#ifndef DW_SPLIT_PMV
+#define DW_SPLIT_PMV 1   // (0: measurement build -- the whole optimizer state of a tile is requested before the K walk, as in rounds 2-3)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 dw_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float dw_f32x16;
@@ -268,32 +273,43 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
     if (skip & 2) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) { pv[q] = dw_f32x4{0.1f, 0.2f, 0.3f, 0.4f}; mv[q] = dw_f32x4{0.f, 0.f, 0.f, 0.f}; vv[q] = dw_f32x4{1e-4f, 1e-4f, 1e-4f, 1e-4f}; }
-    } else
-    if constexpr (EPI == RTX_DW_ADAM) {
-        // out-of-range threads load a clamped (valid) address instead of branching around the load: a branch per load
-        // makes hipcc wait vmcnt(0) behind each one
-        if constexpr (AL) {
-            const int colc = min(col, p.N_real - 4);
+    }
+    // out-of-range threads load a clamped (valid) address instead of branching around the load: a branch per load makes hipcc
+    // wait vmcnt(0) behind each one.  AL = false: the row's last group is partial: its thread loads the row's LAST four elements
+    // (a valid address); its own are taken from them, shifted, where they are consumed (below).
+    auto load_state = [&](auto q0c, auto q1c) __attribute__((always_inline)) {
+        constexpr int q0 = decltype(q0c)::value, q1 = decltype(q1c)::value;
+        const int colc = min(col, p.N_real - 4);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
-                const size_t off = (size_t)rowc * p.N_real + colc;
+        for (int q = q0; q < q1; ++q) {
+            const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
+            const size_t off = (size_t)rowc * p.N_real + colc;
+            if constexpr (AL) {
                 pv[q] = dw_ld_nt(p.adam.p + off);
                 mv[q] = dw_ld_nt(p.adam.m + off);
                 vv[q] = dw_ld_nt(p.adam.v + off);
-            }
-        } else {
-            // the row's last group is partial: its thread loads the row's LAST four elements (a valid address); its own are taken
-            // from them, shifted, where they are consumed (below)
-            const int colc = min(col, p.N_real - 4);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int rowc = min(tm * TM + q * RPP + rowl, p.M_real - 1);
-                const size_t off = (size_t)rowc * p.N_real + colc;
+            } else {
                 pv[q] = dw_ld_nt_u(p.adam.p + off);
                 mv[q] = dw_ld_nt_u(p.adam.m + off);
                 vv[q] = dw_ld_nt_u(p.adam.v + off);
             }
+        }
+    };
+    // Round 4: the tile's optimizer state arrives in TWO halves.  The first (passes 0 .. NP/2) leaves before the K walk as before;
+    // the second leaves right behind the LAST operand slice's DMA, three slices before the walk ends, and is consumed after the
+    // first half has gone through Adam and its stores: half the bytes queue in front of the first operand slice (the walk starts
+    // earlier), and a workgroup's reads overlap its own writes instead of coming in one burst each (the kernel needs reads and
+    // writes in flight together: DESIGN.md 4.5).  Needs the three-stage ring and at least three slices; otherwise all up front.
+#ifndef DW_EARLY_PASSES
+#define DW_EARLY_PASSES (NP / 2)   // (measurement builds: 0 .. NP)
+#endif
+    constexpr int NPH = (DW_SPLIT_PMV && EPI == RTX_DW_ADAM && NS == 3 && NP >= 2) ? (DW_EARLY_PASSES < NP ? DW_EARLY_PASSES : NP) : NP;   // passes loaded up front
+    constexpr int HL = 3 * (NP - NPH);                                                               // late load instructions per thread
+    const bool late = HL > 0 && !(skip & 3) && p.k_slices >= 3;
+    if (!(skip & 2)) {
+        if constexpr (EPI == RTX_DW_ADAM) {
+            load_state(std::integral_constant<int, 0>(), std::integral_constant<int, NPH>());
+            if (!late && NPH < NP) load_state(std::integral_constant<int, NPH>(), std::integral_constant<int, NP>());
         }
     }
 
@@ -342,14 +358,19 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
     if (stamps && tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
-        if (NS == 3 && nk - t >= 2) dw_wait_vm<LPS>();   // my pieces of slice t have landed (slice t+1 may be in flight; p / m / v are older)
-        else dw_wait_vm<0>();
+        // my pieces of slice t have landed.  Younger operations that may still fly: slice t + 1's pieces (LPS), and -- in the last two
+        // iterations -- the late half of the optimizer state (HL), issued behind the last slice's DMA; p / m / v's first half is older
+        if (NS == 3 && nk - t > 2) dw_wait_vm<LPS>();
+        else if (NS == 3 && nk - t == 2) { if (late) dw_wait_vm<LPS + HL>(); else dw_wait_vm<LPS>(); }
+        else { if (late && NS == 3) dw_wait_vm<HL>(); else dw_wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();         // everybody's have; everybody is done reading slice t-1
         if (stamps && tid == 0 && t == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
         if (t + NS - 1 < nk) {                // refill the stage slice t-1 just released
             int nst = stage + NS - 1;
             if (nst >= NS) nst -= NS;
             load_slice(nst, t + NS - 1);
+            if constexpr (HL > 0)
+                if (late && t + NS == nk) load_state(std::integral_constant<int, NPH>(), std::integral_constant<int, NP>());   // behind the LAST slice's DMA
         }
         {
             const unsigned sbase = (unsigned)(size_t)(lbase + stage * STAGE);
@@ -372,7 +393,8 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
 #undef DW_FRAG
 #undef DW_MMA
     if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();
-    dw_wait_vm<0>();
+    if (late && nk) dw_wait_vm<HL>();   // (every DMA piece has landed: the last iteration waited for it; the late state loads may still fly)
+    else dw_wait_vm<0>();
     __builtin_amdgcn_s_barrier();   // every fragment read is done: the stages become the gradient tile's parking space
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
