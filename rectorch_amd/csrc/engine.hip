@@ -127,6 +127,7 @@ struct rtx_engine {
     // record / wait: -3 us per step in three alternating pairs (283.7 / 280.1 / 276.0 -> 280.1 / 276.8 / 273.2,
     // profiles/r4_hop_values.txt); where the device cannot wait on a value the events remain
     int opt_hop_values = 1;
+    int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
     uint32_t hop_seq = 0;
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
@@ -303,6 +304,7 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form 
         // costs: 16 slabs instead of 25 at the ml-20m shape is 5 us per step (286 vs 291; 12: 288, 8: 292)
         if (form == RTX_FORM_NN && s > 16) s = 16;
         if (pl.k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
+        if (pl.k_slices >= 64 && form == RTX_FORM_NT && e->opt_splitk_fwd > 0) s = e->opt_splitk_fwd;
         const int max_s = pl.k_slices / 2 > 0 ? pl.k_slices / 2 : 1;
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
@@ -1743,6 +1745,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
     else if (k == "hop_values") e->opt_hop_values = value != 0;
+    else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
     else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
     else if (k == "dp_shard_min_elems") {
         RTX_CHECK(!e->dp.on && value >= 1, RTX_ESTATE, "set_option: dp_shard_min_elems (>= 1) must be set before rtx_engine_dp_attach");

@@ -67,6 +67,8 @@ def main():
         same = all(np.allclose(d[m], h[m], rtol=1e-12, equal_nan=True) for m in mets)
         if ref is None:
             ref = d
+        if numerics == "bf16":
+            out_bf16_metrics = d
         tf = flops_user * U / t_dev / 1e12
         out[numerics] = {"evaluate_device_s": t_dev, "users_per_s_device": U / t_dev, "evaluate_host_metrics_s": t_host,
                          "users_per_s_host_metrics": U / t_host, "device_equals_host_metrics": bool(same),
@@ -78,6 +80,17 @@ def main():
         del model, net
     out["value"] = out["bf16"]["users_per_s_device"]
     out["unit"] = "users/s"
+    # the same held-out users in batches of 2000 (the sampler's batch size is the caller's choice; per batch the path costs three C
+    # calls and a handful of tensor allocations on the host, which a 500-user batch does not amortise)
+    smp_big = DataSampler(tr, te, batch_size=2000, shuffle=False)
+    net = MultiVAE_net([L, H, I])
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    model = MultiVAE(net, predict_numerics="bf16")
+    evaluate_device(model, smp_big, mets)
+    t_big, d_big = timed(lambda: evaluate_device(model, smp_big, mets), 3)
+    out["bf16_batch_2000"] = {"evaluate_device_s": t_big, "users_per_s_device": U / t_big,
+                              "same_metrics_as_batch_500": bool(all(np.allclose(d_big[m], out_bf16_metrics[m], rtol=1e-12, equal_nan=True) for m in mets))}
+    del model, net
     # the reference's op sequence on the host cores: dense batch -> float32 forward (oracle/rectorch_cpu.py) -> -inf at the train
     # items -> Metrics.compute (argpartition); bounded sample of 2 batches after one warm-up batch
     from oracle.rectorch_cpu import CpuNet
