@@ -1082,68 +1082,12 @@ struct RtxTopkArgs {
     int B;
 };
 
-__global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
+// bitonic sort of n (a power of two <= RTX_TOPK_MAX) (key, index) pairs in LDS: key descending, index ascending among equal keys
+__device__ __forceinline__ void topk_sort(uint32_t* ckey, int32_t* cidx, int n, int tid)
 {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t ckey[RTX_TOPK_MAX];
-    __shared__ int32_t cidx[RTX_TOPK_MAX];
-    __shared__ float rel[RTX_TOPK_MAX];
-    __shared__ uint32_t sh_prefix, sh_mask, sh_need, sh_cnt_gt, sh_cnt_eq;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* row = a.scores + (size_t)b * a.ld;
-    const int K = a.K;
-    // ---- radix select: key T of the K-th largest element
-    if (tid == 0) { sh_prefix = 0; sh_mask = 0; sh_need = (uint32_t)K; }
-    __syncthreads();
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
-        __syncthreads();
-        const uint32_t prefix = sh_prefix, mask = sh_mask;
-        for (int i = tid; i < a.n_items; i += 256) {
-            const uint32_t k = score_key(row[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t need = sh_need, d = 255;
-            for (;; --d) {            // from the largest digit down
-                if (hist[d] >= need || d == 0) break;
-                need -= hist[d];
-            }
-            sh_need = need;           // rank inside digit d
-            sh_prefix = prefix | (d << shift);
-            sh_mask = mask | (255u << shift);
-        }
-        __syncthreads();
-    }
-    const uint32_t T = sh_prefix;
-    const uint32_t need_eq = sh_need;   // how many elements equal to T belong to the top K
-    // ---- collect: everything above T, then need_eq of the ties (lowest index first is not guaranteed: ties at the
-    //      K-th place are arbitrary in the reference's argpartition too)
-    if (tid == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
-    for (int i = tid; i < a.Kp2; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; }
-    __syncthreads();
-    for (int i = tid; i < a.n_items; i += 256) {
-        const uint32_t k = score_key(row[i]);
-        if (k > T) {
-            const uint32_t p = atomicAdd(&sh_cnt_gt, 1u);
-            if (p < (uint32_t)K) { ckey[p] = k; cidx[p] = i; }
-        }
-    }
-    __syncthreads();
-    const uint32_t n_gt = sh_cnt_gt;
-    for (int i = tid; i < a.n_items; i += 256) {
-        const uint32_t k = score_key(row[i]);
-        if (k == T) {
-            const uint32_t p = atomicAdd(&sh_cnt_eq, 1u);
-            if (p < need_eq && n_gt + p < (uint32_t)K) { ckey[n_gt + p] = k; cidx[n_gt + p] = i; }
-        }
-    }
-    __syncthreads();
-    // ---- bitonic sort of Kp2 (key desc, index asc); the padding (key 0, idx max) sinks to the end
-    for (int size = 2; size <= a.Kp2; size <<= 1) {
+    for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < a.Kp2 / 2; i += 256) {
+            for (int i = tid; i < n / 2; i += 256) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
@@ -1155,6 +1099,121 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
             __syncthreads();
         }
     }
+}
+
+// Exact top-K of a score row + the ranking metrics.  Round 4: the selection no longer histograms the row.  The 4-pass radix
+// select of rounds 1-3 put 20 108 LDS atomics per pass on one or two bins (the scores of a row share sign and exponent bits, so
+// the first digits are the same for nearly all of them): 285 us per 500 users, half of evaluate_device (profiles/r4_eval_kernel_stats.txt).
+//   1. every thread keeps the c = ceil(K / 256) largest keys of its 79 elements (registers, no atomics);
+//   2. the K-th largest of these 256 c keys -- all distinct elements -- is a LOWER BOUND L of the K-th largest score of the row
+//      (bitonic sort of <= 1024 keys in LDS);
+//   3. the elements >= L (a few hundred) are collected and sorted; the first K are the answer.
+// More than RTX_TOPK_MAX elements >= L (a row of ties): the radix select below, unchanged, takes over.
+__global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t ckey[RTX_TOPK_MAX];
+    __shared__ int32_t cidx[RTX_TOPK_MAX];
+    __shared__ float rel[RTX_TOPK_MAX];
+    __shared__ double dred[4];
+    __shared__ uint32_t sh_prefix, sh_mask, sh_need, sh_cnt_gt, sh_cnt_eq;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = a.scores + (size_t)b * a.ld;
+    const int K = a.K;
+    // ---- 1. per-thread maxima
+    const int c = (K + 255) / 256;              // 1 .. 4
+    uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;    // this thread's largest keys, descending (0 = below every real key)
+    if (c == 1) {
+        for (int i = tid; i < a.n_items; i += 256) t0 = max(t0, score_key(row[i]));
+    } else {
+        for (int i = tid; i < a.n_items; i += 256) {
+            uint32_t k = score_key(row[i]);
+            if (k > t0) { const uint32_t x = t0; t0 = k; k = x; }
+            if (k > t1) { const uint32_t x = t1; t1 = k; k = x; }
+            if (k > t2) { const uint32_t x = t2; t2 = k; k = x; }
+            if (k > t3) t3 = k;
+        }
+    }
+    // ---- 2. L = K-th largest of the 256 c thread maxima
+    const int n1 = c == 1 ? 256 : (c == 2 ? 512 : 1024);
+    ckey[tid] = t0; cidx[tid] = tid;
+    if (c >= 2) { ckey[256 + tid] = t1; cidx[256 + tid] = 256 + tid; }
+    if (c >= 3) {
+        ckey[512 + tid] = t2; cidx[512 + tid] = 512 + tid;
+        ckey[768 + tid] = c >= 4 ? t3 : 0u; cidx[768 + tid] = 768 + tid;
+    }
+    __syncthreads();
+    topk_sort(ckey, cidx, n1, tid);
+    const uint32_t L = ckey[K - 1];             // (K <= 256 c; 0 when the row has fewer than K elements: everything is collected)
+    __syncthreads();
+    // ---- 3. collect the elements >= L
+    if (tid == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
+    for (int i = tid; i < RTX_TOPK_MAX; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int i = tid; i < a.n_items; i += 256) {
+        const uint32_t k = score_key(row[i]);
+        if (k >= L) {
+            const uint32_t p = atomicAdd(&sh_cnt_gt, 1u);
+            if (p < (uint32_t)RTX_TOPK_MAX) { ckey[p] = k; cidx[p] = i; }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_cand = sh_cnt_gt;
+    int n_sort = a.Kp2;
+    if (n_cand <= (uint32_t)RTX_TOPK_MAX) {
+        while ((uint32_t)n_sort < n_cand) n_sort <<= 1;
+    } else {
+        // ---- a row with more than RTX_TOPK_MAX elements tied at / above the bound: radix select of the K-th largest key T, then
+        //      everything above T and need_eq of the ties (ties at the K-th place are arbitrary in the reference's argpartition too)
+        __syncthreads();
+        if (tid == 0) { sh_prefix = 0; sh_mask = 0; sh_need = (uint32_t)K; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sh_prefix, mask = sh_mask;
+            for (int i = tid; i < a.n_items; i += 256) {
+                const uint32_t k = score_key(row[i]);
+                if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t need = sh_need, d = 255;
+                for (;; --d) {            // from the largest digit down
+                    if (hist[d] >= need || d == 0) break;
+                    need -= hist[d];
+                }
+                sh_need = need;           // rank inside digit d
+                sh_prefix = prefix | (d << shift);
+                sh_mask = mask | (255u << shift);
+            }
+            __syncthreads();
+        }
+        const uint32_t T = sh_prefix;
+        const uint32_t need_eq = sh_need;   // how many elements equal to T belong to the top K
+        if (tid == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
+        for (int i = tid; i < RTX_TOPK_MAX; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; }
+        __syncthreads();
+        for (int i = tid; i < a.n_items; i += 256) {
+            const uint32_t k = score_key(row[i]);
+            if (k > T) {
+                const uint32_t p = atomicAdd(&sh_cnt_gt, 1u);
+                if (p < (uint32_t)K) { ckey[p] = k; cidx[p] = i; }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_gt = sh_cnt_gt;
+        for (int i = tid; i < a.n_items; i += 256) {
+            const uint32_t k = score_key(row[i]);
+            if (k == T) {
+                const uint32_t p = atomicAdd(&sh_cnt_eq, 1u);
+                if (p < need_eq && n_gt + p < (uint32_t)K) { ckey[n_gt + p] = k; cidx[n_gt + p] = i; }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- sort the candidates (key desc, index asc); the padding (key 0, idx max) sinks to the end: the first K are the top K
+    topk_sort(ckey, cidx, n_sort, tid);
     // ---- relevance of every ranked item: value of the held-out row at that item (0 if absent)
     const int64_t u = csr_row(a.held, b);
     const int64_t hb = a.held.indptr[u], he = a.held.indptr[u + 1];
@@ -1164,34 +1223,47 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
         int64_t lo = hb, hi = he;     // binary search (column ids are sorted within a row)
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            const int c = a.held.indices[mid];
-            if (c < item) lo = mid + 1; else hi = mid;
+            const int cc = a.held.indices[mid];
+            if (cc < item) lo = mid + 1; else hi = mid;
         }
         if (lo < he && a.held.indices[lo] == item) v = a.held.values ? a.held.values[lo] : 1.f;
         rel[r] = v;
         if (a.topk) a.topk[(size_t)b * K + r] = item;
     }
     __syncthreads();
-    if (tid == 0) {
-        double gsum = 0.0;
-        long npos = 0;
-        for (int64_t k = hb; k < he; ++k) {
-            const float v = a.held.values ? a.held.values[k] : 1.f;
-            gsum += (double)v;
-            npos += v > 0.f;
+    // ---- metrics.  The terms are the reference's (metrics.py:136-147, 187-196: rel / log2(r + 2), 1 / log2(r + 2)); they are
+    //      computed one per thread and summed by a fixed-order block reduction in double (the serial loop of rounds 1-3 spent
+    //      ~250 double-precision log2 calls on ONE lane per user)
+    double gsum = 0.0;
+    long npos = 0;
+    for (int64_t k = hb; k < he; ++k) {      // (every thread: ~20 entries, no divergence)
+        const float v = a.held.values ? a.held.values[k] : 1.f;
+        gsum += (double)v;
+        npos += v > 0.f;
+    }
+    auto block_sum_f64 = [&](double v) -> double {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) dred[tid >> 6] = v;
+        __syncthreads();
+        return (dred[0] + dred[1]) + (dred[2] + dred[3]);
+    };
+    for (int q = 0; q < a.n_k; ++q) {
+        const int kk = min(min(a.ks[q], a.n_items), K);
+        const long nid = min((long)gsum, (long)min(a.ks[q], a.n_items));      // tp[:min(int(n), k)].sum()   (metrics.py:146)
+        double dcg = 0.0, idcg = 0.0, hits = 0.0;
+        for (int r = tid; r < RTX_TOPK_MAX; r += 256) {
+            const double l2 = log2((double)(r + 2));
+            if (r < kk) { dcg += (double)rel[r] / l2; hits += rel[r] > 0.f ? 1.0 : 0.0; }
+            if (r < nid) idcg += 1.0 / l2;
         }
-        for (int q = 0; q < a.n_k; ++q) {
-            const int kk = min(a.ks[q], a.n_items);
-            double dcg = 0.0, idcg = 0.0;
-            long hits = 0;
-            for (int r = 0; r < kk && r < K; ++r) {
-                dcg += (double)rel[r] / log2((double)(r + 2));
-                hits += rel[r] > 0.f;
-            }
-            const long nid = min((long)gsum, (long)kk);      // tp[:min(int(n), k)].sum()   (metrics.py:146)
-            for (long r = 0; r < nid; ++r) idcg += 1.0 / log2((double)(r + 2));
+        dcg = block_sum_f64(dcg);
+        idcg = block_sum_f64(idcg);
+        hits = block_sum_f64(hits);
+        if (tid == 0) {
             if (a.ndcg) a.ndcg[(size_t)q * a.B + b] = dcg / idcg;
-            if (a.recall) a.recall[(size_t)q * a.B + b] = (double)(float)hits / (double)min((long)kk, npos);   // metrics.py:194-195
+            if (a.recall) a.recall[(size_t)q * a.B + b] = (double)(float)hits / (double)min((long)min(a.ks[q], a.n_items), npos);   // metrics.py:194-195
         }
     }
 }
