@@ -97,3 +97,26 @@ def test_mfma_utilisation_and_hbm_json_from_the_pmc_passes(tmp_path):
     table.write_text(_run(rs.pmc, db))
     out = [ln for ln in _run(rs.mfma, str(table)).splitlines() if ln.startswith("void rtx_gemm_nt")]
     assert len(out) == 1 and abs(float(out[0].split()[-1]) - 0.25) < 1e-4 and abs(float(out[0].split()[-2]) - 0.25) < 1e-4
+
+
+def test_dw_stamps_groups_tiles_by_hardware_slot(tmp_path):
+    """tools/dw_stamps.py on a hand-made stamp file ([workgroup][8] u64, 100-MHz ticks): two hardware slots, three tiles each,
+    2-us gaps -- the report must find the slots, the gaps and the phase means (round 4's probe of the weight-gradient kernel)"""
+    import subprocess
+    import numpy as np
+    rows = []
+    for slot in range(2):
+        t = 1000 + slot * 37
+        for tile in range(3):
+            st = t
+            marks = [st, st + 400, st + 700, st + 1200, st + 1300, st + 1800, st + 1900]    # issue 4, first 3, walk 5, park 1, adam 5, ack 1 us
+            rows.append(marks + [(slot << 32) | (0x100 * slot + 3)])                       # XCC_ID << 32 | HW_ID
+            t = marks[-1] + 200                                                              # 2 us until the slot's next tile
+    rows.append([0] * 8)                                                                     # a padding workgroup: no stamps
+    path = str(tmp_path / "stamps_0.bin")
+    np.array(rows, dtype=np.uint64).tofile(path)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dw_stamps.py"), path], capture_output=True, text=True, check=True).stdout
+    assert "6 tiles" in out and "mean life 19.00 us" in out
+    assert "2 distinct slots; tiles per slot: min 3 max 3" in out
+    assert "n 4 mean 2.00" in out                                    # four gaps of 2 us
+    assert "issue 4.00 | first slice 3.00 | K walk 5.00 | park 1.00 | adam+stores 5.00 | store ack 1.00" in out
