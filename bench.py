@@ -336,24 +336,32 @@ def main():
                          "finite": bool(all(torch.isfinite(p).all().item() for p in net.parameters()))}
     # N > 1: the north star names the ALL-REDUCE schedule; the default is the sharded optimizer -- time the other one beside it
     replicated_ab = None
-    if world > 1 and args.sharded and not args.no_extras:
-        eng.dp_attach(None)
-        net_r, model_r = build_model(args, I, H, L, args.numerics)
-        plan_r = parallel.attach(model_r, fixed_global_batch=global_batch, sharded=False, engine=args.dp_engine, transport=args.dp_transport)
-        st_r, _, m_r, v_r = model_r._ensure_train_state()
-        net_r.rtx_engine(args.numerics, B, train_buffers=(st_r.grads, m_r, v_r)).set_option("sparse_in", int(args.first_layer == "sparse"))
+    if (world > 1 or args.force_dp) and not emu and args.sharded and not args.no_extras:
+        # (the first plan's communicator goes before the second comes up: never two live RCCL communicators in the process;
+        #  `--force-dp --sharded` runs this block with ONE real RCCL rank, which is how it is exercised on the one-GPU boxes)
+        if world > 1:
+            dist.barrier()
+        if hasattr(plan, "close"):
+            plan.close()
+        try:
+            net_r, model_r = build_model(args, I, H, L, args.numerics)
+            plan_r = parallel.attach(model_r, fixed_global_batch=global_batch, sharded=False, engine=args.dp_engine, transport=args.dp_transport)
+            st_r, _, m_r, v_r = model_r._ensure_train_state()
+            net_r.rtx_engine(args.numerics, B, train_buffers=(st_r.grads, m_r, v_r)).set_option("sparse_in", int(args.first_layer == "sparse"))
 
-        def run_r(n, start):
-            for i in range(n):
-                model_r._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
-        k_r = max(10, min(args.steps, 50))
-        run_r(5, 0)
-        w_r = timed_windows(run_r, k_r, 2, world, 5)
-        replicated_ab = {"ms_per_step": float(np.median(w_r)) / k_r * 1e3, "value": global_batch * k_r / float(np.median(w_r)), "unit": "users/s",
-                         "steps": k_r, "what": "the same job with all-reduce + the whole Adam update on every rank (--replicated)"}
-        if hasattr(plan_r, "close"):
-            plan_r.close()
-        del net_r, model_r
+            def run_r(n, start):
+                for i in range(n):
+                    model_r._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
+            k_r = max(10, min(args.steps, 50))
+            run_r(5, 0)
+            w_r = timed_windows(run_r, k_r, 2, world, 5)
+            replicated_ab = {"ms_per_step": float(np.median(w_r)) / k_r * 1e3, "value": global_batch * k_r / float(np.median(w_r)), "unit": "users/s",
+                             "steps": k_r, "what": "the same job with all-reduce + the whole Adam update on every rank (--replicated)"}
+            if hasattr(plan_r, "close"):
+                plan_r.close()
+            del net_r, model_r
+        except Exception as ex:                      # the headline line must survive a failure of the side measurement
+            replicated_ab = {"error": repr(ex)[:300]}
     if world > 1:
         dist.barrier()
     if plan is not None and hasattr(plan, "close"):
