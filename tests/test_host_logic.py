@@ -241,6 +241,22 @@ def test_checkpoint_layout_and_reference_checkpoint_loads():
 
 
 # ------------------------------------------------------------------ utilities
+def test_shard_batch_keeps_the_global_batch_size():
+    """parallel.shard_batch (round 4): a rank's slice of the resident sampler's batch remembers the global batch size, so the
+    data-parallel step needs no per-step all-reduce + host read for 1 / global batch; the slices partition the batch"""
+    from rectorch_amd.parallel import shard_batch
+    from rectorch_amd.engine import RowBatch
+    rows = torch.arange(100, 137, dtype=torch.int32)
+    rb = RowBatch("tr", "te", rows)
+    assert rb.global_len is None
+    got = []
+    for r in range(5):
+        sb = shard_batch(rb, r, 5)
+        assert sb.tr == "tr" and sb.te == "te" and sb.global_len == 37 and sb.rows.is_contiguous()
+        got.append(sb.rows)
+    assert torch.equal(torch.cat(got), rows) and max(len(g) for g in got) - min(len(g) for g in got) <= 1
+
+
 def test_shard_rows_partition():
     for n in (0, 1, 7, 500, 4096):
         for w in (1, 2, 3, 8):
