@@ -127,6 +127,7 @@ struct rtx_engine {
     // record / wait: -3 us per step in three alternating pairs (283.7 / 280.1 / 276.0 -> 280.1 / 276.8 / 273.2,
     // profiles/r4_hop_values.txt); where the device cannot wait on a value the events remain
     int opt_hop_values = 1;
+    int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
     uint32_t hop_seq = 0;
@@ -1212,6 +1213,19 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         g.splits = 1; g.C = e->grads[2 * li]; g.gbias = e->grads[2 * li + 1];
         if (dp && dp->cfg.comm_dtype == RTX_FP32) { g.C = xg32(2 * li); g.gbias = xg32(2 * li + 1); }
         g.M_real = l.out; g.N_real = l.in;
+        // A hidden layer's gradient is 10-20 tiles of 128 x 128 with K = the batch: one workgroup per tile walks 16 K slices at the
+        // f32 MFMA rate of ONE CU (1.7 us per slice) while 240 CUs idle -- 40 us per launch, 80 us of the 1.05-ms float32 step
+        // (profiles/r4_fp32_step_timeline.txt).  Such products are split over the batch into slabs and summed in a fixed order.
+        const int tiles = g.m_tiles * g.n_tiles;
+        int sp = std::min(8, g.k_slices / 2);
+        while (sp > 1 && (sp - 1) * ((g.k_slices + sp - 1) / sp) >= g.k_slices) --sp;   // no empty split
+        if (e->opt_f32_dw_split && tiles <= 64 && sp >= 2 && (size_t)sp * l.outp * l.inp <= e->cacc_elems) {
+            float* gW = g.C;
+            float* gb = g.gbias;
+            g.splits = sp; g.C = e->Cacc; g.ldc = l.inp; g.slab_stride = (long)l.outp * l.inp; g.gbias = nullptr;
+            RTX_TRY(rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, ws));
+            return rtx_launch_dw_slab_reduce(e->Cacc, sp, g.slab_stride, g.ldc, l.out, l.in, gW, gb, ws);
+        }
         return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
     };
     // ---- data parallel: exchange + optimizer of layers [l_lo, l_hi) on stream ws; `alt`: the big matrices' Adam writes the NEXT
@@ -1745,6 +1759,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
     else if (k == "hop_values") e->opt_hop_values = value != 0;
+    else if (k == "f32_dw_split") e->opt_f32_dw_split = value != 0;
     else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
     else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
     else if (k == "dp_shard_min_elems") {

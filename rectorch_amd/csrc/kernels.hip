@@ -1308,6 +1308,32 @@ __global__ __launch_bounds__(256) void k_cast_f32_bf16(const float* __restrict__
     }
 }
 
+// Split-K slabs of a small weight-gradient product -> the gradient tensors (float32 parity mode, round 4):
+//   gW[m * N_real + n] = sum_s C[s * slab_stride + m * ldc + n]  (m < M_real, n < N_real);  gbias[m] = the same at n == N_real.
+// Fixed summation order (s ascending): the step stays bit-reproducible.
+__global__ __launch_bounds__(256) void k_dw_slab_reduce(const float* __restrict__ C, int splits, long slab_stride, long ldc, int M_real, int N_real,
+                                                        float* __restrict__ gW, float* __restrict__ gbias)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)M_real * (N_real + 1);
+    if (i >= total) return;
+    const int m = (int)(i / (N_real + 1)), n = (int)(i - (long)m * (N_real + 1));
+    const float* c = C + (size_t)m * ldc + n;
+    float v = 0.f;
+    for (int s2 = 0; s2 < splits; ++s2) v += c[(size_t)s2 * slab_stride];
+    if (n < N_real) gW[(size_t)m * N_real + n] = v;
+    else if (gbias) gbias[m] = v;
+}
+
+int rtx_launch_dw_slab_reduce(const float* C, int splits, long slab_stride, long ldc, int M_real, int N_real, float* gW, float* gbias, hipStream_t stream)
+{
+    const long total = (long)M_real * (N_real + 1);
+    if (total <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_dw_slab_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, C, splits, slab_stride, ldc, M_real, N_real, gW, gbias);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
 int rtx_launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream)
 {
     if (n <= 0) return RTX_OK;
