@@ -327,7 +327,10 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * small_layers.hip -- for padded widths <= 1024), "logits16" (0/1, bf16 training step: the logits leave their product as IEEE half
  * in the buffer of d loss / d logits and the loss kernel converts them in place), "gather_scatter" (0/1: the dense batch image stays
  * all-zero between batches and only the stored entries are cleared / written -- resident CSR batches), "dp_shard_min_elems" (>= 1, before
- * rtx_engine_dp_attach: smallest weight matrix the sharded optimizer shards; default 2^20 elements).
+ * rtx_engine_dp_attach: smallest weight matrix the sharded optimizer shards; default 2^20 elements), "hop_values" (0/1: the step's
+ * two cross-stream dependencies as hipStreamWriteValue32 / hipStreamWaitValue32 pairs on signal memory instead of events; falls
+ * back to events where the device cannot wait on a value), "hop_wrap" (>= 2: the sequence number at which both streams drain and
+ * the signal words restart from zero; default 2^31 - 16, tests lower it).
  * Replaces round 1's RTX_* environment switches. */
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value);
 /* the current value of a knob; also "last_sparse_in": 1 when the last forward pass ran the first layer as the sparse product;

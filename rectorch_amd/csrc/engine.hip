@@ -131,6 +131,7 @@ struct rtx_engine {
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
     uint32_t hop_seq = 0;
+    uint32_t hop_wrap = 0x7ffffff0u;   // the sequence restarts from zero here (option "hop_wrap": tests lower it)
     // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
     int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
     int opt_dw_cfg = RTX_DW_64x128;
@@ -1060,6 +1061,14 @@ static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hi
             }
         }
         if (e->hop_mem) {
+            // two numbers per step: 2^31 is reached after ~80 hours of 270-us steps.  Before the sequence gets there (whether the
+            // device compares signed or unsigned) both streams drain and the words start again from zero.
+            if (e->hop_seq >= e->hop_wrap) {
+                RTX_HIP(hipStreamSynchronize(from));
+                RTX_HIP(hipStreamSynchronize(to));
+                RTX_HIP(hipMemset(e->hop_mem, 0, 64));
+                e->hop_seq = 0;
+            }
             const uint32_t v = ++e->hop_seq;
             RTX_HIP(hipStreamWriteValue32(from, e->hop_mem + slot, v, 0));
             RTX_HIP(hipStreamWaitValue32(to, e->hop_mem + slot, v, hipStreamWaitValueGte, 0xffffffffu));
@@ -1759,6 +1768,10 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
     else if (k == "hop_values") e->opt_hop_values = value != 0;
+    else if (k == "hop_wrap") {
+        RTX_CHECK(value >= 2, RTX_EINVAL, "set_option: hop_wrap must be >= 2");
+        e->hop_wrap = (uint32_t)value;
+    }
     else if (k == "f32_dw_split") e->opt_f32_dw_split = value != 0;
     else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
     else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
