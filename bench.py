@@ -241,11 +241,6 @@ def main():
     rccl_ranks = None
     dp = world > 1 or args.force_dp or emu > 0
     plan = None
-    if emu and os.environ.get("RTX_PROBE_INIT_PG"):      # experiment: a live nccl process group that the step never uses
-        import tempfile
-        dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="rtx_pg_"), "store"), rank=0, world_size=1)
-        _p = torch.ones(1, device="cuda")
-        dist.all_reduce(_p)
     if emu:
         # rank 0 of an emu-rank job on this one GPU: weak scaling keeps --batch users here, strong scaling --batch / emu
         if args.scaling == "strong":
@@ -257,9 +252,6 @@ def main():
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)                                 # an actual RCCL collective: the line is self-checking
         rccl_ranks = int(round(float(probe.item())))
-        if os.environ.get("RTX_PROBE_IDLE_COMM"):          # experiment: an RCCL communicator that is never used
-            from rectorch_amd.parallel import NativePlan
-            _idle = NativePlan(rank, world, False, torch.bfloat16, None, "rccl")
         plan = parallel.attach(model, fixed_global_batch=global_batch, sharded=args.sharded, engine=args.dp_engine, transport=args.dp_transport)
     # resident sampler over the global batch; each rank takes its slice of every global batch
     np.random.seed(20240927)
