@@ -680,6 +680,79 @@ static int run_dw_cases()
     return fails;
 }
 
+// ---- "mfmaclk": what the matrix pipes deliver from registers alone, and the shader clock they run at (round 4) -----------------
+// Every wave issues independent-accumulator MFMAs with register operands for a few hundred microseconds: no LDS, no memory.  Per
+// workgroup: shader-clock cycles and the 100-MHz real-time counter across the loop -> the clock under sustained matrix load; from
+// HIP events around the launch: the TFLOP/s a perfect kernel could reach on THIS device (the denominator behind every
+// "fraction of the MFMA peak" in DESIGN.md).
+typedef __attribute__((ext_vector_type(16))) float tg_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 tg_bf16x8;
+template <int F32>
+__global__ __launch_bounds__(256) void k_mfma_clock(unsigned long long* out, int iters, float seed)
+{
+    tg_f32x16 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+    const float a = seed * (float)(threadIdx.x & 7), b = seed * 0.5f;
+    tg_bf16x8 a8, b8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a8[e] = (__bf16)a; b8[e] = (__bf16)b; }
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (F32) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+            else acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[u & 3], 0, 0, 0);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[u][e];
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = c1 - c0; out[blockIdx.x * 2 + 1] = r1 - r0; }
+    if (sum == 12345.678f) out[0] = 0;   // (keeps the accumulators alive)
+}
+
+static void mfma_clock(int f32, int wgs_per_cu, int cus)
+{
+    const int wgs = wgs_per_cu * cus, iters = f32 ? 400 : 800;
+    unsigned long long* dst;
+    CK(hipMalloc(&dst, (size_t)wgs * 16));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {   // the last of three back-to-back launches is reported (clocks settle)
+        CK(hipEventRecord(e0));
+        if (f32) hipLaunchKernelGGL(k_mfma_clock<1>, dim3(wgs), dim3(256), 0, 0, dst, iters, 1e-3f);
+        else hipLaunchKernelGGL(k_mfma_clock<0>, dim3(wgs), dim3(256), 0, 0, dst, iters, 1e-3f);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<unsigned long long> h((size_t)wgs * 2);
+    CK(hipMemcpy(h.data(), dst, h.size() * 8, hipMemcpyDeviceToHost));
+    double lo = 1e9, hi = 0, mean = 0;
+    for (int w = 0; w < wgs; ++w) {
+        const double ghz = (double)h[w * 2] / ((double)h[w * 2 + 1] * 10.0);
+        lo = std::min(lo, ghz); hi = std::max(hi, ghz); mean += ghz / wgs;
+    }
+    const double flop_per_mfma = f32 ? 32.0 * 32 * 2 * 2 : 32.0 * 32 * 16 * 2;
+    const double flops = (double)wgs * 4 * iters * 16 * flop_per_mfma;
+    const double cyc_per_mfma = 0.0;
+    (void)cyc_per_mfma;
+    double mc = 0;
+    for (int w = 0; w < wgs; ++w) mc += (double)h[w * 2] / wgs;
+    printf("mfmaclk %s  %d workgroup(s)/CU x 4 waves: %.1f us, %.1f TFLOP/s (%.3f of the %s peak); shader clock under load %.3f GHz (min %.3f, max %.3f); "
+           "%.1f cycles per MFMA and wave\n", f32 ? "f32 32x32x2 " : "bf16 32x32x16", wgs_per_cu, ms * 1e3, flops / (ms * 1e-3) * 1e-12,
+           flops / (ms * 1e-3) * 1e-12 / (f32 ? 157.3 : 2500.0), f32 ? "157.3-TF f32" : "2.5-PF bf16", mean, lo, hi, mc / ((double)iters * 16));
+    hipFree(dst);
+}
+
 int main(int argc, char** argv)
 {
     int fails = 0;
@@ -730,6 +803,11 @@ int main(int argc, char** argv)
             }
         }
         hipFree(dst);
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "mfmaclk")) {
+        for (int f32 : {1, 0})
+            for (int per_cu : {1, 2, 4}) mfma_clock(f32, per_cu, prop.multiProcessorCount);
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "chan")) {   // power-of-two row strides against odd multiples of 128 B (L2 channel spread)
