@@ -120,3 +120,21 @@ def test_dw_stamps_groups_tiles_by_hardware_slot(tmp_path):
     assert "2 distinct slots; tiles per slot: min 3 max 3" in out
     assert "n 4 mean 2.00" in out                                    # four gaps of 2 us
     assert "issue 4.00 | first slice 3.00 | K walk 5.00 | park 1.00 | adam+stores 5.00 | store ack 1.00" in out
+
+
+def test_bench_reports_committed_counters_only_for_the_profiled_kernel_source():
+    """bench.py's default run (no --pmc-json) takes roofline.traffic from the newest committed counter summary -- only while the
+    sha256 of the dominant kernel's source equals the one recorded with the counters; any other source: null."""
+    import hashlib
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "rectorch_amd", "csrc", "dw_adam.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    traffic, source = bench.committed_traffic(root)
+    if traffic is not None:            # the committed summary matches this source: it must be the file it names
+        pj = json.load(open(os.path.join(root, source["file"])))
+        assert pj["kernel_source_sha256"] == sha and pj["hbm_bytes_per_launch"] == traffic
+        # the ml-20m decoder / encoder launches: between the algorithmic 24 B/param and twice that
+        assert 24.0 * 20108 * 600 <= traffic <= 48.0 * 20108 * 600
+    assert bench.committed_traffic(root, sha="0" * 64) == (None, None)
