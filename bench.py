@@ -2,7 +2,9 @@
 """Headline benchmark: MultiVAE training users/sec on ml-20m-shaped synthetic data (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N > 1, either way:  python bench.py --gpus N ...   -- bench.py starts its N ranks itself (one process per visible GPU, rendezvous
+                        on 127.0.0.1 at a free port; rank 0 prints the line; any rank's failure is a non-zero exit with its stderr)
+                        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" is one MultiVAE.train_batch on one batch of users per GPU: sparse-row gather -> forward -> multinomial + beta-KL
 loss -> backward -> (RCCL exchange of the gradients when N > 1) -> Adam, through the same ``_fused_step`` that
@@ -16,7 +18,9 @@ Workloads (``--workload``):
 bf16 MFMA operands with f32 accumulation / f32 master weights + Adam, dropout 0.5, beta 0.2 annealed over 100 000 steps,
 lr 1e-3, inputs resident in HBM before the timed region.
 
-Timing: W warm-up steps, then ``--windows`` (default 3) windows of EXACTLY K steps, each bracketed by a barrier +
+Timing: an untimed PRE-HEAT (``--preheat-seconds``, default 0.4 s of steps: clocks, caches and the side stream settle -- the
+first 18 ms after start are 3-4 % slower than steady state, which is what short windows would otherwise measure), W warm-up
+steps, then ``--windows`` (default 3) windows of EXACTLY K steps, each bracketed by a barrier +
 ``torch.cuda.synchronize()`` on both sides and reduced with MAX over ranks; the line reports the MEDIAN window
 (median of >= 3 windows), all windows are listed.
 
@@ -50,6 +54,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200, help="steps per timed window")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps; the median is reported")
+    ap.add_argument("--preheat-seconds", type=float, default=0.4,
+                    help="untimed steps for about this long BEFORE the declared warm-up (0 = none): steady-state clocks for short windows")
     ap.add_argument("--workload", default="ml20m", choices=["ml20m", "netflix"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: --batch users per GPU; strong: --batch users in the GLOBAL batch (default: weak for ml20m, strong for netflix)")
@@ -164,22 +170,24 @@ def _flush_c_stdio():
 
 
 def committed_traffic(root, sha=None):
-    """(hbm_bytes_per_launch, source) from the newest ``profiles/r*_pmc_summary.json`` whose ``kernel_source_sha256`` equals the
-    sha256 of the dominant kernel's source as it is NOW (``sha`` overrides the file's hash: tests), else (None, None)."""
+    """(hbm_bytes_per_launch, source) from the newest ``profiles/r*_pmc_summary.json`` whose ``launch_sources_sha256`` equals the
+    sha256 over EVERY source that shapes the dominant launch as they are NOW (tools/launch_hash.py: the kernel, the engine that
+    picks its tile / grouping / streams, their headers; ``sha`` overrides it: tests), else (None, None).  The caller uses it for
+    the default configuration only (no --opt knob, default first layer)."""
     import glob
-    import hashlib
-    src = os.path.join(root, "rectorch_amd", "csrc", "dw_adam.hip")
+    from tools.launch_hash import launch_sources_sha, LAUNCH_SOURCES
     if sha is None:
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+        sha = launch_sources_sha(root)
     for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
             pj = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if sha and pj.get("kernel_source_sha256") == sha and pj.get("hbm_bytes_per_launch"):
+        if sha and pj.get("launch_sources_sha256") == sha and pj.get("hbm_bytes_per_launch") and not pj.get("bench_opts"):
             return pj["hbm_bytes_per_launch"], {"file": os.path.relpath(f, root), "git": pj.get("git"),
-                                                "kind": "committed counters of a companion run (tools/pmc_bench.sh); "
-                                                        + pj.get("kernel_source", "kernel source") + " unchanged since (sha256 match)"}
+                                                "kind": "committed counters of a companion run (tools/pmc_bench.sh) of the default "
+                                                        "configuration; " + ", ".join(os.path.basename(x) for x in LAUNCH_SOURCES)
+                                                        + " unchanged since (sha256 match)"}
     return None, None
 
 
@@ -223,11 +231,72 @@ def timed_windows(run, steps, windows, world, start):
     return out
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks (this script again, one process per visible GPU, the
+    environment ``python -m torch.distributed.run`` would export, rendezvous on 127.0.0.1 at a free port), pass rank 0's stdout
+    through (the ONE JSON line), keep every rank's stderr, and exit non-zero with the failing rank's stderr as soon as one fails."""
+    import socket
+    import subprocess
+    import tempfile
+    gloo = os.environ.get("RTX_DIST_BACKEND") == "gloo"      # tests: the ranks share one GPU
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (n_dev < n and not gloo):
+        sys.stderr.write("bench.py --gpus %d: %d HIP device(s) visible; one MI355X per rank is needed "
+                         "(RTX_DIST_BACKEND=gloo lets the ranks share a device: functional tests only)\n" % (n, n_dev))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs, logs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RTX_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        log = tempfile.TemporaryFile(mode="w+")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else log, stderr=log))
+    failed = None
+    try:
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() is not None and p.returncode != 0:
+                    failed = r
+                    break
+            time.sleep(0.05)
+        if failed is None:
+            failed = next((r for r, p in enumerate(procs) if p.returncode != 0), None)
+        if failed is not None:
+            t_end = time.time() + 5.0           # the peers of a failed rank block in a collective: give them a moment, then stop them
+            while time.time() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+    finally:
+        for p in procs:                         # (exactly the processes started above)
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    def tail(r, limit=6000):
+        logs[r].seek(0)
+        return logs[r].read()[-limit:]
+    if failed is not None:
+        sys.stderr.write("bench.py --gpus %d: rank %d exited with code %s; its output:\n%s\n" % (n, failed, procs[failed].returncode, tail(failed)))
+        return procs[failed].returncode if procs[failed].returncode and procs[failed].returncode > 0 else 1
+    sys.stderr.write(tail(0))                   # rank 0's warnings (RCCL's informational lines) stay visible, after the result
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     from rectorch_amd import parallel
     rank, world, local = parallel.init_from_env()
-    assert world == args.gpus, "launch with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: under a launcher, start --nproc-per-node %d" % (world, args.gpus, args.gpus)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: an MI355X is required"
     import torch.distributed as dist
     from rectorch_amd.utils import synth_interactions
@@ -296,6 +365,23 @@ def main():
     for kv in args.opt:                                 # measurement knobs (rtx_engine_set_option), e.g. --opt two_stream=0
         k, v = kv.split("=")
         eng0.set_option(k, int(v))
+    # pre-heat: untimed steps for ~preheat_seconds.  Every rank runs the SAME number of steps (a data-parallel step is a
+    # collective): the count comes from a short probe whose duration is max-reduced over the ranks.
+    preheat_steps = 0
+    if args.preheat_seconds > 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(4, 0)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / 4
+        if world > 1:
+            t = torch.tensor([per], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            per = float(t.item())
+        # (the probe's 4 steps include one-off costs -- the first step builds the side stream -- so the count is a lower bound)
+        preheat_steps = int(min(4000, max(0, args.preheat_seconds / max(per, 1e-6))))
+        run(preheat_steps, 4)
+        preheat_steps += 4
     run(args.warmup, 0)
     torch.cuda.synchronize()
     _flush_c_stdio()
@@ -310,7 +396,7 @@ def main():
     wins = timed_windows(run, args.steps, args.windows, world, args.warmup)
     timings = eng.get_timings()
     eng.set_timing(None, False)
-    n_steps_total = args.warmup + args.steps * args.windows
+    n_steps_total = preheat_steps + args.warmup + args.steps * args.windows
     loss_mean = model._read_loss_sum() / n_steps_total
 
     comm = None
@@ -420,7 +506,8 @@ def main():
         # run of the same build, named here -- never a constant
         pj = json.load(open(args.pmc_json))
         traffic, traffic_src = pj.get("hbm_bytes_per_launch"), {"file": os.path.relpath(args.pmc_json, ROOT), "git": pj.get("git")}
-    elif not dp and args.numerics == "bf16" and args.workload == "ml20m" and B == 500 and I == 20108:
+    elif (not dp and args.numerics == "bf16" and args.workload == "ml20m" and B == 500 and I == 20108 and not args.opt
+          and args.first_layer == "dense" and not Cd):
         # no counter file given (the driver's run): the newest committed counter summary of THIS shape counts only while the
         # dominant kernel's source is byte-for-byte what was profiled (its sha256 travels in the summary); otherwise null
         traffic, traffic_src = committed_traffic(ROOT)
@@ -449,6 +536,8 @@ def main():
                    "numerics": "bf16 MFMA operands, f32 accumulate, f32 master weights + Adam" if args.numerics == "bf16"
                                else "f32 MFMA (parity mode)"},
         "windows": {"n": args.windows, "steps_each": args.steps, "seconds": wins, "reported": "median"},
+        "preheat": {"steps": preheat_steps, "seconds_asked": args.preheat_seconds,
+                    "what": "untimed steps before the declared warm-up (steady-state clocks); not part of any timed window"},
         "rccl_ranks": rccl_ranks,
         "comm": comm,
         "replica_check": replica_check,

@@ -218,6 +218,15 @@ typedef struct {
     int32_t emulate;       /* 1: no communicator, device copies of the same size (timing of rank 0's step on one GPU) */
     rtx_comm* comm;        /* RCCL communicator, or NULL when ops / emulate is given */
     const rtx_dp_ops* ops; /* caller-supplied collectives (copied), or NULL */
+    /* ABI 7: the collectives of bucket A (the decoder matrix, issued on the engine's SIDE stream beside the data-gradient
+     * chain) go through a communicator / function table of their own, so that RCCL's per-communicator serialisation cannot
+     * couple them with bucket B's collectives on the caller's stream (with ONE communicator used from two streams RCCL runs
+     * the operations in issue order: bucket B's reduce would wait for bucket A's all-gather).  NULL = bucket A shares
+     * comm / ops (the single-communicator schedule of ABI 5-6).  Every rank must make the same choice. */
+    rtx_comm* comm_side;        /* second RCCL communicator of the same ranks (rtx_comm_init with a second id), or NULL */
+    const rtx_dp_ops* ops_side; /* caller-supplied collectives for the side stream (copied), or NULL */
+    int32_t shard_min_elems;    /* sharded = 1: weight matrices of at least this many elements are sharded; 0 = the engine's
+                                 * default (2^20, or what the option "dp_shard_min_elems" says) */
 } rtx_dp_cfg;
 int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg /* NULL detaches */);
 int rtx_engine_train_step_dp(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
@@ -228,6 +237,13 @@ int rtx_engine_dp_owned_rows(const rtx_engine* e, int32_t layer, int32_t* row_lo
 
 /* float32 -> bfloat16 (round to nearest even) of n contiguous elements: stages a gradient bucket for a bf16 all-reduce */
 int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+/* ABI 7 -- THIS step's loss without draining the stream (the reference's train_batch ends in `return loss.item()`,
+ * models.py:835).  With the mailbox enabled the loss reduction of every training step ALSO stores {loss, step->step} into
+ * coherent host memory owned by the engine; rtx_engine_wait_loss(step) spins on the host until the mailbox carries that step
+ * count and returns its loss: the kernels behind the loss (weight gradients, Adam) keep running and the host can enqueue the next
+ * step under them.  timeout_s <= 0: 60 s.  Steps must be waited for in order (the mailbox holds the LAST step's loss). */
+int rtx_engine_loss_mailbox(rtx_engine* e, int32_t enable);
+int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double timeout_s);
 /* both of the above: one full train_batch */
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out,
                           float* loss_accum, void* stream);

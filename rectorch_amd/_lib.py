@@ -68,7 +68,8 @@ class DpOps(C.Structure):
 
 class DpCfg(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("sharded", C.c_int32), ("comm_dtype", C.c_int32),
-                ("emulate", C.c_int32), ("comm", C.c_void_p), ("ops", C.POINTER(DpOps))]
+                ("emulate", C.c_int32), ("comm", C.c_void_p), ("ops", C.POINTER(DpOps)),
+                ("comm_side", C.c_void_p), ("ops_side", C.POINTER(DpOps)), ("shard_min_elems", C.c_int32)]
 
 
 # every symbol include/rectorch_hip.h declares: name -> (restype, argtypes)
@@ -110,6 +111,8 @@ SIGNATURES = {
     "rtx_engine_dp_owned_rows": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
+    "rtx_engine_loss_mailbox": (C.c_int, [_P, C.c_int32]),
+    "rtx_engine_wait_loss": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_double]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "rtx_sum_l2_norms": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rtx_topk_metrics": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P]),

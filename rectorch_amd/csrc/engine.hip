@@ -23,7 +23,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -66,7 +68,9 @@ struct TempCsr {  // dense batch converted to CSR on the device
 struct DpState {
     bool on = false;
     rtx_dp_cfg cfg = {};
-    rtx_dp_ops ops = {};
+    rtx_dp_ops ops = {};                      // bucket B (and everything on ONE stream): the caller's stream
+    rtx_dp_ops ops_side = {};                 // bucket A on the side stream: a communicator of its own when the plan brings one (ABI 7)
+    bool two_comms = false;                   // ops_side is a different communicator / table than ops
     void* xg = nullptr;                       // exchange buffer, comm dtype
     size_t xbytes = 0, xesz = 4;
     size_t xoff[2 * 2 * RTX_MAX_LAYERS] = {};   // element offset of tensor t
@@ -138,6 +142,8 @@ struct rtx_engine {
     int opt_dp_shard_min_elems = 1 << 20;   // sharded optimizer: weight matrices of at least this many elements are reduce-scattered /
                                 //   updated by rows / all-gathered, smaller ones all-reduced and replicated (tests lower it so that
                                 //   small golden networks exercise the sharded path with real data)
+    uint32_t* loss_mailbox = nullptr;   // coherent host memory {loss bits, sequence}: rtx_engine_loss_mailbox / rtx_engine_wait_loss
+    int opt_dp_one_comm = 0;    // 1: bucket A shares bucket B's communicator even when the plan brings a second one (ABI 5-6 schedule; A/B knob)
     int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
     int opt_logits16 = 1;       // bf16 training step: the logits leave their product as IEEE half, written where d loss / d logits
@@ -689,7 +695,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 6; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step); 6: rtx_svae_set_option
+int32_t rtx_abi_version(void) { return 7; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step); 6: rtx_svae_set_option; 7: rtx_dp_cfg.comm_side / ops_side / shard_min_elems (bucket A's own communicator), rtx_engine_loss_mailbox / rtx_engine_wait_loss
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -821,6 +827,7 @@ int rtx_engine_destroy(rtx_engine* e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->hop_mem) (void)hipFree(e->hop_mem);
+    if (e->loss_mailbox) (void)hipHostFree(e->loss_mailbox);
     for (auto& kv : e->side_cache)
         if (kv.second.first) (void)hipStreamDestroy(kv.second.first);
     delete e;
@@ -1162,7 +1169,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         ScopedTimer tm(e, "reduce_loss", ws);
         const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);
         return rtx_launch_reduce_loss(e->row_loss, B * rtx_dlogits_chunks(e->Ip), step->lam, reg_in_loss ? e->sumsq : nullptr, 2 * NL, loss_out,
-                                      loss_accum, ws);
+                                      loss_accum, ws, e->loss_mailbox, (uint32_t)step->step);
     };
     // weight + bias gradient of layer li on stream ws: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column
     // `in` of the product (the ones column of A) is the bias gradient
@@ -1242,6 +1249,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     auto dp_bucket = [&](int l_lo, int l_hi, hipStream_t ws, bool alt) -> int {
         DpState& d = *dp;
         const int cdt = d.cfg.comm_dtype;
+        // the side stream's bucket talks through its own communicator: RCCL orders the operations of ONE communicator in issue
+        // order across streams, which would make bucket B's reduce (caller's stream) wait for bucket A's all-gather
+        const rtx_dp_ops& O = (ws == e->side && two) ? d.ops_side : d.ops;
         int order[2 * 2 * RTX_MAX_LAYERS];
         const int n_order = dp_layout_order(e, order);
         auto in_bucket = [&](int t) { return t / 2 >= l_lo && t / 2 < l_hi; };
@@ -1259,12 +1269,12 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         //     collective of the communicator) and marks the plan unusable until it is attached again.
         {
             ScopedTimer tm(e, ws == e->side && two ? "dp_exchange_side" : "dp_exchange_main", ws);
-            if (d.ops.group_start) RTX_CHECK(d.ops.group_start(d.ops.ctx) == 0, RTX_EHIP, "data parallel: group_start failed: %s", rtx_last_error_str());
+            if (O.group_start) RTX_CHECK(O.group_start(O.ctx) == 0, RTX_EHIP, "data parallel: group_start failed: %s", rtx_last_error_str());
             auto in_group = [&]() -> int {
                 long run_lo = -1, run_hi = -1;
                 auto flush = [&]() -> int {
                     if (run_lo >= 0 && run_hi > run_lo) {
-                        RTX_CHECK(d.ops.all_reduce(d.ops.ctx, (char*)d.xg + (size_t)run_lo * d.xesz, run_hi - run_lo, cdt, ws) == 0, RTX_EHIP,
+                        RTX_CHECK(O.all_reduce(O.ctx, (char*)d.xg + (size_t)run_lo * d.xesz, run_hi - run_lo, cdt, ws) == 0, RTX_EHIP,
                                   "data parallel: all_reduce failed: %s", rtx_last_error_str());
                         d.st_all_reduce += (int64_t)(run_hi - run_lo) * (int64_t)d.xesz;
                         d.st_collectives += 1;
@@ -1278,7 +1288,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
                     if (!in_bucket(t) || sharded_w) {
                         RTX_TRY(flush());
                         if (in_bucket(t)) {
-                            RTX_CHECK(d.ops.reduce_scatter(d.ops.ctx, (char*)d.xg + d.xoff[t] * d.xesz, (int64_t)dp_region_elems(e, d, t), cdt, ws) == 0,
+                            RTX_CHECK(O.reduce_scatter(O.ctx, (char*)d.xg + d.xoff[t] * d.xesz, (int64_t)dp_region_elems(e, d, t), cdt, ws) == 0,
                                       RTX_EHIP, "data parallel: reduce_scatter failed: %s", rtx_last_error_str());
                             d.st_reduce_scatter += (int64_t)dp_region_elems(e, d, t) * (int64_t)d.xesz;
                             d.st_collectives += 1;
@@ -1294,10 +1304,10 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             if (rc != RTX_OK) {
                 d.broken = true;
                 std::string msg = rtx_last_error_str();           // group_end may overwrite the thread's error slot
-                if (d.ops.group_end) (void)d.ops.group_end(d.ops.ctx);
+                if (O.group_end) (void)O.group_end(O.ctx);
                 RTX_CHECK(false, rc, "%s", msg.c_str());
             }
-            if (d.ops.group_end && d.ops.group_end(d.ops.ctx) != 0) {
+            if (O.group_end && O.group_end(O.ctx) != 0) {
                 d.broken = true;
                 RTX_CHECK(false, RTX_EHIP, "data parallel: group_end failed: %s", rtx_last_error_str());
             }
@@ -1337,7 +1347,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             if (d.shard[li]) {
                 Layer& l = e->L[li];
                 ScopedTimer tm(e, ws == e->side && two ? "dp_allgather_side" : "dp_allgather_main", ws);
-                if (d.ops.all_gather(d.ops.ctx, (alt && l.Wsh_alt) ? l.Wsh_alt : l.Wsh, (int64_t)((size_t)l.outp * l.inp * e->esz), ws) != 0) {
+                if (O.all_gather(O.ctx, (alt && l.Wsh_alt) ? l.Wsh_alt : l.Wsh, (int64_t)((size_t)l.outp * l.inp * e->esz), ws) != 0) {
                     d.broken = true;
                     RTX_CHECK(false, RTX_EHIP, "data parallel: all_gather failed: %s", rtx_last_error_str());
                 }
@@ -1694,12 +1704,30 @@ int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
         d.ops = *cfg->ops;
     }
     d.cfg.ops = nullptr;
+    // bucket A's table: a second communicator / function table when the plan brings one, else the same as bucket B's
+    d.ops_side = d.ops;
+    d.two_comms = false;
+    if (!cfg->emulate && cfg->comm && cfg->comm_side && !e->opt_dp_one_comm) {
+        int32_t r = -1, w = -1;
+        RTX_TRY(rtx_comm_rank(cfg->comm_side, &r, &w));
+        RTX_CHECK(r == cfg->rank && w == cfg->world, RTX_EINVAL, "dp_attach: comm_side is rank %d of %d, the plan says %d of %d", r, w, cfg->rank, cfg->world);
+        RTX_CHECK(cfg->comm_side != cfg->comm, RTX_EINVAL, "dp_attach: comm_side must be a communicator of its own (or NULL)");
+        d.ops_side.ctx = cfg->comm_side;
+        d.two_comms = true;
+    } else if (!cfg->emulate && cfg->ops && cfg->ops_side && !e->opt_dp_one_comm) {
+        RTX_CHECK(cfg->ops_side->all_reduce && cfg->ops_side->reduce_scatter && cfg->ops_side->all_gather, RTX_EINVAL,
+                  "dp_attach: ops_side needs all_reduce, reduce_scatter and all_gather");
+        d.ops_side = *cfg->ops_side;
+        d.two_comms = true;
+    }
+    d.cfg.ops_side = nullptr;
     d.xesz = cfg->comm_dtype == RTX_BF16 ? 2 : 4;
     size_t biggest = 0;
     for (int li = 0; li < e->NL; ++li) {
         const Layer& l = e->L[li];
         // a hidden layer that keeps a transposed compute copy (WshT) is never sharded: that copy is a column-block layout
-        d.shard[li] = cfg->sharded && (long)l.out * l.in >= (long)e->opt_dp_shard_min_elems && !l.WshT && l.outp % cfg->world == 0;
+        const long min_elems = cfg->shard_min_elems > 0 ? (long)cfg->shard_min_elems : (long)e->opt_dp_shard_min_elems;
+        d.shard[li] = cfg->sharded && (long)l.out * l.in >= min_elems && !l.WshT && l.outp % cfg->world == 0;
         biggest = std::max(biggest, (size_t)l.outp * l.inp * std::max(e->esz, d.xesz));
     }
     int order[2 * 2 * RTX_MAX_LAYERS];
@@ -1759,6 +1787,47 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
     return rtx_engine_apply_adam(e, step, stream);
 }
 
+// The reference's train_batch ends in `return loss.item()` (models.py:835): the host needs THIS step's loss.  Draining the stream
+// for it also waits for the weight-gradient + Adam kernels behind the loss (a third of the step) and leaves the GPU idle while
+// the host enqueues the next step.  With the mailbox on, the loss reduction of every training step also stores {loss, step count}
+// into coherent host memory (system-scope release), and rtx_engine_wait_loss spins on the step count: the float it returns is
+// this step's loss, the stream keeps running.
+int rtx_engine_loss_mailbox(rtx_engine* e, int32_t enable)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    if (enable && !e->loss_mailbox) {
+        void* p = nullptr;
+        RTX_HIP(hipHostMalloc(&p, 64, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(p, 0, 64);
+        e->loss_mailbox = (uint32_t*)p;
+    } else if (!enable && e->loss_mailbox) {
+        RTX_HIP(hipDeviceSynchronize());
+        (void)hipHostFree(e->loss_mailbox);
+        e->loss_mailbox = nullptr;
+    }
+    return RTX_OK;
+}
+
+int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double timeout_s)
+{
+    RTX_CHECK(e && loss_host, RTX_EINVAL, "wait_loss: NULL argument");
+    RTX_CHECK(e->loss_mailbox, RTX_ESTATE, "wait_loss: rtx_engine_loss_mailbox(e, 1) has not been called");
+    volatile uint32_t* mb = e->loss_mailbox;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (__atomic_load_n(&mb[1], __ATOMIC_ACQUIRE) == (uint32_t)step) break;
+        if ((spin & 0x3ff) == 0x3ff) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            RTX_CHECK(el < (timeout_s > 0 ? timeout_s : 60.0), RTX_EHIP, "wait_loss: step %d did not report its loss within %.1f s (mailbox holds step %u)",
+                      step, el, (unsigned)mb[1]);
+            if (el > 0.002) sched_yield();      // a long wait is a long kernel: stop burning the core
+        }
+    }
+    const uint32_t bits = __atomic_load_n(&mb[0], __ATOMIC_RELAXED);
+    memcpy(loss_host, &bits, 4);
+    return RTX_OK;
+}
+
 // measurement knobs: one entry point instead of environment variables scattered over the kernels' launchers
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
 {
@@ -1778,6 +1847,10 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "dp_shard_min_elems") {
         RTX_CHECK(!e->dp.on && value >= 1, RTX_ESTATE, "set_option: dp_shard_min_elems (>= 1) must be set before rtx_engine_dp_attach");
         e->opt_dp_shard_min_elems = value;
+    }
+    else if (k == "dp_one_comm") {
+        RTX_CHECK(!e->dp.on, RTX_ESTATE, "set_option: dp_one_comm must be set before rtx_engine_dp_attach");
+        e->opt_dp_one_comm = value != 0;
     }
     else if (k == "two_stream") e->opt_two_stream = value != 0;
     else if (k == "side_low_prio") {
@@ -1830,6 +1903,8 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "dp_bytes_reduce_scatter") *value = (int32_t)std::min<int64_t>(e->dp.st_reduce_scatter, INT32_MAX);
     else if (k == "dp_bytes_all_gather") *value = (int32_t)std::min<int64_t>(e->dp.st_all_gather, INT32_MAX);
     else if (k == "dp_collectives") *value = e->dp.st_collectives;
+    else if (k == "dp_one_comm") *value = e->opt_dp_one_comm;
+    else if (k == "dp_two_comms") *value = e->dp.on && e->dp.two_comms;   // bucket A's collectives have a communicator of their own
     else if (k == "two_stream") *value = e->opt_two_stream;
     else if (k == "side_low_prio") *value = e->opt_side_low_prio;
     else if (k == "nt_regstage") *value = e->opt_nt_regstage;

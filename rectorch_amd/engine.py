@@ -292,6 +292,18 @@ class Engine:
         check(lib().rtx_engine_train_step(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           stream_ptr()))
 
+    def loss_mailbox(self, enable=True):
+        """every training step also reports {loss, step count} to coherent host memory (``wait_loss``)"""
+        check(lib().rtx_engine_loss_mailbox(self.handle, int(bool(enable))))
+        self._mailbox = bool(enable)
+
+    def wait_loss(self, step_count, timeout_s=0.0):
+        """the loss of the training step whose Adam step count is ``step_count``: spins on the host mailbox, no stream drain
+        (reference models.py:835 ``return loss.item()``)"""
+        out = C.c_float()
+        check(lib().rtx_engine_wait_loss(self.handle, int(step_count), C.byref(out), float(timeout_s)))
+        return out.value
+
     # ---- data parallel, scheduled by the engine (rtx_engine_dp_attach / rtx_engine_train_step_dp) --------------------
     def dp_attach(self, plan):
         """``plan``: a :class:`rectorch_amd.parallel.NativePlan` (rank, world, sharded, comm dtype and ONE of an RCCL
@@ -302,10 +314,11 @@ class Engine:
             if old is not None and hasattr(old, "_forget"):
                 old._forget(self)
             return
-        cfg = plan.c_cfg()
-        if getattr(plan, "shard_min_elems", None):
-            self.set_option("dp_shard_min_elems", int(plan.shard_min_elems))
-        check(lib().rtx_engine_dp_attach(self.handle, C.byref(cfg)))
+        cfg = plan.c_cfg()            # (the sharding threshold travels in the cfg: nothing of an earlier plan stays in the engine)
+        old = getattr(self, "_dp_plan", None)
+        check(lib().rtx_engine_dp_attach(self.handle, C.byref(cfg)))     # (the C side releases an earlier attachment first)
+        if old is not None and old is not plan and hasattr(old, "_forget"):
+            old._forget(self)         # the old plan's close() must not detach this engine from its new plan
         self._dp_plan = plan          # keeps the communicator / callback objects alive as long as the engine uses them
         # what the ENGINE decided to shard (a plan that asks for the sharded optimizer on a network of small matrices shards nothing)
         self._dp_any_sharded = any(self.dp_owned_rows(l)[2] for l in range(self.n_tensors // 2))

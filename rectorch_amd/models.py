@@ -176,6 +176,10 @@ class AETrainer(TorchNNTrainer):
         # reach HBM and p.grad is NOT refreshed; set True to also store them (4 B/param).  float32 numerics and the
         # data-parallel step always store them.
         self.keep_grads = False
+        # train_batch returns THIS step's loss as a float (reference models.py:835).  True: the float comes from the engine's host
+        # mailbox (rtx_engine_wait_loss: the host spins on a step count in coherent host memory while the step's remaining
+        # kernels keep running); False: ``loss.item()``, which drains the stream like the reference does.
+        self.loss_mailbox = True
         self._rtx = _RtxState()
 
     # ------------------------------------------------------------------------------------------ loss
@@ -305,6 +309,9 @@ class AETrainer(TorchNNTrainer):
                                # data parallel: the (rank-independent) DAE regulariser enters the summed loss once
                                (_lib.RTX_STEP_NO_REG_IN_LOSS if red is not None and red.rank != 0 else 0))
         loss_out, loss_acc = st.loss_buf[0:1], st.loss_buf[1:2]
+        mailbox = red is None and want_loss and self.loss_mailbox
+        if mailbox and not getattr(eng, "_mailbox", False):
+            eng.loss_mailbox(True)
         if red is None:
             eng.train_step(x, target, step, loss_out, loss_acc)
         elif native:
@@ -346,6 +353,10 @@ class AETrainer(TorchNNTrainer):
         if want_loss:
             if red is not None:
                 return red.reduce_scalar(st.loss_buf[0:1].clone())
+            if mailbox:
+                # THIS step's loss (reference models.py:835 `return loss.item()`) from the engine's host mailbox: the weight-gradient
+                # + Adam kernels behind the loss keep running while the host returns and enqueues the next step
+                return eng.wait_loss(st.adam_step)
             return st.loss_buf[0].item()       # the reference's per-step loss.item() sync
         return None
 

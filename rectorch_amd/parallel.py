@@ -30,7 +30,7 @@ backend: "nccl" (= RCCL on ROCm) for device tensors, "gloo" for the CPU tests of
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_rows", "GradAllReducer", "NativePlan", "init_from_env", "attach"]
+__all__ = ["shard_rows", "GradAllReducer", "NativePlan", "LocalGroup", "init_from_env", "attach"]
 
 
 def shard_rows(n_rows, rank, world):
@@ -307,32 +307,56 @@ class NativePlan:
     ``world`` would move and Adam on 1/world of the rows (``bench.py --emulate-world``: the HBM cost of a G-rank step on one GPU)."""
     native = True
 
-    def __init__(self, rank, world, sharded, comm_dtype, group=None, transport="rccl", shard_min_elems=None):
-        from . import _lib
+    def __init__(self, rank, world, sharded, comm_dtype, group=None, transport="rccl", shard_min_elems=None, two_comms=None):
+        import os
         import weakref
         self.rank, self.world, self.sharded, self.group, self.transport = int(rank), int(world), bool(sharded), group, transport
         self.comm_dtype = comm_dtype
         self.shard_min_elems = shard_min_elems     # None: the engine's default (2^20 elements); tests lower it
-        self.comm = None
-        self._ops = None
+        # bucket A (side stream) and bucket B (caller's stream) each get a communicator of their own: RCCL runs the operations of
+        # ONE communicator in issue order whatever their streams, which would make bucket B's reduce wait for bucket A's
+        # all-gather.  RTX_DP_ONE_COMM=1 (every rank alike) keeps the single-communicator schedule.
+        if two_comms is None:
+            two_comms = os.environ.get("RTX_DP_ONE_COMM", "0") != "1"
+        self.two_comms = bool(two_comms) and transport != "emulate"
+        self.comm = self.comm_side = None
+        self._ops = self._ops_side = None
+        self._side_group = None
         self.error = None
         self._engines = weakref.WeakSet()          # engines attached to this plan: close() detaches them first
         if transport == "rccl":
-            import ctypes as C
-            ident = [None]
-            if self.rank == 0:
-                buf = (C.c_uint8 * 128)()
-                _lib.check(_lib.lib().rtx_comm_unique_id(buf))
-                ident[0] = bytes(buf)
-            if self.world > 1:
-                dist.broadcast_object_list(ident, src=0, group=group)
-            h = C.c_void_p()
-            _lib.check(_lib.lib().rtx_comm_init((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world, C.byref(h)))
-            self.comm = h
+            self.comm = self._new_comm()
+            if self.two_comms:
+                self.comm_side = self._new_comm()
         elif transport == "torch":
-            self._ops = self._torch_ops()
+            self._ops = self._torch_ops(group)
+            if self.two_comms:
+                # (a collective call: every rank of `group` builds the side group, in the same order)
+                ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+                self._side_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+                self._ops_side = self._torch_ops(self._side_group)
+        elif transport == "local":
+            assert isinstance(group, LocalGroup), "transport 'local' needs a parallel.LocalGroup"
+            self._ops = group.ops(self, "main")
+            if self.two_comms:
+                self._ops_side = group.ops(self, "side")
         else:
             assert transport == "emulate", transport
+
+    def _new_comm(self):
+        """one RCCL communicator over the ranks of the plan (collective: rank 0 draws the id, torch.distributed carries it)"""
+        import ctypes as C
+        from . import _lib
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check(_lib.lib().rtx_comm_unique_id(buf))
+            ident[0] = bytes(buf)
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0, group=self.group)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().rtx_comm_init((C.c_uint8 * 128).from_buffer_copy(ident[0]), self.rank, self.world, C.byref(h)))
+        return h
 
     # -- the engine's view ---------------------------------------------------------------------------------------------
     def c_cfg(self):
@@ -345,13 +369,16 @@ class NativePlan:
         cfg.emulate = int(self.transport == "emulate")
         cfg.comm = self.comm
         cfg.ops = C.pointer(self._ops) if self._ops is not None else None
+        cfg.comm_side = self.comm_side
+        cfg.ops_side = C.pointer(self._ops_side) if self._ops_side is not None else None
+        cfg.shard_min_elems = int(self.shard_min_elems or 0)
         return cfg
 
-    def _torch_ops(self):
+    def _torch_ops(self, group):
         """rtx_dp_ops over torch.distributed: every call wraps the engine's buffer in a tensor and issues the collective on
         the stream the engine names"""
         from . import _lib
-        native = dist.get_backend(self.group) != "gloo"
+        native = dist.get_backend(group) != "gloo"
         dts = {_lib.RTX_FP32: torch.float32, _lib.RTX_BF16: torch.bfloat16}
 
         def guarded(fn):
@@ -383,26 +410,27 @@ class NativePlan:
         def all_reduce(_ctx, buf, n, dtype, stream):
             t = _alias(buf, n * (2 if dtype == _lib.RTX_BF16 else 4), dts[dtype])
             with on(stream):
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
         def reduce_scatter(_ctx, buf, n, dtype, stream):
             t = _alias(buf, n * (2 if dtype == _lib.RTX_BF16 else 4), dts[dtype])
             with on(stream):
                 if native:
                     per = n // self.world
-                    dist.reduce_scatter_tensor(t[self.rank * per:(self.rank + 1) * per], t, op=dist.ReduceOp.SUM, group=self.group)
+                    dist.reduce_scatter_tensor(t[self.rank * per:(self.rank + 1) * per], t, op=dist.ReduceOp.SUM, group=group)
                 else:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)     # gloo: block `rank` holds the sum, as asked
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)     # gloo: block `rank` holds the sum, as asked
 
         def all_gather(_ctx, buf, nbytes, stream):
             t = _alias(buf, nbytes, torch.uint8)
             with on(stream):
-                _all_gather_blocks(t, self.rank, self.world, self.group, native)
+                _all_gather_blocks(t, self.rank, self.world, group, native)
 
         ops = _lib.DpOps()
-        self._cbs = (_lib.DP_REDUCE_FN(guarded(all_reduce)), _lib.DP_REDUCE_FN(guarded(reduce_scatter)),
-                     _lib.DP_GATHER_FN(guarded(all_gather)))            # the engine calls these for as long as it is attached
-        ops.all_reduce, ops.reduce_scatter, ops.all_gather = self._cbs
+        cbs = (_lib.DP_REDUCE_FN(guarded(all_reduce)), _lib.DP_REDUCE_FN(guarded(reduce_scatter)),
+               _lib.DP_GATHER_FN(guarded(all_gather)))
+        self._cbs = getattr(self, "_cbs", ()) + cbs                   # the engine calls these for as long as it is attached
+        ops.all_reduce, ops.reduce_scatter, ops.all_gather = cbs
         return ops
 
     # -- the trainer's view (same small interface as GradAllReducer) -----------------------------------------------------
@@ -420,11 +448,15 @@ class NativePlan:
         ``attach(..., fixed_global_batch=)`` do): one blocking all-reduce + host read per step."""
         if self.world == 1 or self.transport == "emulate":
             return local_batch * (self.world if self.transport == "emulate" else 1)
+        if self.transport == "local":
+            return int(round(self.group.host_sum(self.rank, float(local_batch))))
         t = torch.tensor([float(local_batch)], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return int(round(t.item()))
 
     def reduce_scalar(self, t):
+        if self.transport == "local":
+            return self.group.host_sum(self.rank, float(t.item()))
         if self.world > 1 and self.transport != "emulate":
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
@@ -434,7 +466,8 @@ class NativePlan:
         rank.  COLLECTIVE: every rank must call it (checkpoints, ``state_dict()``, engines of another numerics mode)."""
         if self.transport == "emulate":
             return
-        native = dist.get_backend(self.group) != "gloo"
+        local = self.transport == "local"
+        native = (not local) and dist.get_backend(self.group) != "gloo"
         for layer in range(n_layers):
             lo, hi, sharded = eng.dp_owned_rows(layer)
             if not sharded:
@@ -447,29 +480,201 @@ class NativePlan:
                 if lo < hi:
                     buf[lo * cols:hi * cols].copy_(t.view(-1)[lo * cols:hi * cols])
                 assert lo == min(self.rank * per, rows)
-                _all_gather_blocks(buf, self.rank, self.world, self.group, native)
+                if local:
+                    self.group.host_all_gather_blocks(self.rank, buf)
+                else:
+                    _all_gather_blocks(buf, self.rank, self.world, self.group, native)
                 t.view(-1).copy_(buf[:rows * cols])
 
     def close(self):
         """detach the engines that use this plan, then destroy the engine's RCCL communicator (every rank, while its peers are
         still alive: before ``dist.destroy_process_group()`` / interpreter exit)."""
         for eng in list(getattr(self, "_engines", ())):
+            if getattr(eng, "_dp_plan", None) is not self:
+                continue                             # the engine has moved on to another plan: leave that one attached
             try:
                 eng.dp_attach(None)                  # no engine keeps a pointer to the communicator that goes now
             except Exception:
                 pass
-        h = getattr(self, "comm", None)
-        if h is not None and h.value:
+        for name in ("comm_side", "comm"):
+            h = getattr(self, name, None)
+            if h is not None and h.value:
+                try:
+                    from . import _lib
+                    torch.cuda.synchronize()
+                    _lib.lib().rtx_comm_destroy(h)
+                except Exception:
+                    pass
+            setattr(self, name, None)
+        sg = getattr(self, "_side_group", None)
+        if sg is not None:
             try:
-                from . import _lib
-                torch.cuda.synchronize()
-                _lib.lib().rtx_comm_destroy(h)
+                dist.destroy_process_group(sg)
             except Exception:
                 pass
-            self.comm = None
+            self._side_group = None
 
     # (no __del__: destroying an RCCL communicator from the garbage collector / at interpreter exit can block for ever once a
     #  peer rank has gone; a plan that was never closed leaks its communicator instead)
+
+
+class LocalGroup:
+    """``world`` ranks as THREADS of one process sharing one GPU, each with an engine and streams of its own: the transport of the
+    stream-ordering tests (``NativePlan(..., transport="local", group=LocalGroup(world))``).
+
+    What it is for: gloo (the other way to put several ranks on one GPU) stages device tensors through the host and needs the
+    DEVICE drained before and after every collective -- by construction it cannot see an ordering bug between the engine's
+    kernels and a collective, or between bucket A on the side stream and bucket B on the caller's.  Here a collective is device
+    work enqueued ON THE STREAM THE ENGINE NAMES, exactly like an RCCL kernel: the rank's buffer is copied to a staging slot
+    (stream-ordered after the kernels that produced it), the ranks meet on a HOST barrier that blocks threads, not the device,
+    and each rank's stream then waits for the peers' "staged" events and combines the slots in rank order (so every rank
+    computes bit-identical sums).  Nothing synchronises the device.  ``drain=True`` adds the device syncs around every collective
+    (the gloo discipline): the reference the non-draining run must equal bit for bit.
+    Each stream role ("main" / "side") is a channel with slots and events of its own, like the two RCCL communicators."""
+
+    def __init__(self, world, drain=False):
+        import threading
+        self.world, self.drain = int(world), bool(drain)
+        self.barrier = threading.Barrier(self.world)
+        self.lock = threading.Lock()
+        self.stage = {}        # (channel, rank) -> uint8 staging tensor
+        self.staged = {}       # (channel, rank) -> event: this rank's slot is written
+        self.consumed = {}     # (channel, rank) -> event: this rank has read every peer's slot
+        self.host = [None] * self.world
+        self.calls = 0
+        self._retired = []
+
+    # -- host-synchronous helpers (outside the step: parameter broadcast, loss sums, consolidate()) ------------------------------
+    def host_sum(self, rank, value):
+        self.host[rank] = value
+        self.barrier.wait()
+        s = sum(self.host[r] for r in range(self.world))     # rank order: the same float on every rank
+        self.barrier.wait()
+        return s
+
+    def host_broadcast(self, rank, tensors):
+        """rank 0's tensors replace every other rank's (what ``dist.broadcast`` does in ``attach``)"""
+        torch.cuda.synchronize()
+        if rank == 0:
+            self.host[0] = tensors
+        self.barrier.wait()
+        if rank != 0:
+            for dst, src in zip(tensors, self.host[0]):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+        self.barrier.wait()
+
+    def host_all_gather_blocks(self, rank, flat):
+        torch.cuda.synchronize()
+        self.host[rank] = flat
+        self.barrier.wait()
+        n = flat.numel() // self.world
+        for r in range(self.world):
+            if r != rank:
+                flat[r * n:(r + 1) * n].copy_(self.host[r][r * n:(r + 1) * n])
+        torch.cuda.synchronize()
+        self.barrier.wait()
+
+    # -- the engine's collectives ---------------------------------------------------------------------------------------------
+    def _slot(self, ch, rank, nbytes, device):
+        t = self.stage.get((ch, rank))
+        if t is None or t.numel() < nbytes:
+            if t is not None:
+                self._retired.append(t)          # a peer's stream may still read it: never handed back to the allocator
+            t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.stage[(ch, rank)] = t
+        return t
+
+    def _collective(self, ch, rank, t, stream, combine):
+        """``t``: this rank's buffer (a typed 1-D alias of the engine's memory); ``combine(slots)`` enqueues the result into ``t``
+        from the ranks' staged copies ``slots[r]`` (same dtype / length as ``t``)"""
+        W = self.world
+        if self.drain:
+            torch.cuda.synchronize()
+        st = torch.cuda.ExternalStream(int(stream or 0))
+        nbytes = t.numel() * t.element_size()
+        with torch.cuda.stream(st):
+            for r in range(W):                   # the peers have read my slot of the previous collective of this channel
+                ev = self.consumed.get((ch, r))
+                if ev is not None and r != rank:
+                    st.wait_event(ev)
+            with self.lock:
+                slot = self._slot(ch, rank, nbytes, t.device)
+            slot[:nbytes].view(t.dtype).copy_(t)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.staged[(ch, rank)] = ev
+        self.barrier.wait()                       # every rank's "staged" event exists (HOST rendezvous: the device keeps running)
+        with torch.cuda.stream(st):
+            for r in range(W):
+                if r != rank:
+                    st.wait_event(self.staged[(ch, r)])
+            combine([self.stage[(ch, r)][:nbytes].view(t.dtype) for r in range(W)])
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self.barrier.wait()                       # (nobody publishes a new "consumed" event while a peer may still read the old one)
+        self.consumed[(ch, rank)] = ev
+        self.barrier.wait()
+        if self.drain:
+            torch.cuda.synchronize()
+        if rank == 0:
+            self.calls += 1
+
+    def ops(self, plan, channel):
+        """an ``rtx_dp_ops`` table for ``plan``'s rank on one channel ("main": the caller's stream, "side": the engine's side stream)"""
+        from . import _lib
+        rank, W = plan.rank, self.world
+        dts = {_lib.RTX_FP32: torch.float32, _lib.RTX_BF16: torch.bfloat16}
+
+        def guarded(fn):
+            def call(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as ex:
+                    plan.error = ex
+                    try:
+                        self.barrier.abort()      # the peers must not wait for ever for a rank that failed
+                    except Exception:
+                        pass
+                    return -1
+            return call
+
+        def all_reduce(_ctx, buf, n, dtype, stream):
+            t = _alias(buf, n * (2 if dtype == _lib.RTX_BF16 else 4), dts[dtype])
+
+            def combine(slots):
+                t.copy_(slots[0])
+                for r in range(1, W):
+                    t.add_(slots[r])
+            self._collective(channel, rank, t, stream, combine)
+
+        def reduce_scatter(_ctx, buf, n, dtype, stream):
+            t = _alias(buf, n * (2 if dtype == _lib.RTX_BF16 else 4), dts[dtype])
+            per = n // W
+            mine = slice(rank * per, (rank + 1) * per)
+
+            def combine(slots):
+                t[mine].copy_(slots[0][mine])
+                for r in range(1, W):
+                    t[mine].add_(slots[r][mine])
+            self._collective(channel, rank, t, stream, combine)
+
+        def all_gather(_ctx, buf, nbytes, stream):
+            t = _alias(buf, nbytes, torch.uint8)
+            per = nbytes // W
+
+            def combine(slots):
+                for r in range(W):
+                    if r != rank:
+                        t[r * per:(r + 1) * per].copy_(slots[r][r * per:(r + 1) * per])
+            self._collective(channel, rank, t, stream, combine)
+
+        ops = _lib.DpOps()
+        cbs = (_lib.DP_REDUCE_FN(guarded(all_reduce)), _lib.DP_REDUCE_FN(guarded(reduce_scatter)), _lib.DP_GATHER_FN(guarded(all_gather)))
+        plan._cbs = getattr(plan, "_cbs", ()) + cbs
+        ops.all_reduce, ops.reduce_scatter, ops.all_gather = cbs
+        return ops
 
 
 def _all_gather_blocks(flat, rank, world, group, native):
@@ -507,7 +712,7 @@ def init_from_env(backend=None):
 
 
 def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None, comm_dtype=None, bucket_adam=True, sharded=False,
-           engine=None, emulate_world=0, transport=None, shard_min_elems=None):
+           engine=None, emulate_world=0, transport=None, shard_min_elems=None, local_rank=None, two_comms=None):
     """Turn a :class:`rectorch_amd.models.AETrainer` into a data-parallel replica: broadcasts rank 0's
     parameters, then every ``train_batch`` exchanges the gradients as described above.  Each rank must feed
     ITS slice of the global batch (see ``shard_rows``).
@@ -526,6 +731,10 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
     (``torch.distributed`` calls on the engine's streams).
     ``shard_min_elems`` (native engine): weight matrices of at least this many elements are sharded (None: the engine's default,
     2^20; the tests lower it so that small golden networks run the sharded path with real data).
+    ``transport="local"`` with ``group`` = a :class:`LocalGroup` and ``local_rank``: the ranks are threads of this process on one
+    GPU and the collectives are stream-ordered device work (the stream-ordering tests; no ``torch.distributed``).
+    ``two_comms`` (native engine): None -> bucket A's collectives (side stream) get a communicator of their own unless
+    ``RTX_DP_ONE_COMM=1``.
     ``bucket_adam`` / ``min_bucket_bytes`` steer the python engine only."""
     st, params, m, v = model._ensure_train_state()
     if comm_dtype is None:
@@ -539,6 +748,15 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
         plan._fixed_global = int(fixed_global_batch) if fixed_global_batch is not None else None
         if plan._fixed_global is not None:
             plan.global_batch = lambda local, _g=plan._fixed_global: _g
+        st.reducer = plan
+        return plan
+    if transport == "local":
+        assert isinstance(group, LocalGroup) and local_rank is not None and on_device
+        group.host_broadcast(int(local_rank), [p.data for p in params])
+        model.network._rtx_shadow_versions.clear()
+        plan = NativePlan(int(local_rank), group.world, sharded, comm_dtype, group, "local", shard_min_elems, two_comms)
+        if fixed_global_batch is not None:
+            plan.global_batch = lambda local, _g=int(fixed_global_batch): _g
         st.reducer = plan
         return plan
     for p in params:
@@ -555,7 +773,7 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
             # issue different collectives than its peers)
             ok = torch.ones(1, device="cuda")
             try:
-                plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "rccl", shard_min_elems)
+                plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "rccl", shard_min_elems, two_comms)
             except Exception as ex:                 # pragma: no cover (needs a broken RCCL)
                 import logging
                 logging.getLogger(__name__).warning("rtx_comm over RCCL did not come up (%s): collectives through torch.distributed", ex)
@@ -564,7 +782,7 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
             if float(ok.item()) < 1.0:
                 plan, transport = None, "torch"
         if plan is None:
-            plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "torch", shard_min_elems)
+            plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "torch", shard_min_elems, two_comms)
         if fixed_global_batch is not None:
             plan.global_batch = lambda local, _g=int(fixed_global_batch): _g
         st.reducer = plan

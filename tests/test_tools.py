@@ -129,12 +129,13 @@ def test_bench_reports_committed_counters_only_for_the_profiled_kernel_source():
     import json
     import bench
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "rectorch_amd", "csrc", "dw_adam.hip")
-    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    from tools.launch_hash import launch_sources_sha, LAUNCH_SOURCES
+    sha = launch_sources_sha(root)
+    assert sha and len(sha) == 64 and "rectorch_amd/csrc/engine.hip" in LAUNCH_SOURCES and "rectorch_amd/csrc/dw_adam.hip" in LAUNCH_SOURCES
     traffic, source = bench.committed_traffic(root)
-    if traffic is not None:            # the committed summary matches this source: it must be the file it names
+    if traffic is not None:            # the committed summary matches EVERY launch-shaping source: it must be the file it names
         pj = json.load(open(os.path.join(root, source["file"])))
-        assert pj["kernel_source_sha256"] == sha and pj["hbm_bytes_per_launch"] == traffic
+        assert pj["launch_sources_sha256"] == sha and pj["hbm_bytes_per_launch"] == traffic and not pj.get("bench_opts")
         # the ml-20m decoder / encoder launches: between the algorithmic 24 B/param and twice that
         assert 24.0 * 20108 * 600 <= traffic <= 48.0 * 20108 * 600
     assert bench.committed_traffic(root, sha="0" * 64) == (None, None)

@@ -15,6 +15,6 @@ for pass in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GR
   DB=$(find /tmp/pmc_$tag -name "*.db" | head -1)
   python $R/tools/rocprof_summary.py pmc $DB > $R/gpurun_out/pmc/bench_$tag.txt
 done
-python $R/tools/rocprof_summary.py pmcjson $R/gpurun_out/pmc > $R/gpurun_out/pmc/pmc_summary.json
+RTX_PMC_BENCH_ARGS="$*" python $R/tools/rocprof_summary.py pmcjson $R/gpurun_out/pmc > $R/gpurun_out/pmc/pmc_summary.json
 python $R/tools/rocprof_summary.py mfma $R/gpurun_out/pmc/bench_SQ_VALU_MFMA_BUSY_CYCLES.txt > $R/gpurun_out/pmc/mfma_util.txt
 cat $R/gpurun_out/pmc/mfma_util.txt

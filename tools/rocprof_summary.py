@@ -130,11 +130,16 @@ def pmcjson(directory):
         if os.path.exists(os.path.join(root, ".git_rev")):                # the GPU box has no .git: tools/gpu.sh leaves the hash here
             git = open(os.path.join(root, ".git_rev")).read().strip()
     import hashlib
+    sys.path.insert(0, root)
+    from tools.launch_hash import launch_sources_sha, LAUNCH_SOURCES
     src = os.path.join(root, "rectorch_amd", "csrc", "dw_adam.hip")     # bench.py reports these counters only for the SAME kernel source
     print(json.dumps({"correction": "gfx950 rocprofv3: FETCH_SIZE doubled (reports 1/2 of a wide coalesced streaming read), WRITE_SIZE as reported; KB -> bytes",
                       "source": "tools/pmc_bench.sh: bench.py under rocprofv3, separate --pmc passes (kernels serialised: each is alone on the device)",
                       "git": git, "kernel_source": "rectorch_amd/csrc/dw_adam.hip",
                       "kernel_source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None,
+                      # every source that shapes the dominant launch (tools/launch_hash.py): what bench.py compares before citing this file
+                      "launch_sources_sha256": launch_sources_sha(root), "launch_sources": list(LAUNCH_SOURCES),
+                      "bench_opts": [a for a in os.environ.get("RTX_PMC_BENCH_ARGS", "").split() if a],
                       "kernels": kernels,
                       "hbm_bytes_per_launch": (sum(v["hbm_bytes_per_launch"] for v in dom) / len(dom)) if dom else None,
                       "dominant": "mean over the weight-gradient + Adam launches (rtx_dw_tn / rtx_dw_tn_group)"}, indent=1))
