@@ -1071,6 +1071,78 @@ def test_dp_world8_on_one_gpu():
     assert out.returncode == 0 and "DP_WORLD8_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+@pytest.mark.parametrize("numerics", ["bf16", "fp32"])
+def test_loss_mailbox_returns_this_steps_loss(numerics):
+    """train_batch returns THIS step's loss (reference models.py:835 `return loss.item()`).  Default: the float comes from the
+    engine's host mailbox (rtx_engine_wait_loss spins on the step count; the stream is not drained); `loss_mailbox = False`:
+    `loss.item()`.  Same seeds -> the two models report bit-identical losses step by step and end with bit-identical parameters;
+    the mailbox's value equals the device loss buffer's after a synchronise; waiting for a step that never ran times out."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    from rectorch_amd import _lib
+    I, H, L, B = 3000, 600, 200, 128
+    X = synth_interactions(6 * B, I, mu=3.5, sigma=0.9, dmax=I // 2, seed=11)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 3)
+    out = []
+    for mailbox in (True, False):
+        net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, learning_rate=1e-3, numerics=numerics)
+        net.to("cuda")
+        model.loss_mailbox = mailbox
+        torch.manual_seed(99)
+        losses = []
+        for rb in DataSampler(X, batch_size=B, shuffle=False).iter_rows():
+            losses.append(model.train_batch(rb))
+            assert isinstance(losses[-1], float) and np.isfinite(losses[-1])
+            if mailbox:
+                torch.cuda.synchronize()
+                assert losses[-1] == float(model._rtx.loss_buf[0].item())
+        eng = net._rtx_engines[numerics]
+        assert bool(getattr(eng, "_mailbox", False)) == mailbox
+        if mailbox:
+            with pytest.raises(_lib.RtxError, match="did not report its loss"):
+                eng.wait_loss(10 ** 6, timeout_s=0.05)
+        out.append((losses, [p.detach().cpu().numpy().copy() for p in net._param_list()]))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+def test_dp_stream_ordered_ranks_on_one_gpu():
+    """the data-parallel step at world 2 and 4 with collectives that are stream-ordered device work and nothing else (ranks =
+    threads of one process, parallel.LocalGroup): the run WITHOUT any device drain equals the drained run bit for bit, replicas
+    are identical, bucket A's collectives have a table of their own -- the ordering between the engine's kernels, the side
+    stream's bucket and the caller's stream's bucket is what this test can see and the gloo tests cannot"""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "dp_local_threads_check.py")], capture_output=True, text=True,
+                         timeout=1200, env=env)
+    print(out.stdout[-1500:])
+    assert out.returncode == 0 and "DP_LOCAL_THREADS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 --steps 3 --warmup 1` with NO launcher (the form the driver uses): bench.py starts the two ranks
+    itself (gloo: they share the one GPU of the box), rank 0 prints the one JSON line, the exchange ran between 2 ranks and left
+    bit-identical replicas"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RTX_DIST_BACKEND"] = "gloo"
+    out = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["replica_check"]["identical"] and d["replica_check"]["finite"] and d["replica_check"]["ranks"] == 2
+    assert d["comm"] and d["comm"]["collectives_per_step"] > 0 and d["comm"]["bytes_per_step_per_rank"]["total"] > 0
+    assert d["config"]["global_batch"] == 1000 and d["scaling"] == "weak" and d["value"] > 0
+    # a rank that dies takes the job down with a non-zero exit and its own message (here: an unknown engine option)
+    bad = subprocess.run(["python3", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--opt", "no_such_knob=1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and "no_such_knob" in bad.stderr and "rank" in bad.stderr, bad.stderr[-3000:]
+    assert not [l for l in bad.stdout.strip().splitlines() if l.startswith("{")]
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_architectures_vs_oracle(seed):
     """randomly drawn networks (depths 1..3 per side, widths that are not multiples of anything, VAE / DAE / conditioned,

@@ -139,3 +139,21 @@ def test_bench_reports_committed_counters_only_for_the_profiled_kernel_source():
         # the ml-20m decoder / encoder launches: between the algorithmic 24 B/param and twice that
         assert 24.0 * 20108 * 600 <= traffic <= 48.0 * 20108 * 600
     assert bench.committed_traffic(root, sha="0" * 64) == (None, None)
+
+
+def test_bench_gpus_n_without_a_launcher_does_not_assert():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py is its own launcher (round 4 asserted "launch with --nproc-per-node").
+    Without a HIP device it refuses with exit code 2 and says what it needs -- no traceback, no JSON line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the refusal path needs a box without a HIP device (the launch itself is tested under -m gpu)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2, (out.returncode, out.stderr[-1500:])
+    assert "0 HIP device(s) visible" in out.stderr and "Traceback" not in out.stderr and "AssertionError" not in out.stderr
+    assert not out.stdout.strip()
