@@ -93,6 +93,8 @@ def parse():
                          "kernel's source is byte-for-byte the profiled one (sha256), else traffic is null")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (train_batch API, sparse first layer; N > 1: the replicated all-reduce A/B)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="every step gathers its own batch at its head (rounds 1-4) instead of announcing the next one to the engine")
     ap.add_argument("--first-layer", default="dense", choices=["dense", "sparse"],
                     help="dense (default, BASELINE.json's north star): [batch, n_items] x [n_items, hidden] on MFMA (k_gather -> split-K "
                          "rtx_gemm_nt -> k_post); sparse: the VALU product over the stored entries (k_in_chunks -> k_spmm_in)")
@@ -356,8 +358,13 @@ def main():
     torch.manual_seed(1000 + rank)
 
     def run(n, start):
+        # as MultiVAE.train_epoch does with the resident sampler: every step announces the batch after it, which the engine gathers
+        # on its side stream under the step's last weight kernel (single GPU; rtx_engine_set_next_batch).  Every step still pays
+        # for one gather: step k's launch carries batch k + 1's.
         for i in range(n):
-            model._fused_step(batches[(start + i) % len(batches)], None, want_loss=False)
+            k = start + i
+            model._fused_step(batches[k % len(batches)], None, want_loss=False,
+                              next_x=None if args.no_prefetch else batches[(k + 1) % len(batches)])
 
     st_, _, m_, v_ = model._ensure_train_state()        # the engine exists before its first step: some knobs must be set by then
     eng0 = net.rtx_engine(args.numerics, B, train_buffers=(st_.grads, m_, v_))
@@ -533,6 +540,8 @@ def main():
                    "dp_scheduler": (None if not dp else ("engine (%s)" % plan.transport if getattr(plan, "native", False) else "python reducer")),
                    "first_layer": "sparse (k_spmm_in, VALU)" if sparse_first else "dense (MFMA split-K GEMM)",
                    "second_stream_concurrent": bool(eng.get_option("side_concurrent")),
+                   "batch_prefetch": {"steps_started_from_a_prefetched_image": eng.get_option("prefetch_hits"),
+                                      "gathers_issued_on_the_side_stream": eng.get_option("prefetch_issued")},
                    "numerics": "bf16 MFMA operands, f32 accumulate, f32 master weights + Adam" if args.numerics == "bf16"
                                else "f32 MFMA (parity mode)"},
         "windows": {"n": args.windows, "steps_each": args.steps, "seconds": wins, "reported": "median"},

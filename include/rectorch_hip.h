@@ -244,6 +244,14 @@ int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
  * step under them.  timeout_s <= 0: 60 s.  Steps must be waited for in order (the mailbox holds the LAST step's loss). */
 int rtx_engine_loss_mailbox(rtx_engine* e, int32_t enable);
 int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double timeout_s);
+/* ABI 7 -- announce the batch of the training step AFTER the next rtx_engine_train_step call (and its dropout stream: seed /
+ * offset / dropout_mask of next_step; the other fields are ignored).  That call then also gathers the announced batch, on the
+ * engine's side stream under its last weight-gradient + Adam launch, into a second batch image; the step that is then given
+ * exactly this batch (same csr / target_csr / row_ids pointers, batch, seed, offset, mask) starts with the first-layer product.
+ * A hint only: any other batch is gathered by its own step.  The announced row ids must stay unchanged until that step.  NULL
+ * cancels.  bf16 numerics, resident CSR batches, single-GPU fused step (the data-parallel step's side stream is busy with the
+ * exchange).  The reference densifies every batch on the host (samplers.py:99-100). */
+int rtx_engine_set_next_batch(rtx_engine* e, const rtx_batch* next, const rtx_step* next_step);
 /* both of the above: one full train_batch */
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out,
                           float* loss_accum, void* stream);

@@ -111,6 +111,7 @@ SIGNATURES = {
     "rtx_engine_dp_owned_rows": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
+    "rtx_engine_set_next_batch": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step)]),
     "rtx_engine_loss_mailbox": (C.c_int, [_P, C.c_int32]),
     "rtx_engine_wait_loss": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_double]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),

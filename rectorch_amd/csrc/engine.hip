@@ -117,6 +117,20 @@ struct rtx_engine {
     int32_t *img_written = nullptr, *img_nwritten = nullptr;
     int img_cap = 0;
     bool img_exact = false;           // A[0] is zero except the listed columns (any other writer of A[0] clears this flag)
+    // The OTHER batch image (round 5): the NEXT step's gather (rtx_engine_set_next_batch) runs on the side stream, which idles
+    // under this step's last weight-gradient + Adam launch, into a second image with lists and target sums of its own; the step
+    // that then gets the announced batch swaps the two sets and starts with the first-layer product (the gather -- 7-9 us of pure
+    // latency at the head of every step -- leaves the critical path).  swap_img_sets() exchanges these with L[0].A, tsum, img_*.
+    void* A0_alt = nullptr;
+    float* tsum_alt = nullptr;
+    int32_t *img_written_alt = nullptr, *img_nwritten_alt = nullptr;
+    int img_cap_alt = 0;
+    bool img_exact_alt = false;
+    struct { bool valid = false; rtx_batch b = {}; rtx_step s = {}; } next;        // announced for the step after the next call
+    struct { bool valid = false; rtx_batch b = {}; uint64_t seed = 0, offset = 0; const uint8_t* mask = nullptr; } pre;   // gathered
+    bool gather_done = false;         // run_forward: A[0] / tsum already hold this batch (a prefetch hit)
+    int opt_prefetch = 1;             // 0: announced batches are ignored (A/B knob)
+    int st_prefetch_hits = 0, st_prefetch_issued = 0;
     int opt_gather_scatter = 1;       // 0: k_gather rewrites the whole image every batch (rounds 1-3)
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
@@ -459,6 +473,60 @@ static int ensure_in_chunks(rtx_engine* e, int64_t chunks, hipStream_t st)
     return RTX_OK;
 }
 
+// The batch image A[0] (+ target row sums, + the scatter lists) of one batch, on stream `st`, into the CURRENT image set.
+static int gather_batch(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg, int B, int training, const rtx_step* step, hipStream_t st)
+{
+    const int Bp = rtx_pad_batch(B);
+    Layer& l = e->L[0];
+    RtxGatherArgs a = {};
+    a.in = *in; a.target = *tg;
+    a.B = B; a.Bp = Bp; a.I = e->I; a.Iin = e->Iin; a.ldx = l.inp;
+    a.X = l.A; a.tsum = e->tsum;
+    a.training = training; a.dropout_p = e->cfg.dropout_p;
+    a.mask = step->dropout_mask; a.seed = step->seed; a.offset = step->offset;
+    // The image is all zeros but for ~75 entries per user: with a resident matrix (its longest row is known) only those are
+    // touched -- cleared, rewritten, listed (k_gather_scatter).  First use, a longer matrix, or another writer of A[0] in
+    // between (the sparse first layer's k_in_chunks, a densified batch through k_gather): one full reset of image and lists.
+    if (e->opt_gather_scatter && in->max_row_len > 0 && ((int64_t)in->max_row_len + 66) * e->Bp_alloc * 4 <= ((int64_t)256 << 20)) {
+        const int need = (in->max_row_len + 2 + 63) / 64 * 64;
+        if (need > e->img_cap) {
+            if (e->img_written) {
+                RTX_HIP(hipStreamSynchronize(st));
+                for (void* q : {(void*)e->img_written, (void*)e->img_nwritten}) {
+                    e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), q));
+                    (void)hipFree(q);
+                }
+                e->img_written = nullptr; e->img_nwritten = nullptr;
+            }
+            RTX_TRY(dev_alloc(e, (void**)&e->img_written, (size_t)e->Bp_alloc * need * sizeof(int32_t), false));
+            RTX_TRY(dev_alloc(e, (void**)&e->img_nwritten, (size_t)e->Bp_alloc * sizeof(int32_t)));
+            e->img_cap = need;
+            e->img_exact = false;
+        }
+        if (!e->img_exact) {
+            RTX_HIP(hipMemsetAsync(l.A, 0, (size_t)e->Bp_alloc * l.inp * e->esz, st));
+            RTX_HIP(hipMemsetAsync(e->img_nwritten, 0, (size_t)e->Bp_alloc * sizeof(int32_t), st));
+            e->img_exact = true;
+        }
+        a.written = e->img_written; a.n_written = e->img_nwritten; a.written_cap = e->img_cap;
+    } else {
+        e->img_exact = false;
+    }
+    TIMED("gather");
+    RTX_TRY(rtx_launch_gather(a, e->bf16, st));
+    return RTX_OK;
+}
+
+static void swap_img_sets(rtx_engine* e)
+{
+    std::swap(e->L[0].A, e->A0_alt);
+    std::swap(e->tsum, e->tsum_alt);
+    std::swap(e->img_written, e->img_written_alt);
+    std::swap(e->img_nwritten, e->img_nwritten_alt);
+    std::swap(e->img_cap, e->img_cap_alt);
+    std::swap(e->img_exact, e->img_exact_alt);
+}
+
 static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg, int B, int training, const rtx_step* step,
                        int want_lse, int l0, int l1, float* logits, long ldlog, float* mu_out, float* lv_out, hipStream_t st)
 {
@@ -468,45 +536,9 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     int64_t in_chunks = 0;
     const bool sparse_in = l0 == 0 && l1 > 1 && sparse_in_ok(e, in, Bp, &in_chunks);
     if (l0 == 0) e->last_sparse_in = sparse_in;
-    if (l0 == 0 && !sparse_in) {
-        Layer& l = e->L[0];
-        RtxGatherArgs a = {};
-        a.in = *in; a.target = *tg;
-        a.B = B; a.Bp = Bp; a.I = e->I; a.Iin = e->Iin; a.ldx = l.inp;
-        a.X = l.A; a.tsum = e->tsum;
-        a.training = training; a.dropout_p = e->cfg.dropout_p;
-        a.mask = step->dropout_mask; a.seed = step->seed; a.offset = step->offset;
-        // The image is all zeros but for ~75 entries per user: with a resident matrix (its longest row is known) only those are
-        // touched -- cleared, rewritten, listed (k_gather_scatter).  First use, a longer matrix, or another writer of A[0] in
-        // between (the sparse first layer's k_in_chunks, a densified batch through k_gather): one full reset of image and lists.
-        if (e->opt_gather_scatter && in->max_row_len > 0 && ((int64_t)in->max_row_len + 66) * e->Bp_alloc * 4 <= ((int64_t)256 << 20)) {
-            const int need = (in->max_row_len + 2 + 63) / 64 * 64;
-            if (need > e->img_cap) {
-                if (e->img_written) {
-                    RTX_HIP(hipStreamSynchronize(st));
-                    for (void* q : {(void*)e->img_written, (void*)e->img_nwritten}) {
-                        e->allocs.erase(std::find(e->allocs.begin(), e->allocs.end(), q));
-                        (void)hipFree(q);
-                    }
-                    e->img_written = nullptr; e->img_nwritten = nullptr;
-                }
-                RTX_TRY(dev_alloc(e, (void**)&e->img_written, (size_t)e->Bp_alloc * need * sizeof(int32_t), false));
-                RTX_TRY(dev_alloc(e, (void**)&e->img_nwritten, (size_t)e->Bp_alloc * sizeof(int32_t)));
-                e->img_cap = need;
-                e->img_exact = false;
-            }
-            if (!e->img_exact) {
-                RTX_HIP(hipMemsetAsync(l.A, 0, (size_t)e->Bp_alloc * l.inp * e->esz, st));
-                RTX_HIP(hipMemsetAsync(e->img_nwritten, 0, (size_t)e->Bp_alloc * sizeof(int32_t), st));
-                e->img_exact = true;
-            }
-            a.written = e->img_written; a.n_written = e->img_nwritten; a.written_cap = e->img_cap;
-        } else {
-            e->img_exact = false;
-        }
-        TIMED("gather");
-        RTX_TRY(rtx_launch_gather(a, e->bf16, st));
-    }
+    const bool gathered = e->gather_done;
+    e->gather_done = false;
+    if (l0 == 0 && !sparse_in && !gathered) RTX_TRY(gather_batch(e, in, tg, B, training, step, st));
     for (int li = l0; li < l1; ++li) {
         Layer& l = e->L[li];
         if (li == e->NL - 1) {
@@ -1087,11 +1119,40 @@ static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hi
     return RTX_OK;
 }
 
+// The batch announced for the NEXT step (rtx_engine_set_next_batch): its gather on the side stream, into the other image set.
+// A hint: whatever keeps it from being issued is not an error (the next step then gathers for itself).
+static int prefetch_next(rtx_engine* e)
+{
+    const rtx_batch& nb = e->next.b;
+    if (!e->opt_prefetch || !e->bf16 || !e->side || !nb.csr || !nb.row_ids || nb.x_dense || nb.target_dense) return RTX_OK;
+    if (nb.batch < 1 || nb.batch > e->cfg.max_batch || nb.csr->n_cols != e->Iin || nb.csr->max_row_len <= 0) return RTX_OK;
+    if (nb.target_csr ? nb.target_csr->n_cols != e->I : e->Iin != e->I) return RTX_OK;
+    RtxCsrView in = {}, tg = {};
+    RTX_TRY(resolve_batch(e, &nb, &in, &tg, e->side));       // (a CSR batch: views only, nothing is enqueued)
+    int64_t chunks = 0;
+    if (sparse_in_ok(e, &in, rtx_pad_batch(nb.batch), &chunks)) return RTX_OK;   // the sparse first layer builds its own stream
+    if (!e->A0_alt) {
+        RTX_TRY(dev_alloc(e, &e->A0_alt, (size_t)e->Bp_alloc * e->L[0].inp * e->esz));
+        RTX_TRY(dev_alloc(e, (void**)&e->tsum_alt, (size_t)e->Bp_alloc * sizeof(float)));
+        e->img_exact_alt = false;
+    }
+    swap_img_sets(e);
+    const int rc = gather_batch(e, &in, &tg, nb.batch, 1, &e->next.s, e->side);
+    swap_img_sets(e);
+    RTX_TRY(rc);
+    e->pre.valid = true;
+    e->pre.b = nb;
+    e->pre.seed = e->next.s.seed; e->pre.offset = e->next.s.offset; e->pre.mask = e->next.s.dropout_mask;
+    ++e->st_prefetch_issued;
+    return RTX_OK;
+}
+
 static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
                            rtx_layer_cb cb, void* user, hipStream_t st, bool fuse, DpState* dp = nullptr)
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
+    struct ClearNext { rtx_engine* e; ~ClearNext() { e->next.valid = false; } } clear_next{e};   // an announcement is for ONE step
     if (dp) {
         RTX_CHECK(!dp->broken, RTX_ESTATE, "data parallel: a collective of an earlier step failed; attach the plan again (rtx_engine_dp_attach)");
         dp->st_all_reduce = dp->st_reduce_scatter = dp->st_all_gather = 0;
@@ -1119,6 +1180,21 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     }
     if (two && !e->side_concurrent) two = false;   // no stream that really runs beside the caller's: one stream, no event traffic
     const int main_li = (two && fuse && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
+    if (e->pre.valid) {
+        // the batch of this step was announced one step ago and gathered on the side stream under that step's last weight
+        // kernel (the step's closing stream dependency ordered it before anything enqueued now): its image set becomes the
+        // current one, the gather is skipped.  Anything else than exactly the announced batch / dropout stream: a normal step.
+        const rtx_batch& pb = e->pre.b;
+        const bool hit = fuse && !dp && two && st == e->side_for && batch->csr && pb.csr == batch->csr && pb.row_ids == batch->row_ids &&
+                         pb.target_csr == batch->target_csr && !batch->x_dense && !batch->target_dense && pb.batch == batch->batch &&
+                         e->pre.seed == step->seed && e->pre.offset == step->offset && e->pre.mask == step->dropout_mask;
+        e->pre.valid = false;
+        if (hit) {
+            swap_img_sets(e);
+            e->gather_done = true;
+            ++e->st_prefetch_hits;
+        }
+    }
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
     if (dae_reg) {
         TIMED("sumsq");
@@ -1462,6 +1538,8 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             RTX_TRY(rtx_dw_launch_group(grp, ng, RTX_DW_ADAM, dw_cfg, st));
         }
         RTX_TRY(reduce_loss(e->side));
+        // the side stream idles from here to the end of the step: the NEXT step's gather, when its batch was announced
+        if (e->next.valid && !rest.n) RTX_TRY(prefetch_next(e));
         if (rest.n > 0) {   // gradients from both streams feed the leftover Adam launch: the side stream waits for this one, then runs it
             RTX_HIP(hipEventRecord(e->ev_d[NL], st));
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[NL], 0));
@@ -1828,6 +1906,24 @@ int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double t
     return RTX_OK;
 }
 
+// ABI 7: the batch (and the dropout stream: seed / offset / dropout_mask of `next_step`; its other fields are ignored) of the
+// training step AFTER the next rtx_engine_train_step call.  That call then also gathers the announced batch -- on the engine's
+// side stream, under its last weight-gradient + Adam launch, into a second batch image -- and the step that is then given exactly
+// this batch (same csr / target_csr / row_ids pointers, batch size, seed, offset, mask) starts with the first-layer product.
+// A hint: a step that gets anything else gathers for itself.  The row ids must not change between the announcement and that
+// step.  NULL cancels.  (The reference has no counterpart: its sampler densifies on the host, samplers.py:99-100.)
+int rtx_engine_set_next_batch(rtx_engine* e, const rtx_batch* next, const rtx_step* next_step)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    e->next.valid = false;
+    if (!next) return RTX_OK;
+    RTX_CHECK(next_step, RTX_EINVAL, "set_next_batch: next_step is NULL");
+    e->next.b = *next;
+    e->next.s = *next_step;
+    e->next.valid = true;
+    return RTX_OK;
+}
+
 // measurement knobs: one entry point instead of environment variables scattered over the kernels' launchers
 int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
 {
@@ -1852,6 +1948,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
         RTX_CHECK(!e->dp.on, RTX_ESTATE, "set_option: dp_one_comm must be set before rtx_engine_dp_attach");
         e->opt_dp_one_comm = value != 0;
     }
+    else if (k == "prefetch") e->opt_prefetch = value != 0;
     else if (k == "two_stream") e->opt_two_stream = value != 0;
     else if (k == "side_low_prio") {
         RTX_CHECK(e->side_cache.empty(), RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
@@ -1904,6 +2001,9 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "dp_bytes_all_gather") *value = (int32_t)std::min<int64_t>(e->dp.st_all_gather, INT32_MAX);
     else if (k == "dp_collectives") *value = e->dp.st_collectives;
     else if (k == "dp_one_comm") *value = e->opt_dp_one_comm;
+    else if (k == "prefetch") *value = e->opt_prefetch;
+    else if (k == "prefetch_hits") *value = e->st_prefetch_hits;       // steps that started from a prefetched batch image
+    else if (k == "prefetch_issued") *value = e->st_prefetch_issued;
     else if (k == "dp_two_comms") *value = e->dp.on && e->dp.two_comms;   // bucket A's collectives have a communicator of their own
     else if (k == "two_stream") *value = e->opt_two_stream;
     else if (k == "side_low_prio") *value = e->opt_side_low_prio;

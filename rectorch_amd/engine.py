@@ -292,6 +292,24 @@ class Engine:
         check(lib().rtx_engine_train_step(self.handle, C.byref(b), C.byref(step), _ptr(loss_out), _ptr(loss_accum),
                                           stream_ptr()))
 
+    def set_next_batch(self, x, target=None, seed=0, offset=0):
+        """announce the batch (a :class:`RowBatch`) and the dropout seed of the training step AFTER the next ``train_step`` call:
+        that call gathers it on the engine's side stream under its last weight kernel (``rtx_engine_set_next_batch``; a hint).
+        Returns False (and announces nothing) for batches the engine cannot prefetch (dense tensors)."""
+        if x is None:
+            check(lib().rtx_engine_set_next_batch(self.handle, None, None))
+            self._next_keep = None
+            return False
+        if not isinstance(x, RowBatch) or (target is not None and not isinstance(target, RowBatch)):
+            return False
+        b = make_batch(x, target, keep=None, n_items=self.n_items, n_in=self.n_in)
+        if not b.csr or b.x_dense or b.target_dense:
+            return False
+        st = self._step(seed=seed, offset=offset)
+        check(lib().rtx_engine_set_next_batch(self.handle, C.byref(b), C.byref(st)))
+        self._next_keep = (x, target)         # the row ids stay alive (and unchanged) until that step has run
+        return True
+
     def loss_mailbox(self, enable=True):
         """every training step also reports {loss, step count} to coherent host memory (``wait_loss``)"""
         check(lib().rtx_engine_loss_mailbox(self.handle, int(bool(enable))))

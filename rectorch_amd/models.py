@@ -53,6 +53,7 @@ class _RtxState:
         self.tensor_offsets = None
         self.adam_step = 0
         self.loss_buf = None      # [0] = last loss, [1] = running sum since the last read-back
+        self.pending_seed = None  # the dropout seed drawn one step early for a batch announced to the engine
         self.reducer = None       # data parallel: rectorch_amd.parallel.GradAllReducer
         self.masters_sharded = False   # sharded optimizer: the float32 master rows of other ranks are stale until gathered
         self.inject = None        # parity tests: (dropout keep-mask, eps) captured from the reference's RNG
@@ -115,6 +116,19 @@ class TorchNNTrainer(RecSysModel):
         return "%s(\n%s\n)" % (type(self).__name__, ",\n".join(fields))
 
     __repr__ = __str__
+
+
+def _with_next(it):
+    """(item, next item or None) over an iterator: one batch of look-ahead for the engine's prefetch"""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
 
 
 class _EpochLog:
@@ -180,6 +194,9 @@ class AETrainer(TorchNNTrainer):
         # mailbox (rtx_engine_wait_loss: the host spins on a step count in coherent host memory while the step's remaining
         # kernels keep running); False: ``loss.item()``, which drains the stream like the reference does.
         self.loss_mailbox = True
+        # train_epoch / callers of _fused_step(next_x=...) announce the next batch to the engine, which gathers it on its side
+        # stream under the current step's last weight kernel (rtx_engine_set_next_batch); False: every step gathers for itself
+        self.prefetch_batches = True
         self._rtx = _RtxState()
 
     # ------------------------------------------------------------------------------------------ loss
@@ -216,10 +233,12 @@ class AETrainer(TorchNNTrainer):
         resident = isinstance(train_loader, DataSampler) and train_loader.resident
         pending = 0.0                       # host path: losses of the current stretch
         done = 0
-        for done, item in enumerate(train_loader.iter_rows() if resident else train_loader, 1):
+        def shaped(item):
+            return item if self._uses_te or item.te is None else RowBatch(item.tr, None, item.rows)
+        for done, (item, nxt) in enumerate(_with_next(train_loader.iter_rows()) if resident else ((i, None) for i in train_loader), 1):
             if resident:
-                rows = item if self._uses_te or item.te is None else RowBatch(item.tr, None, item.rows)
-                self._fused_step(rows, None, want_loss=False)
+                # (the batch after this one is announced to the engine: it is gathered under this step's last weight kernel)
+                self._fused_step(shaped(item), None, want_loss=False, next_x=None if nxt is None else shaped(nxt))
             else:
                 data, gt = item
                 pending += self.train_batch(data, gt)
@@ -275,7 +294,10 @@ class AETrainer(TorchNNTrainer):
         v = [self.optimizer.state[p]['exp_avg_sq'] for p in params]
         return st, params, m, v
 
-    def _fused_step(self, x, target, want_loss=True):
+    def _fused_step(self, x, target, want_loss=True, next_x=None, next_target=None):
+        """``next_x`` (optional, a :class:`RowBatch`): the batch of the NEXT ``_fused_step`` call.  The engine gathers it on its
+        side stream under this step's last weight kernel, so that step starts with the first-layer product (single GPU, bf16).
+        Its dropout seed is drawn now and kept for that step: the sequence of draws from torch's generator is unchanged."""
         _lib.require_gpu()
         st, params, m, v = self._ensure_train_state()
         if not isinstance(x, RowBatch):
@@ -298,7 +320,13 @@ class AETrainer(TorchNNTrainer):
             red.direct16 = direct16
             eng.bind_grads16(red.grads16_ptrs() if direct16 else None)
         inj = self._rtx.inject or (None, None)     # (keep-mask uint8 [B, n_items], eps [B, latent]) for parity tests
-        step = eng._step(seed=draw_seed(), offset=0 if red is None else red.rank, mask=inj[0], noise=inj[1],
+        seed = st.pending_seed if st.pending_seed is not None else draw_seed()     # (drawn one step early for an announced batch)
+        st.pending_seed = None
+        if (next_x is not None and red is None and self.numerics == "bf16" and self._rtx.inject is None and self.prefetch_batches
+                and isinstance(next_x, RowBatch)):
+            st.pending_seed = draw_seed()
+            eng.set_next_batch(next_x, next_target, seed=st.pending_seed, offset=0)
+        step = eng._step(seed=seed, offset=0 if red is None else red.rank, mask=inj[0], noise=inj[1],
                          beta=float(beta), lam=float(lam),
                          # (a rank's slice made by parallel.shard_batch knows the global batch: no collective, no host sync)
                          inv_batch=1.0 / (B if red is None else (getattr(x, "global_len", None) or red.global_batch(B))),

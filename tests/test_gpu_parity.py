@@ -1107,6 +1107,70 @@ def test_loss_mailbox_returns_this_steps_loss(numerics):
         assert np.array_equal(a.view(np.int32), b.view(np.int32))
 
 
+def test_prefetched_batches_equal_self_gathered_batches():
+    """rtx_engine_set_next_batch: the NEXT step's gather on the side stream under this step's last weight kernel, into a second
+    batch image.  Same seeds -> the run that announces every next batch (train_epoch's default) ends with bit-identical
+    parameters and loss sums to the run where every step gathers for itself; every step but the first starts from a prefetched
+    image; a ragged last batch, an announced batch that is NOT the one that arrives, a prediction between two steps and a model
+    that switches the hint off mid-run all land on the same bits."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L, B = 3000, 600, 200, 192
+    X = synth_interactions(5 * B + 77, I, mu=3.5, sigma=0.9, dmax=I // 2, seed=13)      # 5 full batches + a ragged one
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 5)
+
+    def fresh(prefetch):
+        net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, learning_rate=1e-3, numerics="bf16",
+                              predict_numerics="bf16")      # (predictions run on the SAME engine, between two training steps)
+        net.to("cuda")
+        model.prefetch_batches = prefetch
+        return net, model
+
+    def params(net):
+        return [p.detach().cpu().numpy().copy() for p in net._param_list()]
+
+    # (1) two epochs through train_epoch (shuffled resident sampler, look-ahead inside) vs the same without the hint
+    res = []
+    for prefetch in (True, False):
+        net, model = fresh(prefetch)
+        np.random.seed(3)
+        torch.manual_seed(17)
+        smp = DataSampler(X, batch_size=B, shuffle=True)
+        for ep in (1, 2):
+            model.train_epoch(ep, smp, verbose=0)
+        eng = net._rtx_engines["bf16"]
+        hits, issued = eng.get_option("prefetch_hits"), eng.get_option("prefetch_issued")
+        assert (hits, issued) == ((10, 10) if prefetch else (0, 0)), (prefetch, hits, issued)   # 2 x (6 batches - the first)
+        res.append((params(net), model._read_loss_sum()))
+    assert res[0][1] == res[1][1], (res[0][1], res[1][1])
+    for a, b in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+    # (2) the announced batch is not the one that arrives; a prediction sits between two steps; the hint goes off mid-run
+    batches = list(DataSampler(X, batch_size=B, shuffle=False).iter_rows())
+    order = [0, 1, 2, 5, 3, 4]
+    res = []
+    for variant in ("plain", "wrong-announcements"):
+        net, model = fresh(variant != "plain")
+        torch.manual_seed(23)
+        for n, k in enumerate(order):
+            nxt = None
+            if variant != "plain":
+                nxt = batches[(k + 1) % len(batches)]           # right for 0 -> 1 -> 2, wrong for 2 -> 5 -> 3, right for 3 -> 4
+                if n == 4:
+                    model.prefetch_batches = False
+            model._fused_step(batches[k], None, want_loss=False, next_x=nxt)
+            if n == 1:
+                model.predict(batches[0].tr.gather_dense(batches[0].rows[:7]))
+                net.train()
+        res.append(params(net))
+        if variant != "plain":
+            eng = net._rtx_engines["bf16"]
+            assert eng.get_option("prefetch_issued") == 4 and eng.get_option("prefetch_hits") == 2, \
+                (eng.get_option("prefetch_issued"), eng.get_option("prefetch_hits"))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
 def test_dp_stream_ordered_ranks_on_one_gpu():
     """the data-parallel step at world 2 and 4 with collectives that are stream-ordered device work and nothing else (ranks =
     threads of one process, parallel.LocalGroup): the run WITHOUT any device drain equals the drained run bit for bit, replicas
