@@ -163,6 +163,11 @@ class Engine:
         self.n_tensors = lib().rtx_engine_n_tensors(h)
         self._bound = None
         self._keep = []
+        # measurement / debugging: RTX_ENGINE_OPTS="hop_values=0,prefetch=0" sets engine options (rtx_engine_set_option) on
+        # every engine this process creates -- A/B runs of whole test files without touching them
+        for kv in filter(None, os.environ.get("RTX_ENGINE_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            check(lib().rtx_engine_set_option(h, k.strip().encode(), int(v)))
 
     @property
     def op_handle(self):

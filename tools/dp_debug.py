@@ -33,8 +33,8 @@ def run(world, sharded, drain, two_comms, sd, batches, masks, noise, opts=(), sy
                     rb = parallel.shard_batch(batches[t], r, world)
                     s, e = parallel.shard_rows(C.B_GLOBAL, r, world)
                     model._rtx.inject = (masks[t][s:e].cuda(), noise[t][s:e].cuda())
-                    loss = model._fused_step(rb, None, want_loss=True)
-                    if sync_each or True:
+                    loss = model._fused_step(rb, None, want_loss=(sync_each or t == C.STEPS - 1))
+                    if sync_each or t == C.STEPS - 1:
                         torch.cuda.synchronize()
                         if sharded:
                             model.consolidate()
@@ -58,7 +58,7 @@ def run(world, sharded, drain, two_comms, sd, batches, masks, noise, opts=(), sy
 
 def diff(a, b, tag):
     for r in range(len(a)):
-        for t in range(len(a[r])):
+        for t in (-1,):
             d = [float(np.abs(x - y).max()) for x, y in zip(a[r][t][0], b[r][t][0])]
             nd = [int((x.view(np.int32) != y.view(np.int32)).sum()) for x, y in zip(a[r][t][0], b[r][t][0])]
             print("%s rank %d step %d loss %.6f vs %.6f  max|d| %s  n_diff %s" % (tag, r, t, a[r][t][1], b[r][t][1], ["%.1e" % x for x in d], nd), flush=True)
@@ -73,17 +73,18 @@ def main():
     batches = list(DataSampler(X, batch_size=C.B_GLOBAL, shuffle=False).iter_rows())
     for sharded in (False, True):
         ref = run(2, sharded, True, True, sd, batches, masks, noise)
-        ref2 = run(2, sharded, True, True, sd, batches, masks, noise)
-        diff(ref2, ref, "sharded=%s drained-vs-drained" % sharded)
+        for rep in range(5):
+            diff(run(2, sharded, False, True, sd, batches, masks, noise), ref, "sharded=%s ordered rep %d" % (sharded, rep))
+        for rep in range(3):
+            diff(run(2, sharded, False, False, sd, batches, masks, noise), ref, "sharded=%s one-table rep %d" % (sharded, rep))
+        for rep in range(3):
+            diff(run(2, sharded, False, True, sd, batches, masks, noise, opts=("two_stream=0",)), ref, "sharded=%s two_stream=0 rep %d" % (sharded, rep))
+        for rep in range(3):
+            diff(run(2, sharded, False, True, sd, batches, masks, noise, opts=("hop_values=0",)), ref, "sharded=%s hop_values=0 rep %d" % (sharded, rep))
         for rep in range(2):
-            got = run(2, sharded, False, True, sd, batches, masks, noise)
-            diff(got, ref, "sharded=%s ordered(rep %d)-vs-drained" % (sharded, rep))
-        got = run(2, sharded, False, False, sd, batches, masks, noise)
-        diff(got, ref, "sharded=%s ordered one-table" % sharded)
-        got = run(2, sharded, False, True, sd, batches, masks, noise, opts=("two_stream=0",))
-        diff(got, ref, "sharded=%s ordered two_stream=0" % sharded)
-        got = run(2, sharded, False, True, sd, batches, masks, noise, opts=("hop_values=0",))
-        diff(got, ref, "sharded=%s ordered hop_values=0" % sharded)
+            diff(run(2, sharded, False, True, sd, batches, masks, noise, sync_each=True), ref, "sharded=%s sync-each rep %d" % (sharded, rep))
+        for rep in range(2):
+            diff(run(2, sharded, True, True, sd, batches, masks, noise), ref, "sharded=%s drained rep %d" % (sharded, rep))
 
 
 if __name__ == "__main__":
