@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams): tensors are passed to librect
 pointers on torch's current HIP stream.  No arithmetic of the path is done by torch.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
