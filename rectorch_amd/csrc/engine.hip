@@ -199,7 +199,15 @@ static int dev_alloc(rtx_engine* e, void** p, size_t bytes, bool zero = true)
         return RTX_ENOMEM;
     }
     if (e) e->allocs.push_back(*p);
-    if (zero) RTX_HIP(hipMemset(*p, 0, bytes));
+    if (zero) {
+        // hipMemset runs on the NULL stream, and neither the engine's side stream nor a caller's non-blocking stream (every
+        // torch.cuda.Stream) waits for that one: without the synchronise below the zeroing can land AFTER the first kernels that
+        // write the buffer.  Found by the stream-ordered multi-rank test and the batch prefetch (round 5): a data-parallel step on
+        // a non-blocking stream lost its first gradient images to the late memset of the exchange buffer, a prefetched batch image
+        // was zeroed after the gather had filled it.  Allocation is set-up time; the wait costs nothing per step.
+        RTX_HIP(hipMemset(*p, 0, bytes));
+        RTX_HIP(hipStreamSynchronize(nullptr));
+    }
     return RTX_OK;
 }
 
@@ -1097,6 +1105,7 @@ static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hi
                 e->opt_hop_values = 0;   // not available here: events
             } else {
                 RTX_HIP(hipMemset(e->hop_mem, 0, 64));
+                RTX_HIP(hipStreamSynchronize(nullptr));   // (the NULL stream's memset must not land after a write of `from`, see dev_alloc)
             }
         }
         if (e->hop_mem) {
@@ -1106,6 +1115,7 @@ static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hi
                 RTX_HIP(hipStreamSynchronize(from));
                 RTX_HIP(hipStreamSynchronize(to));
                 RTX_HIP(hipMemset(e->hop_mem, 0, 64));
+                RTX_HIP(hipStreamSynchronize(nullptr));   // (the NULL stream's memset must not land after a write of `from`, see dev_alloc)
                 e->hop_seq = 0;
             }
             const uint32_t v = ++e->hop_seq;
