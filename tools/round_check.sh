@@ -6,6 +6,8 @@
 # Outputs: gpurun_out/$1/.   usage: tools/gpu.sh --timeout 1500 -- 'bash tools/round_check.sh r4final'
 OUT=gpurun_out/${1:-check}
 mkdir -p $OUT
+# the driver's own invocation, verbatim (its line is the graded one): kept as profiles/r5_bench_driver_cmd.json
+timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; echo "driver cmd rc=$?"; tail -1 $OUT/bench_driver_cmd.json | cut -c1-200
 timeout 300 bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; echo "pmc rc=$?"; cp gpurun_out/pmc/* $OUT/ 2>/dev/null
 timeout 300 python bench.py --pmc-json gpurun_out/pmc/pmc_summary.json > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"; tail -1 $OUT/bench_default.json | cut -c1-330
 B="--steps 100 --no-cpu-baseline --no-fp32-parity --no-extras"
@@ -16,6 +18,7 @@ try:
 except Exception as e: print('no line', e)
 ")"; }
 run fused
+run no_prefetch --no-prefetch
 run sparse_first_layer --first-layer sparse
 run one_stream --opt two_stream=0
 run generic_kernels --opt small_fwd=0 --opt small_bwd=0
@@ -26,7 +29,7 @@ run emu8_sharded --emulate-world 8
 run emu2_sharded --emulate-world 2
 run netflix_b4096_fused --workload netflix
 bash tools/prof_cmd.sh ${1:-check}/prof_fused
-RTX_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --steps 3 --warmup 1 --windows 1 > $OUT/bench_8ranks_gloo_onegpu.json 2> $OUT/bench_8ranks_gloo_onegpu.err; echo "8 gloo ranks rc=$?"
+RTX_DIST_BACKEND=gloo timeout 300 python3 bench.py --gpus 8 --steps 3 --warmup 1 --windows 1 > $OUT/bench_8ranks_gloo_onegpu.json 2> $OUT/bench_8ranks_gloo_onegpu.err; echo "8 gloo ranks (self-launched) rc=$?"
 timeout 200 python tools/bench_eval.py 10000 500 > $OUT/bench_eval.json 2> $OUT/bench_eval.err; echo "eval rc=$?"
 timeout 200 python tools/bench_ease.py > $OUT/bench_ease.json 2> $OUT/bench_ease.err; echo "ease rc=$?"
 timeout 200 python tools/bench_svae.py > $OUT/bench_svae.json 2> $OUT/bench_svae.err; echo "svae rc=$?"
