@@ -147,6 +147,9 @@ struct rtx_engine {
     int opt_hop_values = 1;
     int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
+    uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
+    uint32_t hopk_seq = 0;
+    int opt_hop_kernels = 1;           // the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
     uint32_t hop_seq = 0;
     uint32_t hop_wrap = 0x7ffffff0u;   // the sequence restarts from zero here (option "hop_wrap": tests lower it)
@@ -867,6 +870,7 @@ int rtx_engine_destroy(rtx_engine* e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->hop_mem) (void)hipFree(e->hop_mem);
+    if (e->hopk_mem) (void)hipFree(e->hopk_mem);
     if (e->loss_mailbox) (void)hipHostFree(e->loss_mailbox);
     for (auto& kv : e->side_cache)
         if (kv.second.first) (void)hipStreamDestroy(kv.second.first);
@@ -1092,8 +1096,44 @@ static size_t dp_region_elems(const rtx_engine* e, const DpState& d, int t)
 
 // `to` continues only after everything enqueued on `from` so far: a write / wait pair of stream memory operations on word `slot` of
 // the engine's signal memory (monotonic sequence numbers, compare >=), or an event record + wait
+// Third form (round 5, option "hop_kernels"): the dependency as two ONE-WAVE KERNELS -- k_hop_set on the producing stream stores a
+// sequence number (agent-scope release) behind the kernels it follows, k_hop_wait on the consuming stream spins on it (acquire,
+// s_sleep between polls, bounded) in front of the kernels that need the data.  A kernel boundary on each side: the producers'
+// end-of-kernel release has completed before k_hop_set runs (in-order queue), the consumers' start-of-kernel acquire comes after
+// k_hop_wait has seen the number.  No stream memory operation, no event: those are packets that make the command processor release
+// to SYSTEM scope (the signal word is host-visible memory) and cost the stream 6-9 us each (profiles/r4_step_timeline.txt: the
+// gaps behind k_dlogits and between two steps).
+__global__ void k_hop_set(uint32_t* word, uint32_t v)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_hop_wait(const uint32_t* word, uint32_t v, uint32_t* stuck)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {   // 4 s: the producer is gone; do not hang the device
+            if (stuck) *stuck = v;
+            __builtin_trap();
+        }
+    }
+}
+
 static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hipEvent_t ev, int slot)
 {
+    if (e->opt_hop_kernels) {
+        if (!e->hopk_mem) {
+            RTX_HIP(hipMalloc((void**)&e->hopk_mem, 64));
+            RTX_HIP(hipMemset(e->hopk_mem, 0, 64));
+            RTX_HIP(hipStreamSynchronize(nullptr));
+        }
+        const uint32_t v = ++e->hopk_seq;       // (compared as a signed difference: wraps after 2^31 hops without any reset)
+        hipLaunchKernelGGL(k_hop_set, dim3(1), dim3(64), 0, from, e->hopk_mem + slot, v);
+        hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, to, e->hopk_mem + slot, v, e->hopk_mem + 8 + slot);
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
+    }
     if (e->opt_hop_values) {
         if (!e->hop_mem) {
             int dev = 0, ok = 0;
@@ -1943,6 +1983,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
     else if (k == "logits16") e->opt_logits16 = value != 0;
     else if (k == "hop_values") e->opt_hop_values = value != 0;
+    else if (k == "hop_kernels") e->opt_hop_kernels = value != 0;
     else if (k == "hop_wrap") {
         RTX_CHECK(value >= 2, RTX_EINVAL, "set_option: hop_wrap must be >= 2");
         e->hop_wrap = (uint32_t)value;
@@ -2004,6 +2045,7 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "lse_fuse") *value = e->opt_lse_fuse;
     else if (k == "logits16") *value = e->opt_logits16;
     else if (k == "hop_values") *value = e->opt_hop_values;
+    else if (k == "hop_kernels") *value = e->opt_hop_kernels;
     else if (k == "gather_scatter") *value = e->opt_gather_scatter;
     else if (k == "dp_shard_min_elems") *value = e->opt_dp_shard_min_elems;
     else if (k == "dp_bytes_all_reduce") *value = (int32_t)std::min<int64_t>(e->dp.st_all_reduce, INT32_MAX);       // per rank, last step
