@@ -145,11 +145,13 @@ struct rtx_engine {
     // record / wait: -3 us per step in three alternating pairs (283.7 / 280.1 / 276.0 -> 280.1 / 276.8 / 273.2,
     // profiles/r4_hop_values.txt); where the device cannot wait on a value the events remain
     int opt_hop_values = 1;
+    int opt_f32_tail_split = 1;        // float32 parity mode: the last partial wave of a big weight-gradient product split over K (RtxGemm::tail_*)
+    int n_cus = 256;                   // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
     uint32_t hopk_seq = 0;
-    int opt_hop_kernels = 1;           // the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
+    int opt_hop_kernels = 0;           // (measured: no gain, a one-wave kernel costs its stream 5-6 us like the packet it replaces) the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
     uint32_t hop_seq = 0;
     uint32_t hop_wrap = 0x7ffffff0u;   // the sequence restarts from zero here (option "hop_wrap": tests lower it)
@@ -335,7 +337,7 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form 
         if (pl.regstage && s >= 8) s &= ~7;   // register-staged kernel: every XCD owns whole splits
         // data-gradient products: the slabs are summed by a post kernel beside the streaming weight kernel, where every slab
         // costs: 16 slabs instead of 25 at the ml-20m shape is 5 us per step (286 vs 291; 12: 288, 8: 292)
-        if (form == RTX_FORM_NN && s > 16) s = 16;
+        if (form == RTX_FORM_NN && s > 16 && e->bf16) s = 16;   // (float32: one stream, nothing beside the post kernel -- fill the chip)
         if (pl.k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
         if (pl.k_slices >= 64 && form == RTX_FORM_NT && e->opt_splitk_fwd > 0) s = e->opt_splitk_fwd;
         const int max_s = pl.k_slices / 2 > 0 ? pl.k_slices / 2 : 1;
@@ -809,6 +811,11 @@ int rtx_engine_create(const rtx_cfg* cfg, rtx_engine** out)
               hipGetErrorString(h));
     rtx_engine* e = new rtx_engine();
     e->cfg = *cfg;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) e->n_cus = cus;
+        (void)hipGetLastError();
+    }
     int rc = build_layers(*cfg, e->L);
     if (rc) { delete e; return rc; }
     e->NL = (int)e->L.size();
@@ -1367,6 +1374,24 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             g.splits = sp; g.C = e->Cacc; g.ldc = l.inp; g.slab_stride = (long)l.outp * l.inp; g.gbias = nullptr;
             RTX_TRY(rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, ws));
             return rtx_launch_dw_slab_reduce(e->Cacc, sp, g.slab_stride, g.ldc, l.out, l.in, gW, gb, ws);
+        }
+        // The last partial wave (round 5): 158 x 5 = 790 tiles on 256 CUs are three full rounds and a fourth that is 9 % full.  The tiles
+        // beyond the last full round (along the long tile dimension) go to extra workgroups, 8 per tile over K, appended to the same
+        // launch; a small fixed-order reduction writes their gradient (gemm_f32.hip, RtxGemm::tail_*).
+        if (e->opt_f32_tail_split && tiles > e->n_cus && g.k_slices >= 16) {
+            const int long_tiles = std::max(g.m_tiles, g.n_tiles), short_tiles = std::min(g.m_tiles, g.n_tiles);
+            const int t0 = (tiles / e->n_cus * e->n_cus) / short_tiles;       // tiles before it fill whole rounds
+            const int tail_tiles = (long_tiles - t0) * short_tiles;
+            const bool m_long = g.m_tiles > g.n_tiles;
+            const int S = 8;
+            const long rows = m_long ? (long)(long_tiles - t0) * 128 : (long)l.outp, cols = m_long ? (long)l.inp : (long)(long_tiles - t0) * 128;
+            // worth it when the last round is less than half full, and the slabs fit the scratch
+            if (g.m_tiles != g.n_tiles && t0 > 0 && tail_tiles > 0 && tail_tiles * 2 <= e->n_cus && (size_t)S * rows * cols <= e->cacc_elems) {
+                g.tail_t0 = t0; g.tail_splits = S; g.tail_C = e->Cacc; g.tail_ldc = cols; g.tail_slab_stride = rows * cols;
+                RTX_TRY(rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws));
+                return rtx_launch_tail_reduce(e->Cacc, S, g.tail_slab_stride, cols, (int)rows, (int)cols, m_long ? t0 * 128 : 0, m_long ? 0 : t0 * 128,
+                                              l.out, l.in, g.C, g.gbias, ws);
+            }
         }
         return rtx_gemm_f32_km_launch(g, RTX_EPI_GRAD, ws);
     };
@@ -1989,6 +2014,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
         e->hop_wrap = (uint32_t)value;
     }
     else if (k == "f32_dw_split") e->opt_f32_dw_split = value != 0;
+    else if (k == "f32_tail_split") e->opt_f32_tail_split = value != 0;
     else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
     else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
     else if (k == "dp_shard_min_elems") {

@@ -32,9 +32,17 @@ __global__ __launch_bounds__(256, 2) void rtx_gemm_f32_km(const RtxGemm p)
     const int r = lane & 31, g = lane >> 5;
 
     int tm, tn, split;
+    bool tail = false;
     {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-        if (p.splits > 1) {
+        if (p.tail_splits > 1 && L >= p.tail_block0) {
+            // an extra workgroup of the last partial wave: tile t of the tail region, K piece `split`
+            tail = true;
+            const int idx = L - p.tail_block0, t = idx / p.tail_splits;
+            split = idx - t * p.tail_splits;
+            if (p.m_tiles > p.n_tiles) { tm = p.tail_t0 + t / p.n_tiles; tn = t % p.n_tiles; if (tm >= p.m_tiles) return; }
+            else { tn = p.tail_t0 + t / p.m_tiles; tm = t % p.m_tiles; if (tn >= p.n_tiles) return; }
+        } else if (p.splits > 1) {
             const int tiles = p.m_tiles * p.n_tiles;
             split = xcd + 8 * (j / tiles);
             if (split >= p.splits) return;
@@ -52,8 +60,9 @@ __global__ __launch_bounds__(256, 2) void rtx_gemm_f32_km(const RtxGemm p)
             tn = j % p.n_tiles;
             if (tm >= p.m_tiles) return;
         }
+        if (!tail && p.tail_splits > 1 && (p.m_tiles > p.n_tiles ? tm : tn) >= p.tail_t0) return;   // the tail's tiles belong to the extra workgroups
     }
-    const int per = (p.k_slices + p.splits - 1) / p.splits;
+    const int per = tail ? (p.k_slices + p.tail_splits - 1) / p.tail_splits : (p.k_slices + p.splits - 1) / p.splits;
     const int ks0 = split * per;
     const int nk = min(ks0 + per, p.k_slices) - ks0;
 
@@ -136,6 +145,19 @@ __global__ __launch_bounds__(256, 2) void rtx_gemm_f32_km(const RtxGemm p)
         }
     }
 
+    if (EPI == RTX_EPI_GRAD && tail) {
+        // partial sums of a tail tile, tile-local coordinates of the tail region
+        const int lr = (p.m_tiles > p.n_tiles ? (tm - p.tail_t0) : tm) * 128 + wm * 64 + 4 * g;
+        const int lc = (p.m_tiles > p.n_tiles ? tn : (tn - p.tail_t0)) * 128 + wn * 64 + r;
+        float* tp = p.tail_C + (size_t)split * p.tail_slab_stride + (size_t)lr * p.tail_ldc + lc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tp[(long)(i * 32 + (e & 3) + 8 * (e >> 2)) * p.tail_ldc + j * 32] = acc[i][j][e];
+        return;
+    }
     // epilogue (as gemm.hip): C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int row_base = tm * 128 + wm * 64 + 4 * g;
     const int col_base = tn * 128 + wn * 64 + r;
@@ -179,7 +201,18 @@ int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream)
     if (g.splits > 1) { groups = g.splits; gsize = tiles; }
     else if (g.m_tiles <= g.n_tiles) { groups = g.n_tiles; gsize = g.m_tiles; }
     else { groups = g.m_tiles; gsize = g.n_tiles; }
-    const dim3 grid((unsigned)(8 * ((groups + 7) / 8) * gsize)), block(256);
+    unsigned n_blocks = (unsigned)(8 * ((groups + 7) / 8) * gsize);
+    RtxGemm gt = g;
+    if (g.tail_splits > 1) {
+        RTX_CHECK(g.splits == 1 && epilogue == RTX_EPI_GRAD && g.tail_C && g.tail_t0 >= 0 && g.tail_t0 < groups, RTX_EINVAL,
+                  "gemm_f32_km: the tail split needs a single-pass gradient product and a tail start inside the long tile dimension");
+        RTX_CHECK((g.tail_splits - 1) * ((g.k_slices + g.tail_splits - 1) / g.tail_splits) < g.k_slices, RTX_EINVAL,
+                  "gemm_f32_km: %d tail splits leave an empty split of %d slices", g.tail_splits, g.k_slices);
+        gt.tail_block0 = (int)n_blocks;
+        n_blocks += (unsigned)((groups - g.tail_t0) * gsize * g.tail_splits);
+    }
+    const RtxGemm& gg = gt;
+    const dim3 grid(n_blocks), block(256);
     constexpr int LDS_NN = 2 * (128 * GF_ROW + 32 * 512), LDS_TN = 2 * (32 * 512 + 32 * 512);
     static bool configured = false;
     if (!configured) {
@@ -190,11 +223,11 @@ int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream)
         configured = true;
     }
     if (g.form == RTX_FORM_NN) {
-        if (epilogue == RTX_EPI_STORE) hipLaunchKernelGGL((rtx_gemm_f32_km<0, RTX_EPI_STORE>), grid, block, LDS_NN, stream, g);
-        else hipLaunchKernelGGL((rtx_gemm_f32_km<0, RTX_EPI_GRAD>), grid, block, LDS_NN, stream, g);
+        if (epilogue == RTX_EPI_STORE) hipLaunchKernelGGL((rtx_gemm_f32_km<0, RTX_EPI_STORE>), grid, block, LDS_NN, stream, gg);
+        else hipLaunchKernelGGL((rtx_gemm_f32_km<0, RTX_EPI_GRAD>), grid, block, LDS_NN, stream, gg);
     } else {
-        if (epilogue == RTX_EPI_STORE) hipLaunchKernelGGL((rtx_gemm_f32_km<1, RTX_EPI_STORE>), grid, block, LDS_TN, stream, g);
-        else hipLaunchKernelGGL((rtx_gemm_f32_km<1, RTX_EPI_GRAD>), grid, block, LDS_TN, stream, g);
+        if (epilogue == RTX_EPI_STORE) hipLaunchKernelGGL((rtx_gemm_f32_km<1, RTX_EPI_STORE>), grid, block, LDS_TN, stream, gg);
+        else hipLaunchKernelGGL((rtx_gemm_f32_km<1, RTX_EPI_GRAD>), grid, block, LDS_TN, stream, gg);
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;

@@ -1332,6 +1332,34 @@ __global__ __launch_bounds__(256) void k_dw_slab_reduce(const float* __restrict_
     else if (gbias) gbias[m] = v;
 }
 
+// the tail region of a float32 gradient product (gemm_f32_km, RtxGemm::tail_*): [splits][rows][ldc] partial sums in tile-local
+// coordinates -> rows row0.., columns col0.. of gW [M_real][N_real] (column N_real of the product = the bias gradient); fixed order
+__global__ __launch_bounds__(256) void k_tail_reduce(const float* __restrict__ C, int splits, long slab_stride, long ldc, int rows, int cols, int row0,
+                                                     int col0, int M_real, int N_real, float* __restrict__ gW, float* __restrict__ gbias)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int m = (int)(i / cols), n = (int)(i - (long)m * cols);
+    const int gm = row0 + m, gn = col0 + n;
+    if (gm >= M_real || gn > N_real) return;
+    const float* c = C + (size_t)m * ldc + n;
+    float v = 0.f;
+    for (int s2 = 0; s2 < splits; ++s2) v += c[(size_t)s2 * slab_stride];
+    if (gn < N_real) gW[(size_t)gm * N_real + gn] = v;
+    else if (gbias) gbias[gm] = v;
+}
+
+int rtx_launch_tail_reduce(const float* C, int splits, long slab_stride, long ldc, int rows, int cols, int row0, int col0, int M_real, int N_real,
+                           float* gW, float* gbias, hipStream_t stream)
+{
+    const long total = (long)rows * cols;
+    if (total <= 0) return RTX_OK;
+    hipLaunchKernelGGL(k_tail_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, C, splits, slab_stride, ldc, rows, cols, row0, col0,
+                       M_real, N_real, gW, gbias);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
 int rtx_launch_dw_slab_reduce(const float* C, int splits, long slab_stride, long ldc, int M_real, int N_real, float* gW, float* gbias, hipStream_t stream)
 {
     const long total = (long)M_real * (N_real + 1);

@@ -76,6 +76,14 @@ struct RtxGemm {
                          //   still taken from the float32 accumulators
     int xcd_block;       // gemm_dma, splits == 1: 1 = every XCD works on 8 x 4 blocks of tiles (12 operand panels per 32 tiles in its
                          //   L2 instead of the strip order's 18 or 33)
+    // gemm_f32_km, splits == 1, RTX_EPI_GRAD (round 5): the LAST partial wave of tiles.  790 tiles on 256 CUs are 3 full rounds and a
+    // fourth one that is 9 % full -- a quarter of the launch's time for 3 % of its work.  Tiles from index `tail_t0` on along the
+    // LONG tile dimension are therefore not computed by the main grid but by `tail_splits` extra workgroups each (appended to the
+    // grid), every one over 1 / tail_splits of K; their partial sums go to tail_C ([split][rows][tail_ldc], tile-local coordinates)
+    // and a small reduction (rtx_launch_tail_reduce, fixed order) writes the gradient.  tail_splits <= 1: off.
+    int tail_t0, tail_splits, tail_block0;
+    float* tail_C;
+    long tail_ldc, tail_slab_stride;
 };
 
 // operand element type.  RTX_DT_F32 = 0 and RTX_DT_BF16 = 1 keep the meaning of the former `is_bf16` flag.

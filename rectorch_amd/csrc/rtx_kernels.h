@@ -256,6 +256,8 @@ struct RtxAdamArgs {
 int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream);
 int rtx_launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t stream);
 // float32 parity mode: split-K slabs [splits][M_pad][ldc] of a small weight-gradient product -> gW [M_real][N_real], gbias [M_real] (column N_real)
+int rtx_launch_tail_reduce(const float* C, int splits, long slab_stride, long ldc, int rows, int cols, int row0, int col0, int M_real, int N_real,
+                           float* gW, float* gbias, hipStream_t stream);
 int rtx_launch_dw_slab_reduce(const float* C, int splits, long slab_stride, long ldc, int M_real, int N_real, float* gW, float* gbias, hipStream_t stream);
 int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, float* sumsq, hipStream_t stream);
 
