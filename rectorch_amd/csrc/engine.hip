@@ -145,7 +145,7 @@ struct rtx_engine {
     // record / wait: -3 us per step in three alternating pairs (283.7 / 280.1 / 276.0 -> 280.1 / 276.8 / 273.2,
     // profiles/r4_hop_values.txt); where the device cannot wait on a value the events remain
     int opt_hop_values = 1;
-    int opt_f32_tail_split = 1;        // float32 parity mode: the last partial wave of a big weight-gradient product split over K (RtxGemm::tail_*)
+    int opt_f32_tail_split = 0;        // (measured: 963 vs 951 us/step, profiles/r5_fp32_tail_split.txt -- off) float32 parity mode: the last partial wave of a big weight-gradient product split over K (RtxGemm::tail_*)
     int n_cus = 256;                   // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
