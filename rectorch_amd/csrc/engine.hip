@@ -147,6 +147,7 @@ struct rtx_engine {
     int opt_hop_values = 1;
     int opt_f32_tail_split = 0;        // (measured: 963 vs 951 us/step, profiles/r5_fp32_tail_split.txt -- off) float32 parity mode: the last partial wave of a big weight-gradient product split over K (RtxGemm::tail_*)
     int n_cus = 256;                   // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    int opt_f32_adam_overlap = 1;      // float32 train step: the decoder matrix's Adam pass on the side stream under the remaining products
     int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
@@ -1205,7 +1206,7 @@ static int prefetch_next(rtx_engine* e)
 }
 
 static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum,
-                           rtx_layer_cb cb, void* user, hipStream_t st, bool fuse, DpState* dp = nullptr)
+                           rtx_layer_cb cb, void* user, hipStream_t st, bool fuse, DpState* dp = nullptr, bool adam_inline = false)
 {
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step, RTX_EINVAL, "loss_grads: step is NULL");
@@ -1236,6 +1237,16 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         }
     }
     if (two && !e->side_concurrent) two = false;   // no stream that really runs beside the caller's: one stream, no event traffic
+    // float32 train step: Adam inside the call, the big last layer's pass on the side stream (see below)
+    bool adam_side = adam_inline && !fuse && !dp && !cb && !e->bf16 && e->opt_f32_adam_overlap && NL >= 2 && layer_is_big(e->L[NL - 1]);
+    if (adam_side) {
+        if (!e->side || e->side_for != st) RTX_TRY(make_side_stream(e, st));
+        if (!e->ev_done) {
+            for (int l = 0; l < NL + 1; ++l) RTX_HIP(hipEventCreateWithFlags(&e->ev_d[l], hipEventDisableTiming));
+            RTX_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+        }
+        if (!e->side_concurrent) adam_side = false;
+    }
     const int main_li = (two && fuse && e->opt_in_on_main && NL >= 2 && layer_is_big(e->L[0]) && layer_is_big(e->L[NL - 1]) && layer_fusable(e, e->L[0])) ? 0 : -1;
     if (e->pre.valid) {
         // the batch of this step was announced one step ago and gathered on the side stream under that step's last weight
@@ -1368,6 +1379,8 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         const int tiles = g.m_tiles * g.n_tiles;
         int sp = std::min(8, g.k_slices / 2);
         while (sp > 1 && (sp - 1) * ((g.k_slices + sp - 1) / sp) >= g.k_slices) --sp;   // no empty split
+        // (Cacc is shared with the data-gradient products: safe because the float32 step runs every PRODUCT on the caller's stream --
+        //  the only kernel it ever puts on the side stream is k_adam, which does not touch the scratch)
         if (e->opt_f32_dw_split && tiles <= 64 && sp >= 2 && (size_t)sp * l.outp * l.inp <= e->cacc_elems) {
             float* gW = g.C;
             float* gb = g.gbias;
@@ -1561,6 +1574,17 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             }
         }
         if (!two) RTX_TRY(weight_grad(li, st));
+        if (adam_side && li == NL - 1) {
+            // float32 train step (round 5): the decoder matrix's Adam pass -- half of the optimizer's 690 MB, HBM-bound -- leaves for
+            // the side stream as soon as its gradient exists and runs under the remaining float32 products, which are MFMA-bound
+            // (its compute copy has no reader left in this step: the data gradient of this layer came first on this stream)
+            RTX_TRY(stream_dependency(e, st, e->side, e->ev_d[li], 0));
+            RtxAdamArgs a = {};
+            fill_adam_tensors(e, a, li, li + 1);
+            fill_adam_scalars(e, step, a, 2 * li);
+            ScopedTimer tm(e, "adam", e->side);
+            RTX_TRY(rtx_launch_adam(a, e->bf16, e->side));
+        }
         if (fuse && !layer_fusable(e, l)) {   // what is left for the multi-tensor Adam launch at the end of the step
             RtxAdamArgs one = {};
             fill_adam_tensors(e, one, li, li + 1);
@@ -1631,6 +1655,18 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             RTX_HIP(hipStreamWaitEvent(e->side, e->ev_d[NL], 0));
             rs = e->side;
         }
+    }
+    if (adam_inline && !fuse && !dp) {
+        // the rest of the optimizer on the caller's stream (everything when the side stream took nothing), then the join
+        RtxAdamArgs a = {};
+        fill_adam_tensors(e, a, 0, adam_side ? NL - 1 : NL);
+        fill_adam_scalars(e, step, a, 0);
+        {
+            TIMED("adam");
+            RTX_TRY(rtx_launch_adam(a, e->bf16, st));
+        }
+        if (adam_side) RTX_TRY(stream_dependency(e, e->side, st, e->ev_done, 1));
+        e->shadows_valid = true;
     }
     if (fuse) {
         if (rest.n > 0) {
@@ -1936,8 +1972,8 @@ int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step*
     RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "train_step: step count must be >= 1");
     if (e->bf16 && e->opt_fuse_adam)
         return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, true);
-    RTX_TRY(loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false));
-    return rtx_engine_apply_adam(e, step, stream);
+    // (float32, or bf16 with the fused optimizer switched off: Adam as launches of its own inside the same call)
+    return loss_grads_impl(e, batch, step, loss_out, loss_accum, nullptr, nullptr, (hipStream_t)stream, false, nullptr, true);
 }
 
 // The reference's train_batch ends in `return loss.item()` (models.py:835): the host needs THIS step's loss.  Draining the stream
@@ -2015,6 +2051,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     }
     else if (k == "f32_dw_split") e->opt_f32_dw_split = value != 0;
     else if (k == "f32_tail_split") e->opt_f32_tail_split = value != 0;
+    else if (k == "f32_adam_overlap") e->opt_f32_adam_overlap = value != 0;
     else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
     else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
     else if (k == "dp_shard_min_elems") {
