@@ -147,11 +147,12 @@ struct rtx_engine {
     int opt_hop_values = 1;
     int opt_f32_tail_split = 0;        // (measured: 963 vs 951 us/step, profiles/r5_fp32_tail_split.txt -- off) float32 parity mode: the last partial wave of a big weight-gradient product split over K (RtxGemm::tail_*)
     int n_cus = 256;                   // compute units of the device (hipDeviceAttributeMultiprocessorCount)
-    int opt_f32_adam_overlap = 1;      // float32 train step: the decoder matrix's Adam pass on the side stream under the remaining products
+    int opt_f32_adam_overlap = 0;      // (measured: 960.5 vs 960.7 us/step, no gain -- off; profiles/r5_fp32_tail_split.txt) float32 train step: the decoder matrix's Adam pass on the side stream under the remaining products
     int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
     uint32_t hopk_seq = 0;
+    int opt_hop_fold = 1;              // the step's fork (caller's stream -> side stream) folded into the data-gradient product (loss_grads_impl)
     int opt_hop_kernels = 0;           // (measured: no gain, a one-wave kernel costs its stream 5-6 us like the packet it replaces) the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
     uint32_t hop_seq = 0;
@@ -370,7 +371,7 @@ static size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
 }
 
 static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, int* splits_out,
-                        hipStream_t st)
+                        hipStream_t st, uint32_t* hop_word = nullptr, uint32_t hop_seq = 0)
 {
     const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, form);
     RtxGemm g = {};
@@ -381,6 +382,8 @@ static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const 
     RTX_CHECK((size_t)g.splits * Mp * Np <= e->cacc_elems, RTX_ESTATE, "internal: Cacc too small (%d x %d x %d)", g.splits, Mp, Np);
     *splits_out = g.splits;
     g.xcd_block = 1;   // (the launcher keeps the strip order for split-K and for grids under 8 x 4 tiles)
+    RTX_CHECK(!hop_word || !pl.regstage, RTX_ESTATE, "internal: a folded stream hop needs the LDS-DMA product");
+    g.hop_word = hop_word; g.hop_seq = hop_seq;
     if (!pl.regstage) return rtx_gemm_dma_launch(g, RTX_EPI_STORE, st);
     if (form == RTX_FORM_NT) return rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_STORE, st);
     return rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, st);
@@ -1121,21 +1124,27 @@ __global__ void k_hop_wait(const uint32_t* word, uint32_t v, uint32_t* stuck)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
     while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {   // 4 s: the producer is gone; do not hang the device
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // 20 s: the producer is gone; do not hang the device
             if (stuck) *stuck = v;
             __builtin_trap();
         }
     }
 }
 
+static int ensure_hopk(rtx_engine* e)
+{
+    if (!e->hopk_mem) {
+        RTX_HIP(hipMalloc((void**)&e->hopk_mem, 64));
+        RTX_HIP(hipMemset(e->hopk_mem, 0, 64));
+        RTX_HIP(hipStreamSynchronize(nullptr));
+    }
+    return RTX_OK;
+}
+
 static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hipEvent_t ev, int slot)
 {
     if (e->opt_hop_kernels) {
-        if (!e->hopk_mem) {
-            RTX_HIP(hipMalloc((void**)&e->hopk_mem, 64));
-            RTX_HIP(hipMemset(e->hopk_mem, 0, 64));
-            RTX_HIP(hipStreamSynchronize(nullptr));
-        }
+        RTX_TRY(ensure_hopk(e));
         const uint32_t v = ++e->hopk_seq;       // (compared as a signed difference: wraps after 2^31 hops without any reset)
         hipLaunchKernelGGL(k_hop_set, dim3(1), dim3(64), 0, from, e->hopk_mem + slot, v);
         hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, to, e->hopk_mem + slot, v, e->hopk_mem + 8 + slot);
@@ -1521,11 +1530,26 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         return RTX_OK;
     };
     const bool dp_side = dp && on_side(NL - 1);
+    bool fold_hop = false;          // this layer's fork is folded into its data-gradient product (below)
+    uint32_t fold_seq = 0;
     if (!two) RTX_TRY(reduce_loss(st));
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
         if (on_side(li)) {   // the long kernel first: it only needs D[li], which exists now
-            RTX_TRY(stream_dependency(e, st, e->side, e->ev_d[li], 0));
+            // The fork (round 5, "hop_fold"): the side stream waits in a one-wave kernel (k_hop_wait) for a number that the NEXT kernel
+            // of the caller's stream -- this layer's data-gradient product, which follows the producers of D[li] in order -- stores as
+            // its first instruction.  The caller's stream, which carries the step's critical path, gets no packet of its own: the
+            // 6-9 us gap behind k_dlogits (profiles/r4_step_timeline.txt) goes.
+            fold_hop = e->opt_hop_fold && e->bf16 && li > 0 && !(li < NL - 1 && l.WshT && e->opt_small_bwd) &&
+                       !plan_gemm(e, Bp, l.inp, l.outp, RTX_FORM_NN).regstage;
+            if (fold_hop) {
+                RTX_TRY(ensure_hopk(e));
+                fold_seq = ++e->hopk_seq;
+                hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, e->side, e->hopk_mem + 2, fold_seq, e->hopk_mem + 10);
+                RTX_HIP(hipGetLastError());
+            } else {
+                RTX_TRY(stream_dependency(e, st, e->side, e->ev_d[li], 0));
+            }
             RTX_TRY(weight_grad(li, e->side));
             if (dp) {   // bucket A: the decoder matrix's exchange and optimizer pass run beside the chain; the loss sum rides along
                 RTX_TRY(reduce_loss(e->side));
@@ -1553,7 +1577,8 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             int splits = 1;
             {
                 TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
-                RTX_TRY(gemm_to_cacc(e, RTX_FORM_NN, l.D, l.outp, l.Wsh, l.inp, Bp, l.inp, l.outp, &splits, st));
+                RTX_TRY(gemm_to_cacc(e, RTX_FORM_NN, l.D, l.outp, l.Wsh, l.inp, Bp, l.inp, l.outp, &splits, st, fold_hop ? e->hopk_mem + 2 : nullptr, fold_seq));
+                fold_hop = false;
             }
             Layer& pv = e->L[li - 1];
             if (e->vae && li == e->cfg.n_enc) {
@@ -2045,6 +2070,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "logits16") e->opt_logits16 = value != 0;
     else if (k == "hop_values") e->opt_hop_values = value != 0;
     else if (k == "hop_kernels") e->opt_hop_kernels = value != 0;
+    else if (k == "hop_fold") e->opt_hop_fold = value != 0;
     else if (k == "hop_wrap") {
         RTX_CHECK(value >= 2, RTX_EINVAL, "set_option: hop_wrap must be >= 2");
         e->hop_wrap = (uint32_t)value;
@@ -2109,6 +2135,7 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "logits16") *value = e->opt_logits16;
     else if (k == "hop_values") *value = e->opt_hop_values;
     else if (k == "hop_kernels") *value = e->opt_hop_kernels;
+    else if (k == "hop_fold") *value = e->opt_hop_fold;
     else if (k == "gather_scatter") *value = e->opt_gather_scatter;
     else if (k == "dp_shard_min_elems") *value = e->opt_dp_shard_min_elems;
     else if (k == "dp_bytes_all_reduce") *value = (int32_t)std::min<int64_t>(e->dp.st_all_reduce, INT32_MAX);       // per rank, last step

@@ -106,6 +106,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64, (WM * WN + LW + 3) / 4) void rt
 
     const unsigned long long t_entry = __builtin_readcyclecounter(), r_entry = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.hop_word && blockIdx.x == 0 && tid == 0) __hip_atomic_store(p.hop_word, p.hop_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int lw = LW ? wave - NW : wave;   // index among the DMA-issuing waves
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, g = lane >> 5;

@@ -81,6 +81,13 @@ struct RtxGemm {
     // LONG tile dimension are therefore not computed by the main grid but by `tail_splits` extra workgroups each (appended to the
     // grid), every one over 1 / tail_splits of K; their partial sums go to tail_C ([split][rows][tail_ldc], tile-local coordinates)
     // and a small reduction (rtx_launch_tail_reduce, fixed order) writes the gradient.  tail_splits <= 1: off.
+    // gemm_dma (round 5): when set, thread 0 of workgroup 0 stores hop_seq to *hop_word (agent scope) before anything else -- the
+    // "producer side" of a cross-stream dependency folded into the first kernel that FOLLOWS the producers on their stream: by the
+    // time any workgroup of this kernel runs, the kernels before it have completed and released (in-order queue), so a consumer that
+    // sees the number on another stream (k_hop_wait) may start kernels that read their output.  Costs the stream nothing, where a
+    // stream memory operation or an event costs it 6-9 us (engine.hip: stream_dependency)
+    unsigned* hop_word;
+    unsigned hop_seq;
     int tail_t0, tail_splits, tail_block0;
     float* tail_C;
     long tail_ldc, tail_slab_stride;

@@ -1664,7 +1664,9 @@ def test_stream_value_sequence_restart():
     """round 4: the step's two cross-stream dependencies are hipStreamWriteValue32 / hipStreamWaitValue32 pairs with a growing
     sequence number; long before 2^31 both streams drain and the words restart from zero.  With the restart forced every second
     step ("hop_wrap" = 3), with the plain value form, with events instead ("hop_values" = 0) and with round 5's third form -- the
-    dependency as two one-wave kernels (k_hop_set / k_hop_wait, "hop_kernels" = 1; measured, not faster, not the default) -- eight training steps end in bit-identical
+    dependency as two one-wave kernels (k_hop_set / k_hop_wait, "hop_kernels" = 1; measured, not faster, not the default) and the
+    default: the fork folded into the data-gradient product ("hop_fold" = 1: that kernel's first instruction stores the number the
+    side stream's k_hop_wait spins on; the caller's stream gets no packet of its own) -- eight training steps end in bit-identical
     parameters and losses.  The network is big enough (2200 x 512 > 2^20 elements) for the decoder matrix's kernel to run on the
     side stream, so both hops of the step carry a real dependency."""
     from rectorch_amd.utils import synth_interactions, hash_state_dict
@@ -1673,7 +1675,7 @@ def test_stream_value_sequence_restart():
     X = synth_interactions(400, I, mu=3.0, sigma=1.0, dmax=I // 3, seed=4)
     sd = hash_state_dict([I, H, L], [L, H, I], "vae", 11, bias_std=0.1)
     outs = []
-    for opts in ({"hop_wrap": 3}, {}, {"hop_values": 0}, {"hop_kernels": 1}):
+    for opts in ({"hop_wrap": 3, "hop_fold": 0}, {"hop_fold": 0}, {"hop_values": 0, "hop_fold": 0}, {"hop_kernels": 1, "hop_fold": 0}, {}):
         net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, numerics="bf16", predict_numerics="bf16")
         st, _, m, v = model._ensure_train_state()
         eng = net.rtx_engine("bf16", 100, train_buffers=(st.grads, m, v))
