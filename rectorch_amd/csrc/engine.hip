@@ -1532,6 +1532,15 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     const bool dp_side = dp && on_side(NL - 1);
     bool fold_hop = false;          // this layer's fork is folded into its data-gradient product (below)
     uint32_t fold_seq = 0;
+    // what the side stream does for layer li once D[li] is there: the long weight kernel, and under data parallelism bucket A
+    auto side_work = [&](int li) -> int {
+        RTX_TRY(weight_grad(li, e->side));
+        if (dp) {   // bucket A: the decoder matrix's exchange and optimizer pass run beside the chain; the loss sum rides along
+            RTX_TRY(reduce_loss(e->side));
+            RTX_TRY(dp_bucket(li, li + 1, e->side, true));
+        }
+        return RTX_OK;
+    };
     if (!two) RTX_TRY(reduce_loss(st));
     for (int li = NL - 1; li >= 0; --li) {
         Layer& l = e->L[li];
@@ -1540,20 +1549,17 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             // of the caller's stream -- this layer's data-gradient product, which follows the producers of D[li] in order -- stores as
             // its first instruction.  The caller's stream, which carries the step's critical path, gets no packet of its own: the
             // 6-9 us gap behind k_dlogits (profiles/r4_step_timeline.txt) goes.
+            // The number is stored by a kernel that is enqueued AFTER this point, so the side stream's work is enqueued behind it
+            // (side_work below): a host that blocks on the side stream in between -- the gloo test transport drains the device inside
+            // its collectives -- would otherwise wait for a number nobody has been told to write yet.
             fold_hop = e->opt_hop_fold && e->bf16 && li > 0 && !(li < NL - 1 && l.WshT && e->opt_small_bwd) &&
                        !plan_gemm(e, Bp, l.inp, l.outp, RTX_FORM_NN).regstage;
             if (fold_hop) {
                 RTX_TRY(ensure_hopk(e));
                 fold_seq = ++e->hopk_seq;
-                hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, e->side, e->hopk_mem + 2, fold_seq, e->hopk_mem + 10);
-                RTX_HIP(hipGetLastError());
             } else {
                 RTX_TRY(stream_dependency(e, st, e->side, e->ev_d[li], 0));
-            }
-            RTX_TRY(weight_grad(li, e->side));
-            if (dp) {   // bucket A: the decoder matrix's exchange and optimizer pass run beside the chain; the loss sum rides along
-                RTX_TRY(reduce_loss(e->side));
-                RTX_TRY(dp_bucket(li, li + 1, e->side, true));
+                RTX_TRY(side_work(li));
             }
         }
         // data gradient: dA[Bp][inp] = D[Bp][outp] x Wsh[outp][inp]   (Wsh read K-major).  On ONE stream it must come before
@@ -1578,7 +1584,12 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             {
                 TIMED(li == NL - 1 ? "gemm_dX_out" : "gemm_dX_hidden");
                 RTX_TRY(gemm_to_cacc(e, RTX_FORM_NN, l.D, l.outp, l.Wsh, l.inp, Bp, l.inp, l.outp, &splits, st, fold_hop ? e->hopk_mem + 2 : nullptr, fold_seq));
-                fold_hop = false;
+                if (fold_hop) {   // the product that stores the number is enqueued: now the side stream's wait and its work
+                    fold_hop = false;
+                    hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, e->side, e->hopk_mem + 2, fold_seq, e->hopk_mem + 10);
+                    RTX_HIP(hipGetLastError());
+                    RTX_TRY(side_work(li));
+                }
             }
             Layer& pv = e->L[li - 1];
             if (e->vae && li == e->cfg.n_enc) {
