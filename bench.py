@@ -93,6 +93,8 @@ def parse():
                          "kernel's source is byte-for-byte the profiled one (sha256), else traffic is null")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (train_batch API, sparse first layer; N > 1: the replicated all-reduce A/B)")
+    ap.add_argument("--no-defer-join", action="store_true",
+                    help="every step ends with the caller's stream waiting for the engine's side stream (rounds 1-4)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="every step gathers its own batch at its head (rounds 1-4) instead of announcing the next one to the engine")
     ap.add_argument("--first-layer", default="dense", choices=["dense", "sparse"],
@@ -360,11 +362,12 @@ def main():
     def run(n, start):
         # as MultiVAE.train_epoch does with the resident sampler: every step announces the batch after it, which the engine gathers
         # on its side stream under the step's last weight kernel (single GPU; rtx_engine_set_next_batch).  Every step still pays
-        # for one gather: step k's launch carries batch k + 1's.
+        # for one gather: step k's launch carries batch k + 1's.  Like train_epoch, the steps leave the join with the engine's side
+        # stream to the next step (RTX_STEP_DEFER_JOIN); the window's closing torch.cuda.synchronize() drains every stream.
         for i in range(n):
             k = start + i
             model._fused_step(batches[k % len(batches)], None, want_loss=False,
-                              next_x=None if args.no_prefetch else batches[(k + 1) % len(batches)])
+                              next_x=None if args.no_prefetch else batches[(k + 1) % len(batches)], defer_join=not args.no_defer_join)
 
     st_, _, m_, v_ = model._ensure_train_state()        # the engine exists before its first step: some knobs must be set by then
     eng0 = net.rtx_engine(args.numerics, B, train_buffers=(st_.grads, m_, v_))

@@ -89,6 +89,14 @@ typedef struct {
  * data-parallel exchange sends (the float32 gradient buffers are not touched, no cast pass follows); the optimizer then reads
  * the reduced bf16 gradients (rtx_engine_apply_adam_layers / _rows with their grads_bf16 arguments) */
 #define RTX_STEP_GRADS_BF16 8
+/* ABI 7 -- rtx_engine_train_step (bf16, single GPU): do NOT make the caller's stream wait for the engine's side stream at the end
+ * of the step.  The caller promises not to touch anything the step produces outside the engine (parameters, optimizer state, the
+ * loss buffers) on any stream before its next call into this engine or rtx_engine_join(e, stream) -- every engine entry point
+ * that takes a stream resolves the open join first; a following training step that starts from a prefetched batch
+ * (rtx_engine_set_next_batch) resolves it INSIDE its first kernel, so two steps follow each other on the caller's stream without
+ * a wait packet between them.  What an epoch loop wants (rectorch/models.py:409-419); train_batch's float (rtx_engine_wait_loss)
+ * needs no join. */
+#define RTX_STEP_DEFER_JOIN 16
 
 /* called on the host right after the kernels producing the gradients of layer `layer` (its W and b)
  * have been enqueued; layers complete in reverse order (last decoder layer first).  A data-parallel
@@ -252,6 +260,9 @@ int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double t
  * cancels.  bf16 numerics, resident CSR batches, single-GPU fused step (the data-parallel step's side stream is busy with the
  * exchange).  The reference densifies every batch on the host (samplers.py:99-100). */
 int rtx_engine_set_next_batch(rtx_engine* e, const rtx_batch* next, const rtx_step* next_step);
+/* resolves a join left open by a step flagged RTX_STEP_DEFER_JOIN: `stream` continues only after everything that step put on
+ * the engine's side stream (no-op when nothing is open) */
+int rtx_engine_join(rtx_engine* e, void* stream);
 /* both of the above: one full train_batch */
 int rtx_engine_train_step(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out,
                           float* loss_accum, void* stream);

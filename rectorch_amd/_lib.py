@@ -19,6 +19,7 @@ RTX_FP32, RTX_BF16 = 0, 1
 RTX_STEP_KEEP_GRADS = 1
 RTX_STEP_NO_REG_IN_LOSS = 2
 RTX_STEP_GRADS_BF16 = 8
+RTX_STEP_DEFER_JOIN = 16
 NUMERICS = {"fp32": RTX_FP32, "bf16": RTX_BF16}
 
 
@@ -112,6 +113,7 @@ SIGNATURES = {
     "rtx_cast_f32_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "rtx_engine_train_step": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step), _P, _P, _P]),
     "rtx_engine_set_next_batch": (C.c_int, [_P, C.POINTER(Batch), C.POINTER(Step)]),
+    "rtx_engine_join": (C.c_int, [_P, _P]),
     "rtx_engine_loss_mailbox": (C.c_int, [_P, C.c_int32]),
     "rtx_engine_wait_loss": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_float), C.c_double]),
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),

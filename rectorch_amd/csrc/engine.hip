@@ -152,6 +152,11 @@ struct rtx_engine {
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
     uint32_t hopk_seq = 0;
+    // a step flagged RTX_STEP_DEFER_JOIN ends with a k_hop_set on the side stream instead of a wait on the caller's: the NEXT use of
+    // the engine on a stream resolves it (resolve_join) -- folded into the first-layer product of the next training step when that
+    // step starts from a prefetched batch image, as a one-wave k_hop_wait otherwise
+    bool join_pending = false, join_fold = false;
+    uint32_t join_seq = 0;
     int opt_hop_fold = 1;              // the step's fork (caller's stream -> side stream) folded into the data-gradient product (loss_grads_impl)
     int opt_hop_kernels = 0;           // (measured: no gain, a one-wave kernel costs its stream 5-6 us like the packet it replaces) the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
@@ -371,7 +376,7 @@ static size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
 }
 
 static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const void* B, long ldb, int Mp, int Np, int Kp, int* splits_out,
-                        hipStream_t st, uint32_t* hop_word = nullptr, uint32_t hop_seq = 0)
+                        hipStream_t st, uint32_t* hop_word = nullptr, uint32_t hop_seq = 0, const uint32_t* wait_word = nullptr, uint32_t wait_seq = 0)
 {
     const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, form);
     RtxGemm g = {};
@@ -384,6 +389,8 @@ static int gemm_to_cacc(rtx_engine* e, int form, const void* A, long lda, const 
     g.xcd_block = 1;   // (the launcher keeps the strip order for split-K and for grids under 8 x 4 tiles)
     RTX_CHECK(!hop_word || !pl.regstage, RTX_ESTATE, "internal: a folded stream hop needs the LDS-DMA product");
     g.hop_word = hop_word; g.hop_seq = hop_seq;
+    RTX_CHECK(!wait_word || e->bf16, RTX_ESTATE, "internal: a folded join needs a bf16 product");
+    g.wait_word = wait_word; g.wait_seq = wait_seq;
     if (!pl.regstage) return rtx_gemm_dma_launch(g, RTX_EPI_STORE, st);
     if (form == RTX_FORM_NT) return rtx_gemm_launch(g, e->bf16 ? RTX_DT_BF16 : RTX_DT_F32, RTX_EPI_STORE, st);
     return rtx_gemm_f32_km_launch(g, RTX_EPI_STORE, st);
@@ -490,6 +497,51 @@ static int ensure_in_chunks(rtx_engine* e, int64_t chunks, hipStream_t st)
     return RTX_OK;
 }
 
+// Third form (round 5, option "hop_kernels"): the dependency as two ONE-WAVE KERNELS -- k_hop_set on the producing stream stores a
+// sequence number (agent-scope release) behind the kernels it follows, k_hop_wait on the consuming stream spins on it (acquire,
+// s_sleep between polls, bounded) in front of the kernels that need the data.  A kernel boundary on each side: the producers'
+// end-of-kernel release has completed before k_hop_set runs (in-order queue), the consumers' start-of-kernel acquire comes after
+// k_hop_wait has seen the number.  No stream memory operation, no event: those are packets that make the command processor release
+// to SYSTEM scope (the signal word is host-visible memory) and cost the stream 6-9 us each (profiles/r4_step_timeline.txt: the
+// gaps behind k_dlogits and between two steps).
+__global__ void k_hop_set(uint32_t* word, uint32_t v)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_hop_wait(const uint32_t* word, uint32_t v, uint32_t* stuck)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // 20 s: the producer is gone; do not hang the device
+            if (stuck) *stuck = v;
+            __builtin_trap();
+        }
+    }
+}
+
+static int ensure_hopk(rtx_engine* e)
+{
+    if (!e->hopk_mem) {
+        RTX_HIP(hipMalloc((void**)&e->hopk_mem, 64));
+        RTX_HIP(hipMemset(e->hopk_mem, 0, 64));
+        RTX_HIP(hipStreamSynchronize(nullptr));
+    }
+    return RTX_OK;
+}
+
+// the join a step flagged RTX_STEP_DEFER_JOIN left open: `st` continues only after everything that step put on the side stream
+static int resolve_join(rtx_engine* e, hipStream_t st)
+{
+    if (!e->join_pending) return RTX_OK;
+    e->join_pending = false;
+    e->join_fold = false;
+    hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, st, e->hopk_mem + 3, e->join_seq, e->hopk_mem + 11);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
 // The batch image A[0] (+ target row sums, + the scatter lists) of one batch, on stream `st`, into the CURRENT image set.
 static int gather_batch(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg, int B, int training, const rtx_step* step, hipStream_t st)
 {
@@ -555,6 +607,12 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     if (l0 == 0) e->last_sparse_in = sparse_in;
     const bool gathered = e->gather_done;
     e->gather_done = false;
+    if (e->join_fold && !(l0 == 0 && l1 > 1 && !sparse_in && gathered && e->bf16)) {
+        // the deferred join cannot ride on the first-layer product after all (it is not this call's first kernel): a kernel of its own
+        e->join_fold = false;
+        hipLaunchKernelGGL(k_hop_wait, dim3(1), dim3(64), 0, st, e->hopk_mem + 3, e->join_seq, e->hopk_mem + 11);
+        RTX_HIP(hipGetLastError());
+    }
     if (l0 == 0 && !sparse_in && !gathered) RTX_TRY(gather_batch(e, in, tg, B, training, step, st));
     for (int li = l0; li < l1; ++li) {
         Layer& l = e->L[li];
@@ -628,7 +686,9 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
         int splits = 1;
         {
             TIMED(li == 0 ? "gemm_fwd_in" : "gemm_fwd_hidden");
-            RTX_TRY(gemm_to_cacc(e, RTX_FORM_NT, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, &splits, st));
+            const bool fold = e->join_fold;      // (set only for a step whose FIRST kernel is this product)
+            e->join_fold = false;
+            RTX_TRY(gemm_to_cacc(e, RTX_FORM_NT, l.A, l.inp, l.Wsh, l.inp, Bp, l.outp, l.inp, &splits, st, nullptr, 0, fold ? e->hopk_mem + 3 : nullptr, e->join_seq));
         }
         Layer& nx = e->L[li + 1];
         if (e->vae && li == e->cfg.n_enc - 1) {
@@ -665,6 +725,7 @@ static int check_ready(rtx_engine* e, bool train)
 
 static int ensure_shadows(rtx_engine* e, hipStream_t st)
 {
+    RTX_TRY(resolve_join(e, st));   // (a join the last training step left open: before anything else of the engine runs on `st`)
     if (e->shadows_valid) return RTX_OK;
     return rtx_engine_sync_shadows(e, st);
 }
@@ -938,10 +999,17 @@ int rtx_engine_bind_grads16(rtx_engine* e, uint16_t* const* grads_bf16)
     return RTX_OK;
 }
 
+int rtx_engine_join(rtx_engine* e, void* stream)
+{
+    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
+    return resolve_join(e, (hipStream_t)stream);
+}
+
 int rtx_engine_sync_shadows(rtx_engine* e, void* stream)
 {
     RTX_TRY(check_ready(e, false));
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(resolve_join(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
     a.update = 0;
@@ -1107,40 +1175,6 @@ static size_t dp_region_elems(const rtx_engine* e, const DpState& d, int t)
 
 // `to` continues only after everything enqueued on `from` so far: a write / wait pair of stream memory operations on word `slot` of
 // the engine's signal memory (monotonic sequence numbers, compare >=), or an event record + wait
-// Third form (round 5, option "hop_kernels"): the dependency as two ONE-WAVE KERNELS -- k_hop_set on the producing stream stores a
-// sequence number (agent-scope release) behind the kernels it follows, k_hop_wait on the consuming stream spins on it (acquire,
-// s_sleep between polls, bounded) in front of the kernels that need the data.  A kernel boundary on each side: the producers'
-// end-of-kernel release has completed before k_hop_set runs (in-order queue), the consumers' start-of-kernel acquire comes after
-// k_hop_wait has seen the number.  No stream memory operation, no event: those are packets that make the command processor release
-// to SYSTEM scope (the signal word is host-visible memory) and cost the stream 6-9 us each (profiles/r4_step_timeline.txt: the
-// gaps behind k_dlogits and between two steps).
-__global__ void k_hop_set(uint32_t* word, uint32_t v)
-{
-    if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void k_hop_wait(const uint32_t* word, uint32_t v, uint32_t* stuck)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-    while ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) {   // 20 s: the producer is gone; do not hang the device
-            if (stuck) *stuck = v;
-            __builtin_trap();
-        }
-    }
-}
-
-static int ensure_hopk(rtx_engine* e)
-{
-    if (!e->hopk_mem) {
-        RTX_HIP(hipMalloc((void**)&e->hopk_mem, 64));
-        RTX_HIP(hipMemset(e->hopk_mem, 0, 64));
-        RTX_HIP(hipStreamSynchronize(nullptr));
-    }
-    return RTX_OK;
-}
-
 static int stream_dependency(rtx_engine* e, hipStream_t from, hipStream_t to, hipEvent_t ev, int slot)
 {
     if (e->opt_hop_kernels) {
@@ -1229,6 +1263,9 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
     if (dp && dae_reg)   // lam * W / ||W|| needs the norm of the WHOLE matrix; a rank of the sharded optimizer holds current rows of its shard only
         for (int li = 0; li < e->NL; ++li)
             RTX_CHECK(!dp->shard[li], RTX_EINVAL, "data parallel: Mult-DAE's norm regulariser (lam != 0) needs whole master matrices; attach with sharded = 0");
+    // a join the previous step left open (RTX_STEP_DEFER_JOIN): decided below, once it is known how this step starts
+    bool join_open = e->join_pending && e->shadows_valid;
+    if (join_open) e->join_pending = false;
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in = {}, tg = {};
     RTX_TRY(resolve_batch(e, batch, &in, &tg, st));
@@ -1270,7 +1307,14 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             swap_img_sets(e);
             e->gather_done = true;
             ++e->st_prefetch_hits;
+            // this step starts with the first-layer product: the open join rides on it (run_forward; every workgroup checks the
+            // number the side stream stored -- long ago -- before it touches the prefetched image)
+            if (join_open && e->opt_hop_fold && e->bf16) { e->join_fold = true; join_open = false; }
         }
+    }
+    if (join_open) {   // any other start: a one-wave kernel in front of the step
+        e->join_pending = true;
+        RTX_TRY(resolve_join(e, st));
     }
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
     if (dae_reg) {
@@ -1713,8 +1757,19 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (two) {
             for (int li = 0; li < NL; ++li)
                 if (on_side(li) && layer_fusable(e, e->L[li])) std::swap(e->L[li].Wsh, e->L[li].Wsh_alt);
-            // everything the step did is ordered on the caller's stream when the call returns
-            RTX_TRY(stream_dependency(e, e->side, st, e->ev_done, 1));
+            if ((step->flags & RTX_STEP_DEFER_JOIN) && e->opt_hop_fold && e->bf16 && !dp) {
+                // the caller will not touch parameters / losses outside the engine before its next engine call (or rtx_engine_join):
+                // the side stream stores a number behind its last kernel, and whoever uses the engine next waits for it -- the next
+                // training step inside its first kernel (no packet, no gap between two steps on the caller's stream)
+                RTX_TRY(ensure_hopk(e));
+                e->join_seq = ++e->hopk_seq;
+                hipLaunchKernelGGL(k_hop_set, dim3(1), dim3(64), 0, e->side, e->hopk_mem + 3, e->join_seq);
+                RTX_HIP(hipGetLastError());
+                e->join_pending = true;
+            } else {
+                // everything the step did is ordered on the caller's stream when the call returns
+                RTX_TRY(stream_dependency(e, e->side, st, e->ev_done, 1));
+            }
         }
         e->shadows_valid = true;
     }
@@ -1732,6 +1787,7 @@ int rtx_engine_apply_adam(rtx_engine* e, const rtx_step* step, void* stream)
     RTX_TRY(check_ready(e, true));
     RTX_CHECK(step && step->step >= 1, RTX_EINVAL, "apply_adam: step count must be >= 1");
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(resolve_join(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a);
     fill_adam_scalars(e, step, a, 0);
@@ -1749,6 +1805,7 @@ int rtx_engine_apply_adam_layers(rtx_engine* e, const rtx_step* step, int32_t la
     RTX_CHECK(layer_lo >= 0 && layer_lo < layer_hi && layer_hi <= e->NL, RTX_EINVAL, "apply_adam_layers: bad layer range [%d, %d) of %d",
               layer_lo, layer_hi, e->NL);
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(resolve_join(e, st));
     RtxAdamArgs a = {};
     fill_adam_tensors(e, a, layer_lo, layer_hi);
     if (grads_bf16)
@@ -1778,6 +1835,7 @@ int rtx_engine_apply_adam_rows(rtx_engine* e, const rtx_step* step, int32_t laye
     RTX_CHECK(!l.WshT || (row_lo == 0 && row_hi >= l.out), RTX_EINVAL,
               "apply_adam_rows: layer %d keeps a transposed compute copy and cannot be sharded by rows (shard the first / last layer only)", layer);
     hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(resolve_join(e, st));
     RtxAdamArgs full = {}, a = {};
     fill_adam_tensors(e, full, layer, layer + 1);
     int ids[2];
@@ -1909,6 +1967,7 @@ int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
 {
     RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
     RTX_HIP(hipDeviceSynchronize());
+    e->join_pending = e->join_fold = false;   // (every stream has drained)
     dp_release(e);
     if (!cfg) return RTX_OK;
     RTX_CHECK(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, RTX_EINVAL, "dp_attach: rank %d of %d", cfg->rank, cfg->world);

@@ -88,6 +88,11 @@ struct RtxGemm {
     // stream memory operation or an event costs it 6-9 us (engine.hip: stream_dependency)
     unsigned* hop_word;
     unsigned hop_seq;
+    // the "consumer side" folded into a kernel (rtx_gemm_nt, rtx_gemm_dma): when set, every workgroup first waits until *wait_word
+    // has reached wait_seq (one lane polls at agent scope; an acquire fence only if it really had to wait -- normally the number
+    // was stored long before this kernel was dispatched and the dispatch's own acquire covers the producers' output)
+    const unsigned* wait_word;
+    unsigned wait_seq;
     int tail_t0, tail_splits, tail_block0;
     float* tail_C;
     long tail_ldc, tail_slab_stride;

@@ -316,6 +316,11 @@ class Engine:
         self._next_keep = (x, target)         # the row ids stay alive (and unchanged) until that step has run
         return True
 
+    def join(self):
+        """resolve a join left open by a training step flagged ``RTX_STEP_DEFER_JOIN``: the current stream continues only after
+        everything that step put on the engine's side stream (no-op when nothing is open)"""
+        check(lib().rtx_engine_join(self.handle, stream_ptr()))
+
     def loss_mailbox(self, enable=True):
         """every training step also reports {loss, step count} to coherent host memory (``wait_loss``)"""
         check(lib().rtx_engine_loss_mailbox(self.handle, int(bool(enable))))

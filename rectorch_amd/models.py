@@ -238,7 +238,8 @@ class AETrainer(TorchNNTrainer):
         for done, (item, nxt) in enumerate(_with_next(train_loader.iter_rows()) if resident else ((i, None) for i in train_loader), 1):
             if resident:
                 # (the batch after this one is announced to the engine: it is gathered under this step's last weight kernel)
-                self._fused_step(shaped(item), None, want_loss=False, next_x=None if nxt is None else shaped(nxt))
+                # (no wait for the engine's side stream between two steps: the next step resolves the join in its first kernel)
+                self._fused_step(shaped(item), None, want_loss=False, next_x=None if nxt is None else shaped(nxt), defer_join=True)
             else:
                 data, gt = item
                 pending += self.train_batch(data, gt)
@@ -294,10 +295,13 @@ class AETrainer(TorchNNTrainer):
         v = [self.optimizer.state[p]['exp_avg_sq'] for p in params]
         return st, params, m, v
 
-    def _fused_step(self, x, target, want_loss=True, next_x=None, next_target=None):
+    def _fused_step(self, x, target, want_loss=True, next_x=None, next_target=None, defer_join=False):
         """``next_x`` (optional, a :class:`RowBatch`): the batch of the NEXT ``_fused_step`` call.  The engine gathers it on its
         side stream under this step's last weight kernel, so that step starts with the first-layer product (single GPU, bf16).
-        Its dropout seed is drawn now and kept for that step: the sequence of draws from torch's generator is unchanged."""
+        Its dropout seed is drawn now and kept for that step: the sequence of draws from torch's generator is unchanged.
+        ``defer_join`` (epoch loops only): the step does not make the stream wait for the engine's side stream at its end
+        (``RTX_STEP_DEFER_JOIN``); the next step resolves the join inside its first kernel.  The caller must not read parameters,
+        optimizer state or the loss buffers before its next ``_fused_step`` / engine call or ``self._join()``."""
         _lib.require_gpu()
         st, params, m, v = self._ensure_train_state()
         if not isinstance(x, RowBatch):
@@ -333,6 +337,7 @@ class AETrainer(TorchNNTrainer):
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
                          eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
                          flags=(_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0) |
+                               (_lib.RTX_STEP_DEFER_JOIN if defer_join and red is None and not want_loss and self.numerics == "bf16" else 0) |
                                (_lib.RTX_STEP_GRADS_BF16 if direct16 else 0) |
                                # data parallel: the (rank-independent) DAE regulariser enters the summed loss once
                                (_lib.RTX_STEP_NO_REG_IN_LOSS if red is not None and red.rank != 0 else 0))
@@ -388,7 +393,13 @@ class AETrainer(TorchNNTrainer):
             return st.loss_buf[0].item()       # the reference's per-step loss.item() sync
         return None
 
+    def _join(self):
+        """order the current stream behind everything the engines' side streams still carry (steps run with ``defer_join``)"""
+        for eng in getattr(self.network, "_rtx_engines", {}).values():
+            eng.join()
+
     def _read_loss_sum(self):
+        self._join()
         st = self._rtx
         if st.reducer is not None:
             s = st.reducer.reduce_scalar(st.loss_buf[1:2].clone())

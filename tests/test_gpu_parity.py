@@ -1171,6 +1171,44 @@ def test_prefetched_batches_equal_self_gathered_batches():
         assert np.array_equal(a.view(np.int32), b.view(np.int32))
 
 
+def test_deferred_join_equals_joined_steps():
+    """RTX_STEP_DEFER_JOIN (train_epoch's steps): no wait for the engine's side stream at the end of a step; the next step resolves
+    the join inside its first-layer product (prefetched batch) or with a one-wave kernel (any other start), every other engine
+    entry point and `_read_loss_sum` / `_join` resolve it first.  Same seeds: deferred and joined runs end in bit-identical
+    parameters, losses and predictions -- with and without announced batches, with a prediction, a loss read-back and a
+    checkpoint in the middle of the run."""
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L, B = 3000, 600, 200, 192
+    X = synth_interactions(6 * B, I, mu=3.5, sigma=0.9, dmax=I // 2, seed=21)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 9)
+    batches = list(DataSampler(X, batch_size=B, shuffle=False).iter_rows())
+    outs = []
+    for defer, announce in ((False, False), (True, False), (True, True), (False, True)):
+        net, model = make_vae([I, H, L], [L, H, I], 0.5, sd, beta=0.2, anneal_steps=0, learning_rate=1e-3, numerics="bf16", predict_numerics="bf16")
+        net.to("cuda")
+        torch.manual_seed(31)
+        res = []
+        for t in range(12):
+            nxt = batches[(t + 1) % 6] if announce else None
+            model._fused_step(batches[t % 6], None, want_loss=False, next_x=nxt, defer_join=defer)
+            if t == 3:      # an engine call of another kind right behind a deferred step
+                res.append(model.predict(batches[0].tr.gather_dense(batches[0].rows[:9]))[0].cpu().numpy())
+                net.train()
+            if t == 6:      # the loss read-back joins first
+                res.append(np.float64(model._read_loss_sum()))
+            if t == 8:      # torch reads the decoder matrix (written on the side stream) after an explicit join
+                model._join()
+                res.append(net._param_list()[6].detach().cpu().numpy().copy())
+        model._join()
+        torch.cuda.synchronize()
+        res += [p.detach().cpu().numpy().copy() for p in net._param_list()]
+        outs.append(res)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_dp_stream_ordered_ranks_on_one_gpu():
     """the data-parallel step at world 2 and 4 with collectives that are stream-ordered device work and nothing else (ranks =
     threads of one process, parallel.LocalGroup): the run WITHOUT any device drain equals the drained run bit for bit, replicas
