@@ -375,6 +375,14 @@ def main():
     for kv in args.opt:                                 # measurement knobs (rtx_engine_set_option), e.g. --opt two_stream=0
         k, v = kv.split("=")
         eng0.set_option(k, int(v))
+    sites = ("adam",) if (dp or args.numerics != "bf16") else ("dW_adam_out", "dW_adam_in")
+    if dp:   # the exchange of each bucket, on the stream it runs on (caller's stream = the end of the step's critical path)
+        sites += ("dp_exchange_main", "dp_exchange_side", "dp_allgather_main", "dp_allgather_side")
+    for sname in (() if args.no_kernel_timing else sites):
+        # HIP events around the dominant kernel, on the stream it runs on, inside the timed region; every 8th launch is
+        # bracketed (the two records of a timed launch cost the step ~5 us each on its critical stream: 322 vs 313 us measured).
+        # Switched on BEFORE the pre-heat: the event pool is built there, not in the first timed window.
+        eng0.set_timing(sname, args.kernel_timing_every)
     # pre-heat: untimed steps for ~preheat_seconds.  Every rank runs the SAME number of steps (a data-parallel step is a
     # collective): the count comes from a short probe whose duration is max-reduced over the ranks.
     preheat_steps = 0
@@ -396,13 +404,7 @@ def main():
     torch.cuda.synchronize()
     _flush_c_stdio()
     eng = net._rtx_engines[args.numerics]
-    sites = ("adam",) if (dp or args.numerics != "bf16") else ("dW_adam_out", "dW_adam_in")
-    if dp:   # the exchange of each bucket, on the stream it runs on (caller's stream = the end of the step's critical path)
-        sites += ("dp_exchange_main", "dp_exchange_side", "dp_allgather_main", "dp_allgather_side")
-    for sname in (() if args.no_kernel_timing else sites):
-        # HIP events around the dominant kernel, on the stream it runs on, inside the timed region; every 8th launch is
-        # bracketed (the two records of a timed launch cost the step ~5 us each on its critical stream: 322 vs 313 us measured)
-        eng.set_timing(sname, args.kernel_timing_every)
+    eng.get_timings()                                   # (drop what the pre-heat and the warm-up recorded: the timed windows only)
     wins = timed_windows(run, args.steps, args.windows, world, args.warmup)
     timings = eng.get_timings()
     eng.set_timing(None, False)
