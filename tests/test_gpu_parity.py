@@ -572,7 +572,7 @@ def test_evaluate_device_equals_host_evaluate():
     from rectorch_amd.utils import synth_interactions, hash_state_dict
     from rectorch_amd.utils.synth import split_heldout
     from rectorch_amd.samplers import DataSampler
-    from rectorch_amd.evaluation import evaluate, evaluate_device, ValidFunc
+    from rectorch_amd.evaluation import evaluate, evaluate_host, evaluate_device, ValidFunc
     from rectorch_amd.engine import CsrMatrix, topk_metrics
     from rectorch_amd.metrics import Metrics
     # (a) raw kernel vs Metrics on golden G6 scores (contains -inf and ties-free random scores)
@@ -601,7 +601,15 @@ def test_evaluate_device_equals_host_evaluate():
     mets = ["ndcg@100", "ndcg@10", "recall@50", "recall@20"]
     smp = DataSampler(val_tr, val_te, batch_size=128, shuffle=False)
     dev_res = evaluate_device(model, smp, mets)
-    host_res = evaluate(model, smp, mets)
+    host_res = evaluate_host(model, smp, mets)       # the reference's loop: scores and held-out rows to the host, numpy metrics
+    auto_res = evaluate(model, smp, mets)            # round 5: evaluate() itself takes the device route on a resident sampler
+    for m in mets:
+        assert np.array_equal(auto_res[m], dev_res[m])
+    model.device_metrics = False
+    off_res = evaluate(model, smp, mets)
+    model.device_metrics = True
+    for m in mets:
+        assert np.array_equal(off_res[m], host_res[m])
     for m in mets:
         assert dev_res[m].shape == host_res[m].shape == (300,)
         assert np.allclose(dev_res[m], host_res[m], rtol=1e-12, atol=0, equal_nan=True), m

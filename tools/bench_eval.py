@@ -27,7 +27,7 @@ from rectorch_amd.utils.synth import split_heldout                           # n
 from rectorch_amd.nets import MultiVAE_net                                   # noqa: E402
 from rectorch_amd.models import MultiVAE                                     # noqa: E402
 from rectorch_amd.samplers import DataSampler                                # noqa: E402
-from rectorch_amd.evaluation import evaluate, evaluate_device                # noqa: E402
+from rectorch_amd.evaluation import evaluate, evaluate_host, evaluate_device   # noqa: E402
 from rectorch_amd.metrics import Metrics                                     # noqa: E402
 
 PEAK_TF = {"fp32": 157.3, "bf16": 2500.0}     # v_mfma_f32_32x32x2_f32 / dense bf16 MFMA (MI355X_MICROARCH.md)
@@ -63,7 +63,7 @@ def main():
         model = MultiVAE(net, predict_numerics=numerics)
         evaluate_device(model, smp, mets)           # warm-up (engine creation, compute copies)
         t_dev, d = timed(lambda: evaluate_device(model, smp, mets), 3)
-        t_host, h = timed(lambda: evaluate(model, smp, mets), 1)
+        t_host, h = timed(lambda: evaluate_host(model, smp, mets), 1)
         same = all(np.allclose(d[m], h[m], rtol=1e-12, equal_nan=True) for m in mets)
         if ref is None:
             ref = d
