@@ -1116,6 +1116,36 @@ __device__ __forceinline__ void topk_sort(uint32_t* ckey, int32_t* cidx, int n, 
 //      (bitonic sort of <= 1024 keys in LDS);
 //   3. the elements >= L (a few hundred) are collected and sorted; the first K are the answer.
 // More than RTX_TOPK_MAX elements >= L (a row of ties): the radix select below, unchanged, takes over.
+// f(key, index) for every element of a score row.  16-byte loads, eight of them in flight per thread, wherever the row is 16-byte
+// aligned (round 5: the 4-byte loads of rounds 1-4 walked the 80-KB row in 79 dependent round trips per thread -- with two
+// workgroups per CU there is nothing to hide them behind; 71 -> see profiles/r5_eval_kernel_stats.txt)
+template <typename F> __device__ __forceinline__ void topk_scan_row(const float* __restrict__ row, int n_items, int tid, F&& f)
+{
+    int done = 0;
+    if ((((uintptr_t)row) & 15) == 0) {
+        const int n4 = n_items >> 2;
+        const float4* __restrict__ r4 = (const float4*)row;
+        int j = tid;
+        for (; j + 7 * 256 < n4; j += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = r4[j + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i0 = (j + u * 256) * 4;
+                f(score_key(v[u].x), i0); f(score_key(v[u].y), i0 + 1); f(score_key(v[u].z), i0 + 2); f(score_key(v[u].w), i0 + 3);
+            }
+        }
+        for (; j < n4; j += 256) {
+            const float4 v = r4[j];
+            const int i0 = j * 4;
+            f(score_key(v.x), i0); f(score_key(v.y), i0 + 1); f(score_key(v.z), i0 + 2); f(score_key(v.w), i0 + 3);
+        }
+        done = n4 * 4;
+    }
+    for (int i = done + tid; i < n_items; i += 256) f(score_key(row[i]), i);
+}
+
 __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
 {
     __shared__ uint32_t hist[256];
@@ -1131,15 +1161,14 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
     const int c = (K + 255) / 256;              // 1 .. 4
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;    // this thread's largest keys, descending (0 = below every real key)
     if (c == 1) {
-        for (int i = tid; i < a.n_items; i += 256) t0 = max(t0, score_key(row[i]));
+        topk_scan_row(row, a.n_items, tid, [&](uint32_t k, int) { t0 = max(t0, k); });
     } else {
-        for (int i = tid; i < a.n_items; i += 256) {
-            uint32_t k = score_key(row[i]);
+        topk_scan_row(row, a.n_items, tid, [&](uint32_t k, int) {
             if (k > t0) { const uint32_t x = t0; t0 = k; k = x; }
             if (k > t1) { const uint32_t x = t1; t1 = k; k = x; }
             if (k > t2) { const uint32_t x = t2; t2 = k; k = x; }
             if (k > t3) t3 = k;
-        }
+        });
     }
     // ---- 2. L = K-th largest of the 256 c thread maxima
     const int n1 = c == 1 ? 256 : (c == 2 ? 512 : 1024);
@@ -1157,13 +1186,12 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
     if (tid == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
     for (int i = tid; i < RTX_TOPK_MAX; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; }
     __syncthreads();
-    for (int i = tid; i < a.n_items; i += 256) {
-        const uint32_t k = score_key(row[i]);
+    topk_scan_row(row, a.n_items, tid, [&](uint32_t k, int i) {
         if (k >= L) {
             const uint32_t p = atomicAdd(&sh_cnt_gt, 1u);
             if (p < (uint32_t)RTX_TOPK_MAX) { ckey[p] = k; cidx[p] = i; }
         }
-    }
+    });
     __syncthreads();
     const uint32_t n_cand = sh_cnt_gt;
     int n_sort = a.Kp2;
@@ -1256,12 +1284,17 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
         __syncthreads();
         return (dred[0] + dred[1]) + (dred[2] + dred[3]);
     };
+    double l2r[RTX_TOPK_MAX / 256];             // log2(r + 2) of this thread's ranks: once, not once per cut-off
+#pragma unroll
+    for (int m = 0; m < RTX_TOPK_MAX / 256; ++m) l2r[m] = log2((double)(tid + 256 * m + 2));
     for (int q = 0; q < a.n_k; ++q) {
         const int kk = min(min(a.ks[q], a.n_items), K);
         const long nid = min((long)gsum, (long)min(a.ks[q], a.n_items));      // tp[:min(int(n), k)].sum()   (metrics.py:146)
         double dcg = 0.0, idcg = 0.0, hits = 0.0;
-        for (int r = tid; r < RTX_TOPK_MAX; r += 256) {
-            const double l2 = log2((double)(r + 2));
+#pragma unroll
+        for (int m = 0; m < RTX_TOPK_MAX / 256; ++m) {
+            const int r = tid + 256 * m;
+            const double l2 = l2r[m];
             if (r < kk) { dcg += (double)rel[r] / l2; hits += rel[r] > 0.f ? 1.0 : 0.0; }
             if (r < nid) idcg += 1.0 / l2;
         }
