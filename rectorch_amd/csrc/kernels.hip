@@ -1146,6 +1146,9 @@ template <typename F> __device__ __forceinline__ void topk_scan_row(const float*
     for (int i = done + tid; i < n_items; i += 256) f(score_key(row[i]), i);
 }
 
+// NV > 0: the whole row (<= NV * 1024 items, 16-byte aligned) is loaded ONCE, NV 16-byte loads per thread in one burst, and stays in
+// registers for both passes over it (maxima, collection); NV = 0: the row is streamed twice (any length / alignment).
+template <int NV>
 __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
 {
     __shared__ uint32_t hist[256];
@@ -1157,13 +1160,35 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = a.scores + (size_t)b * a.ld;
     const int K = a.K;
+    float4 rv[NV > 0 ? NV : 1];
+    const int n4 = a.n_items >> 2;
+    if constexpr (NV > 0) {
+        const float4* __restrict__ r4 = (const float4*)row;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) rv[u] = r4[min(tid + u * 256, n4 > 0 ? n4 - 1 : 0)];   // (clamped: the guard is at the use)
+    }
+    auto scan = [&](auto&& f) __attribute__((always_inline)) {
+        if constexpr (NV > 0) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int j = tid + u * 256;
+                if (j < n4) {
+                    const int i0 = j * 4;
+                    f(score_key(rv[u].x), i0); f(score_key(rv[u].y), i0 + 1); f(score_key(rv[u].z), i0 + 2); f(score_key(rv[u].w), i0 + 3);
+                }
+            }
+            for (int i = n4 * 4 + tid; i < a.n_items; i += 256) f(score_key(row[i]), i);
+        } else {
+            topk_scan_row(row, a.n_items, tid, f);
+        }
+    };
     // ---- 1. per-thread maxima
     const int c = (K + 255) / 256;              // 1 .. 4
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;    // this thread's largest keys, descending (0 = below every real key)
     if (c == 1) {
-        topk_scan_row(row, a.n_items, tid, [&](uint32_t k, int) { t0 = max(t0, k); });
+        scan([&](uint32_t k, int) { t0 = max(t0, k); });
     } else {
-        topk_scan_row(row, a.n_items, tid, [&](uint32_t k, int) {
+        scan([&](uint32_t k, int) {
             if (k > t0) { const uint32_t x = t0; t0 = k; k = x; }
             if (k > t1) { const uint32_t x = t1; t1 = k; k = x; }
             if (k > t2) { const uint32_t x = t2; t2 = k; k = x; }
@@ -1186,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
     if (tid == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
     for (int i = tid; i < RTX_TOPK_MAX; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; }
     __syncthreads();
-    topk_scan_row(row, a.n_items, tid, [&](uint32_t k, int i) {
+    scan([&](uint32_t k, int i) {
         if (k >= L) {
             const uint32_t p = atomicAdd(&sh_cnt_gt, 1u);
             if (p < (uint32_t)RTX_TOPK_MAX) { ckey[p] = k; cidx[p] = i; }
@@ -1325,7 +1350,10 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
         a.ks[q] = ks[q];
     }
     a.ndcg = ndcg; a.recall = recall; a.topk = topk; a.B = B;
-    hipLaunchKernelGGL(k_topk_metrics, dim3(B), dim3(256), 0, stream, a);
+    if ((((uintptr_t)scores) & 15) == 0 && (ld & 3) == 0 && n_items <= 20 * 1024)
+        hipLaunchKernelGGL(k_topk_metrics<20>, dim3(B), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_topk_metrics<0>, dim3(B), dim3(256), 0, stream, a);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
