@@ -1694,8 +1694,8 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RTX_TRY(dp_bucket(0, b_hi, st, false));
         if (dp_side) {
             std::swap(e->L[NL - 1].Wsh, e->L[NL - 1].Wsh_alt);
-            RTX_HIP(hipEventRecord(e->ev_done, e->side));
-            RTX_HIP(hipStreamWaitEvent(st, e->ev_done, 0));
+            // (the same form of dependency as the single-GPU step's join: stream values where the device has them, else the event)
+            RTX_TRY(stream_dependency(e, e->side, st, e->ev_done, 1));
         }
         e->shadows_valid = true;
     } else if (two && main_li >= 0) {
