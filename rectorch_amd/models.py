@@ -411,6 +411,7 @@ class AETrainer(TorchNNTrainer):
     # ----------------------------------------------------------------------------------- prediction
     def _predict_tuple(self, x, remove_train):
         _lib.require_gpu()
+        self._join()         # (an epoch interrupted between two deferred-join steps: order this stream behind the side streams first)
         if self._rtx.masters_sharded and self.predict_numerics != self.numerics:
             # that engine's compute copies come from the float32 masters, of which this rank holds only its rows
             raise _lib.RtxError("sharded optimizer: the float32 master rows of the other ranks are stale on this rank; call "
@@ -483,6 +484,7 @@ class AETrainer(TorchNNTrainer):
 
     def _sync_optimizer_state(self):
         """write the step count the fused Adam kernel is at into torch.optim.Adam's state"""
+        self._join()         # (checkpoints read parameters and moments through torch: behind the engines' side streams)
         for p in self.network.parameters():
             state = self.optimizer.state.get(p)
             if state is not None and 'step' in state:
