@@ -11,7 +11,7 @@ mkdir -p $R/gpurun_out/pmc
 for pass in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/pmc_$tag
-  rocprofv3 --pmc $pass --kernel-trace -d /tmp/pmc_$tag -o p -- python $R/bench.py --steps 30 --warmup 5 --windows 1 --no-cpu-baseline --no-fp32-parity --no-extras "$@" > /tmp/p_$tag.log 2>&1
+  rocprofv3 --pmc $pass --kernel-trace -d /tmp/pmc_$tag -o p -- python $R/bench.py --steps 30 --warmup 5 --windows 1 --preheat-seconds 0 --no-cpu-baseline --no-fp32-parity --no-extras "$@" > /tmp/p_$tag.log 2>&1
   DB=$(find /tmp/pmc_$tag -name "*.db" | head -1)
   python $R/tools/rocprof_summary.py pmc $DB > $R/gpurun_out/pmc/bench_$tag.txt
 done
