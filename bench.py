@@ -378,6 +378,10 @@ def main():
     sites = ("adam",) if (dp or args.numerics != "bf16") else ("dW_adam_out", "dW_adam_in")
     if dp:   # the exchange of each bucket, on the stream it runs on (caller's stream = the end of the step's critical path)
         sites += ("dp_exchange_main", "dp_exchange_side", "dp_allgather_main", "dp_allgather_side")
+    if not args.no_kernel_timing:
+        # every timed bracket is followed by an EMPTY one on the same stream (site "<name>#empty"): what two event records cost with
+        # nothing between them.  A bracket holds its kernel PLUS that; the reported duration is bracket - empty bracket, both listed.
+        eng0.set_option("timing_calibrate", 1)
     for sname in (() if args.no_kernel_timing else sites):
         # HIP events around the dominant kernel, on the stream it runs on, inside the timed region; every 8th launch is
         # bracketed (the two records of a timed launch cost the step ~5 us each on its critical stream: 322 vs 313 us measured).
@@ -507,8 +511,11 @@ def main():
         # (the gradient's 4 + 4 B of SURVEY 8d's 32 B/param no longer exist; the 2-B compute copy and the operand reads
         # are not counted)
         (t_out, n_out), (t_in, n_in) = timings.get("dW_adam_out", (0.0, 0)), timings.get("dW_adam_in", (0.0, 0))
+        (c_out, m_out), (c_in, m_in) = timings.get("dW_adam_out#empty", (0.0, 0)), timings.get("dW_adam_in#empty", (0.0, 0))
         kn = n_out + n_in
-        kus = (t_out + t_in) * 1e3 / max(kn, 1)
+        kus_bracket = (t_out + t_in) * 1e3 / max(kn, 1)
+        bracket_overhead_us = (c_out + c_in) * 1e3 / max(m_out + m_in, 1)
+        kus = max(kus_bracket - bracket_overhead_us, 0.0)
         kbytes = 24.0 * I * H
         kname = ("rtx_dw_tn / rtx_dw_tn_group <64x128, RTX_DW_ADAM> (weight gradient fused with Adam: the decoder n_items x 600 matrix on "
                  "the side stream, the encoder matrix + the hidden layers' in one launch on the caller's; 2 launches/step)")
@@ -560,6 +567,10 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_TBS * 1000.0, "unit": "GB/s",
                      "frac": (achieved / (HBM_PEAK_TBS * 1000.0)) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": kbytes, "avg_us": kus, "launches_timed": kn,
+                     "avg_us_event_bracket": locals().get("kus_bracket"), "event_bracket_overhead_us": locals().get("bracket_overhead_us"),
+                     "timing": "HIP events on the stream each launch runs on, inside the timed region; avg_us = mean bracket minus the mean EMPTY "
+                               "bracket recorded right behind each timed one (two event records with nothing between them); "
+                               "profiles/r5_bench_kernel_stats.txt is the rocprofv3 summary of the same command",
                      "timed_every": args.kernel_timing_every},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
                           "frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000.0),

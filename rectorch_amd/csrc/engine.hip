@@ -157,6 +157,7 @@ struct rtx_engine {
     // step starts from a prefetched batch image, as a one-wave k_hop_wait otherwise
     bool join_pending = false, join_fold = false;
     uint32_t join_seq = 0;
+    int opt_timing_calibrate = 0;      // every timed bracket is followed by an empty one (site "<name>#empty"): what the events themselves cost
     int opt_hop_fold = 1;              // the step's fork (caller's stream -> side stream) folded into the data-gradient product (loss_grads_impl)
     int opt_hop_kernels = 0;           // (measured: no gain, a one-wave kernel costs its stream 5-6 us like the packet it replaces) the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
@@ -265,8 +266,10 @@ struct ScopedTimer {
     hipStream_t s;
     TimingSite* site = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ScopedTimer(rtx_engine* eng, const char* name, hipStream_t st) : e(eng), s(st)
+    std::string name;
+    ScopedTimer(rtx_engine* eng, const char* nm, hipStream_t st) : e(eng), s(st), name(nm)
     {
+        const char* name = nm;
         if (!e->timing_all && e->timing_sites.empty()) return;
         if (!e->timing_all) {
             auto it = e->timing_sites.find(name);
@@ -294,6 +297,19 @@ struct ScopedTimer {
         if (!site) return;
         if (e1) (void)hipEventRecord(e1, s);
         if (e0 && e1) site->pending.push_back({e0, e1});
+        if (e->opt_timing_calibrate && e1) {
+            // an EMPTY bracket right behind the timed one, on the same stream at the same moment: the time between two event records
+            // with nothing in between is what the bracket above contains besides its kernel (option "timing_calibrate";
+            // reported as site "<name>#empty", the caller subtracts)
+            hipEvent_t a = nullptr, b = nullptr;
+            if (!e->event_pool.empty()) { a = e->event_pool.back(); e->event_pool.pop_back(); } else if (hipEventCreate(&a) != hipSuccess) a = nullptr;
+            if (!e->event_pool.empty()) { b = e->event_pool.back(); e->event_pool.pop_back(); } else if (hipEventCreate(&b) != hipSuccess) b = nullptr;
+            if (a && b) {
+                (void)hipEventRecord(a, s);
+                (void)hipEventRecord(b, s);
+                e->sites[name + "#empty"].pending.push_back({a, b});
+            }
+        }
     }
 };
 #define RTX_CAT2(a, b) a##b
@@ -2141,6 +2157,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "hop_values") e->opt_hop_values = value != 0;
     else if (k == "hop_kernels") e->opt_hop_kernels = value != 0;
     else if (k == "hop_fold") e->opt_hop_fold = value != 0;
+    else if (k == "timing_calibrate") e->opt_timing_calibrate = value != 0;
     else if (k == "hop_wrap") {
         RTX_CHECK(value >= 2, RTX_EINVAL, "set_option: hop_wrap must be >= 2");
         e->hop_wrap = (uint32_t)value;
