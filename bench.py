@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--items", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-parity", action="store_true")
-    ap.add_argument("--kernel-timing-every", type=int, default=8, help="bracket every N-th launch of the dominant kernel with HIP events")
+    ap.add_argument("--kernel-timing-every", type=int, default=16, help="bracket every N-th launch of the dominant kernel with HIP events")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="no HIP events around the dominant kernel (roofline.achieved becomes null): measures what the events cost")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
