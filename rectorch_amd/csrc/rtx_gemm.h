@@ -111,7 +111,9 @@ int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream);
 
 // ---- weight gradient in TN form, optionally fused with the Adam update (dw_adam.hip; bf16 operands) ------------------
 enum RtxDwEpilogue { RTX_DW_GRAD = 0, RTX_DW_ADAM = 1 };
-enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2, RTX_DW_128x128 = 3 };
+enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2, RTX_DW_128x128 = 3,
+                RTX_DW_128x128_W4 = 4 };   // round 5: 128 x 128 on FOUR waves (32 x 128 of dW per wave: 4 MFMAs per 5 fragment reads instead of
+                                           //   1 per 2): the long-K tile (a batch of thousands of rows: configs[3] on one GPU)
 struct RtxDw {
     const void* A;       // delta      bf16 [K_pad][lda]: k = batch row, m = output feature (contiguous)
     const void* B;       // activation bf16 [K_pad][ldb]: n = input feature (contiguous); column N_real holds ones

@@ -661,7 +661,7 @@ static int run_f32_case(const char* name, int form, int M, int N, int K, int spl
 static int run_dw_cases()
 {
     int fails = 0;
-    for (int cfg = 0; cfg < 4; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave)
+    for (int cfg = 0; cfg < 5; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / 128x128 on four waves
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
         fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
@@ -874,6 +874,14 @@ int main(int argc, char** argv)
             printf("    per XCC_ID: ");
             for (int x = 0; x < 8; ++x) printf("%d: %d wgs, life %.1f us | ", x, cnt[x], cnt[x] ? life[x] / cnt[x] : 0.0);
             printf("\n");
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "dwk")) {   // the weight-gradient + Adam kernel at a LONG K (a batch of thousands of rows), every tile
+        for (int cfg : {0, 3, 4}) {
+            perf_dw("netflix dW4+adam K=4096", cfg, RTX_DW_ADAM, 17769, 600, 4096, 3);
+            perf_dw("netflix dW1+adam K=4096", cfg, RTX_DW_ADAM, 600, 17769, 4096, 3);
+            perf_dw("ml20m dW4+adam K=500", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
         }
         return 0;
     }
