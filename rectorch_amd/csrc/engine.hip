@@ -464,6 +464,7 @@ static int resolve_batch(rtx_engine* e, const rtx_batch* b, RtxCsrView* in, RtxC
         RTX_CHECK(b->target_csr->n_cols == e->I, RTX_EINVAL, "target CSR has %d columns, expected %d", b->target_csr->n_cols, e->I);
         tg->indptr = b->target_csr->indptr; tg->indices = b->target_csr->indices; tg->values = b->target_csr->values;
         tg->row_ids = b->row_ids;
+        tg->max_row_len = b->target_csr->max_row_len;
     } else if (b->target_dense) {
         RTX_TRY(dense_to_view(e, e->tmp_tg, b->target_dense, b->batch, e->I, tg, st));
     } else {

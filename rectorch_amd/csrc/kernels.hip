@@ -627,6 +627,117 @@ __global__ __launch_bounds__(256) void k_dlogits(const RtxDlogitsArgs a)
     }
 }
 
+// The same, ONE WORKGROUP PER USER ROW (round 5; the training step's half-precision logits in place, D == Y16).  The chunked kernel
+// above runs 5 workgroups per user; each re-merges the row's 316 strip partials, zeroes and fills a 16-KB target image in LDS, and
+// the 2560 of them need 1.25 rounds of the chip: 16.4 us for 41 MB.  Here a row's logits (NV 16-byte loads per thread) leave for
+// the registers in ONE burst at kernel entry and stay there; the partials are merged once per row; the target needs no dense image:
+// its <= RTX_DLR_CAP stored entries are read (logit still in place), corrected and parked in LDS, the dense pass writes every element
+// from the registers, and behind a barrier the corrected entries overwrite theirs.  512 workgroups, all resident, one round.
+#define RTX_DLR_CAP 4096
+template <int NV>
+__global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
+{
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+    __shared__ float red[8];
+    __shared__ int32_t t_idx[RTX_DLR_CAP];
+    __shared__ float t_val[RTX_DLR_CAP];
+    const RtxLossArgs& L = a.loss;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n8 = a.ldd >> 3;
+    bf16_t* Drow = (bf16_t*)a.D + (size_t)b * a.ldd;
+    if (b >= L.B) {
+        for (int j = tid; j < n8; j += 256) *(uint4*)(Drow + (size_t)j * 8) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    // (1) the row's logits: every load in flight before anything else
+    const _Float16* y16 = (const _Float16*)a.Y16 + (size_t)b * a.ldd;
+    f16x8_t yy[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) yy[u] = *(const f16x8_t*)(y16 + (size_t)min(tid + u * 256, n8 - 1) * 8);
+    // (2) log-sum-exp of the row from the strip partials of the logits product
+    float lse;
+    {
+        float m = -INFINITY, s = 0.f;
+        for (int k = tid; k < L.n_strips; k += 256) {
+            const float2 pr = L.part[(size_t)b * L.part_ld + k];
+            online_merge(m, s, pr.x, pr.y);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            online_merge(m, s, m2, s2);
+        }
+        if ((tid & 63) == 0) { red[tid >> 6] = m; red[4 + (tid >> 6)] = s; }
+        __syncthreads();
+        float M = red[0], S = red[4];
+        online_merge(M, S, red[1], red[5]);
+        online_merge(M, S, red[2], red[6]);
+        online_merge(M, S, red[3], red[7]);
+        lse = M + logf(S);
+        __syncthreads();          // (red is reused by the sums below)
+    }
+    const float sc = L.tsum[b] * L.inv_batch;
+    // (3) the target's stored entries, while their logits are still in place: <t, y>, and the corrected gradient parked in LDS
+    const int64_t uu = csr_row(L.target, b);
+    const int64_t tb = L.target.indptr[uu], te = L.target.indptr[uu + 1];
+    const int nt = (int)min((int64_t)RTX_DLR_CAP, te - tb);       // (the launcher checked the matrix's longest row)
+    float dot = 0.f;
+    for (int k = tid; k < nt; k += 256) {
+        const int i = L.target.indices[tb + k];
+        int idx = -1;
+        float d = 0.f;
+        if (i < L.I) {
+            const float tv = L.target.values ? L.target.values[tb + k] : 1.f;
+            const float yv = (float)y16[i];
+            dot += tv * yv;
+            d = sc * __expf(yv - lse) - tv * L.inv_batch;
+            idx = i;
+        }
+        t_idx[k] = idx;
+        t_val[k] = d;
+    }
+    __syncthreads();              // every target logit has been read: the row may be overwritten now
+    // (4) the dense pass, from the registers: 16 bytes out per thread and load
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = tid + u * 256;
+        if (j < n8) {
+            const int col = j * 8;
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = (col + e < L.I) ? sc * __expf((float)yy[u][e] - lse) : 0.f;
+            uint4 o;
+            o.x = pack_bf16x2(d[0], d[1]);
+            o.y = pack_bf16x2(d[2], d[3]);
+            o.z = pack_bf16x2(d[4], d[5]);
+            o.w = pack_bf16x2(d[6], d[7]);
+            *(uint4*)(Drow + (size_t)col) = o;
+        }
+    }
+    // (5) the stored entries' values replace what the dense pass wrote there (same workgroup: release, barrier, then the scatter)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    for (int k = tid; k < nt; k += 256)
+        if (t_idx[k] >= 0) Drow[t_idx[k]] = f32_to_bf16(t_val[k]);
+    // (6) row loss: -<t, y> / B + s lse / B + beta KL / B, all in partial 0 of the row (the others are zero)
+    dot = block_sum(dot, red);
+    float kl = 0.f;
+    if (L.mu32) {
+        for (int j = tid; j < L.Z; j += 256) {
+            const float m = L.mu32[(size_t)b * L.Z + j], lv = L.lv32[(size_t)b * L.Z + j];
+            kl += 1.f + lv - m * m - expf(lv);
+        }
+        kl = block_sum(kl, red);
+    }
+    const int chunks = (a.ldd + RTX_GATHER_CHUNK - 1) / RTX_GATHER_CHUNK;
+    if (tid == 0) {
+        L.lse[b] = lse;
+        L.row_loss[(size_t)b * chunks] = -dot * L.inv_batch + L.tsum[b] * lse * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
+    } else if (tid < chunks) {
+        L.row_loss[(size_t)b * chunks + tid] = 0.f;
+    }
+}
+
 int rtx_dlogits_chunks(int ldd) { return (ldd + RTX_GATHER_CHUNK - 1) / RTX_GATHER_CHUNK; }
 
 // a.loss.row_loss receives B * rtx_dlogits_chunks(a.ldd) partial sums (row-major [B][chunks]): sum them with
@@ -642,6 +753,16 @@ int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream)
         RTX_HIP(hipGetLastError());
     }
     const dim3 grid(a.Bp, rtx_dlogits_chunks(a.ldd));
+    // the training step's in-place half logits: one workgroup per row (k_dlogits_row) when the row fits its registers (<= 20 480
+    // columns) and the target matrix's longest row its LDS list; RTX_DLOGITS_ROW=0 keeps the chunked kernel (A/B)
+    static const bool row_kernel = [] { const char* v = getenv("RTX_DLOGITS_ROW"); return !(v && v[0] == '0'); }();
+    if (is_bf16 && a.Y16 && a.loss.part && row_kernel && a.ldd <= 20 * 1024 && a.loss.target.max_row_len > 0 &&
+        a.loss.target.max_row_len <= RTX_DLR_CAP && rtx_dlogits_chunks(a.ldd) <= 256) {
+        if (a.ldd <= 5 * 2048) hipLaunchKernelGGL(k_dlogits_row<5>, dim3(a.Bp), dim3(256), 0, stream, a);     // NV x 256 threads x 8 columns
+        else hipLaunchKernelGGL(k_dlogits_row<10>, dim3(a.Bp), dim3(256), 0, stream, a);
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
+    }
     if (is_bf16)
         hipLaunchKernelGGL(k_dlogits<bf16_t>, grid, dim3(256), 0, stream, a);
     else
