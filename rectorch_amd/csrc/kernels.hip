@@ -649,16 +649,35 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
         for (int j = tid; j < n8; j += 256) *(uint4*)(Drow + (size_t)j * 8) = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    // (1) the row's logits: every load in flight before anything else
+    // (1) the row's logits: every load in flight before anything else -- behind the one load the longest dependent chain starts
+    //     with (row number -> row bounds -> stored entries -> their logits: four round trips, all of them under the merge below)
+    const int64_t uu = csr_row(L.target, b);
     const _Float16* y16 = (const _Float16*)a.Y16 + (size_t)b * a.ldd;
     f16x8_t yy[NV];
 #pragma unroll
     for (int u = 0; u < NV; ++u) yy[u] = *(const f16x8_t*)(y16 + (size_t)min(tid + u * 256, n8 - 1) * 8);
+    float2 pr0 = make_float2(-INFINITY, 0.f), pr1 = make_float2(-INFINITY, 0.f);     // this thread's strip partials (n_strips <= 512 here)
+    if (tid < L.n_strips) pr0 = L.part[(size_t)b * L.part_ld + tid];
+    if (tid + 256 < L.n_strips) pr1 = L.part[(size_t)b * L.part_ld + tid + 256];
+    const int64_t tb = L.target.indptr[uu], te = L.target.indptr[uu + 1];
+    const int nt = (int)min((int64_t)RTX_DLR_CAP, te - tb);       // (the launcher checked the matrix's longest row)
+    // the first 256 stored entries (nearly every row has fewer): index, value and logit, requested before the log-sum-exp exists
+    int i0 = -1;
+    float tv0 = 0.f, yv0 = 0.f;
+    if (tid < nt) {
+        const int i = L.target.indices[tb + tid];
+        if (i < L.I) {
+            i0 = i;
+            tv0 = L.target.values ? L.target.values[tb + tid] : 1.f;
+            yv0 = (float)y16[i];
+        }
+    }
     // (2) log-sum-exp of the row from the strip partials of the logits product
     float lse;
     {
-        float m = -INFINITY, s = 0.f;
-        for (int k = tid; k < L.n_strips; k += 256) {
+        float m = pr0.x, s = pr0.y;
+        online_merge(m, s, pr1.x, pr1.y);
+        for (int k = tid + 512; k < L.n_strips; k += 256) {       // (rows of more than 32 768 items)
             const float2 pr = L.part[(size_t)b * L.part_ld + k];
             online_merge(m, s, pr.x, pr.y);
         }
@@ -678,11 +697,13 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     }
     const float sc = L.tsum[b] * L.inv_batch;
     // (3) the target's stored entries, while their logits are still in place: <t, y>, and the corrected gradient parked in LDS
-    const int64_t uu = csr_row(L.target, b);
-    const int64_t tb = L.target.indptr[uu], te = L.target.indptr[uu + 1];
-    const int nt = (int)min((int64_t)RTX_DLR_CAP, te - tb);       // (the launcher checked the matrix's longest row)
     float dot = 0.f;
-    for (int k = tid; k < nt; k += 256) {
+    if (tid < nt) {               // the entries requested at kernel entry
+        t_idx[tid] = i0;
+        t_val[tid] = i0 >= 0 ? sc * __expf(yv0 - lse) - tv0 * L.inv_batch : 0.f;
+        dot += tv0 * yv0;
+    }
+    for (int k = tid + 256; k < nt; k += 256) {
         const int i = L.target.indices[tb + k];
         int idx = -1;
         float d = 0.f;
