@@ -644,9 +644,12 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     const RtxLossArgs& L = a.loss;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n8 = a.ldd >> 3;
+    // gridDim.y workgroups share a row: this one owns the 16-byte groups [j0, j1) (<= NV * 256 of them) = columns [8 j0, 8 j1)
+    const int S = gridDim.y, part_y = blockIdx.y;
+    const int j0 = (int)((long)n8 * part_y / S), j1 = (int)((long)n8 * (part_y + 1) / S);
     bf16_t* Drow = (bf16_t*)a.D + (size_t)b * a.ldd;
     if (b >= L.B) {
-        for (int j = tid; j < n8; j += 256) *(uint4*)(Drow + (size_t)j * 8) = make_uint4(0u, 0u, 0u, 0u);
+        for (int j = j0 + tid; j < j1; j += 256) *(uint4*)(Drow + (size_t)j * 8) = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     // (1) the row's logits: every load in flight before anything else -- behind the one load the longest dependent chain starts
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     const _Float16* y16 = (const _Float16*)a.Y16 + (size_t)b * a.ldd;
     f16x8_t yy[NV];
 #pragma unroll
-    for (int u = 0; u < NV; ++u) yy[u] = *(const f16x8_t*)(y16 + (size_t)min(tid + u * 256, n8 - 1) * 8);
+    for (int u = 0; u < NV; ++u) yy[u] = *(const f16x8_t*)(y16 + (size_t)min(j0 + tid + u * 256, n8 - 1) * 8);
     float2 pr0 = make_float2(-INFINITY, 0.f), pr1 = make_float2(-INFINITY, 0.f);     // this thread's strip partials (n_strips <= 512 here)
     if (tid < L.n_strips) pr0 = L.part[(size_t)b * L.part_ld + tid];
     if (tid + 256 < L.n_strips) pr1 = L.part[(size_t)b * L.part_ld + tid + 256];
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     float tv0 = 0.f, yv0 = 0.f;
     if (tid < nt) {
         const int i = L.target.indices[tb + tid];
-        if (i < L.I) {
+        if (i < L.I && i >= 8 * j0 && i < 8 * j1) {      // (the entries of this workgroup's columns)
             i0 = i;
             tv0 = L.target.values ? L.target.values[tb + tid] : 1.f;
             yv0 = (float)y16[i];
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
         const int i = L.target.indices[tb + k];
         int idx = -1;
         float d = 0.f;
-        if (i < L.I) {
+        if (i < L.I && i >= 8 * j0 && i < 8 * j1) {
             const float tv = L.target.values ? L.target.values[tb + k] : 1.f;
             const float yv = (float)y16[i];
             dot += tv * yv;
@@ -717,12 +720,12 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
         t_idx[k] = idx;
         t_val[k] = d;
     }
-    __syncthreads();              // every target logit has been read: the row may be overwritten now
+    __syncthreads();              // every target logit of these columns has been read: they may be overwritten now
     // (4) the dense pass, from the registers: 16 bytes out per thread and load
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-        const int j = tid + u * 256;
-        if (j < n8) {
+        const int j = j0 + tid + u * 256;
+        if (j < j1) {
             const int col = j * 8;
             float d[8];
 #pragma unroll
@@ -743,18 +746,24 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     // (6) row loss: -<t, y> / B + s lse / B + beta KL / B, all in partial 0 of the row (the others are zero)
     dot = block_sum(dot, red);
     float kl = 0.f;
-    if (L.mu32) {
+    if (L.mu32 && part_y == 0) {
         for (int j = tid; j < L.Z; j += 256) {
             const float m = L.mu32[(size_t)b * L.Z + j], lv = L.lv32[(size_t)b * L.Z + j];
             kl += 1.f + lv - m * m - expf(lv);
         }
         kl = block_sum(kl, red);
     }
+    // partial `part_y` of the row: this workgroup's share of -<t, y> / B; partial 0 also carries s lse / B + beta KL / B; the row's
+    // remaining partials (the chunked kernel writes rtx_dlogits_chunks of them, and the loss sum reads them all) are zero
     const int chunks = (a.ldd + RTX_GATHER_CHUNK - 1) / RTX_GATHER_CHUNK;
     if (tid == 0) {
-        L.lse[b] = lse;
-        L.row_loss[(size_t)b * chunks] = -dot * L.inv_batch + L.tsum[b] * lse * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
-    } else if (tid < chunks) {
+        float part = -dot * L.inv_batch;
+        if (part_y == 0) {
+            L.lse[b] = lse;
+            part += L.tsum[b] * lse * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
+        }
+        L.row_loss[(size_t)b * chunks + part_y] = part;
+    } else if (part_y == 0 && tid >= S && tid < chunks) {
         L.row_loss[(size_t)b * chunks + tid] = 0.f;
     }
 }
@@ -779,8 +788,9 @@ int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream)
     static const bool row_kernel = [] { const char* v = getenv("RTX_DLOGITS_ROW"); return !(v && v[0] == '0'); }();
     if (is_bf16 && a.Y16 && a.loss.part && row_kernel && a.ldd <= 20 * 1024 && a.loss.target.max_row_len > 0 &&
         a.loss.target.max_row_len <= RTX_DLR_CAP && rtx_dlogits_chunks(a.ldd) <= 256) {
-        if (a.ldd <= 5 * 2048) hipLaunchKernelGGL(k_dlogits_row<5>, dim3(a.Bp), dim3(256), 0, stream, a);     // NV x 256 threads x 8 columns
-        else hipLaunchKernelGGL(k_dlogits_row<10>, dim3(a.Bp), dim3(256), 0, stream, a);
+        // NV = 5 loads x 256 threads x 8 columns = 10 240 columns per workgroup: two workgroups share a longer row
+        const int S = (a.ldd + 10239) / 10240;
+        hipLaunchKernelGGL(k_dlogits_row<5>, dim3(a.Bp, S), dim3(256), 0, stream, a);
         RTX_HIP(hipGetLastError());
         return RTX_OK;
     }
