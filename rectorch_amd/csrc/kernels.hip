@@ -789,7 +789,8 @@ int rtx_launch_dlogits(const RtxDlogitsArgs& a, int is_bf16, hipStream_t stream)
     if (is_bf16 && a.Y16 && a.loss.part && row_kernel && a.ldd <= 20 * 1024 && a.loss.target.max_row_len > 0 &&
         a.loss.target.max_row_len <= RTX_DLR_CAP && rtx_dlogits_chunks(a.ldd) <= 256) {
         // NV = 5 loads x 256 threads x 8 columns = 10 240 columns per workgroup: two workgroups share a longer row
-        const int S = (a.ldd + 10239) / 10240;
+        static const int s_env = [] { const char* v = getenv("RTX_DLOGITS_SPLIT"); return v ? atoi(v) : 0; }();   // (measurement: more workgroups per row)
+        const int S = std::min(rtx_dlogits_chunks(a.ldd), std::max((a.ldd + 10239) / 10240, s_env));
         hipLaunchKernelGGL(k_dlogits_row<5>, dim3(a.Bp, S), dim3(256), 0, stream, a);
         RTX_HIP(hipGetLastError());
         return RTX_OK;
