@@ -93,6 +93,8 @@ def parse():
                          "kernel's source is byte-for-byte the profiled one (sha256), else traffic is null")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (train_batch API, sparse first layer; N > 1: the replicated all-reduce A/B)")
+    ap.add_argument("--replicated-ab", action="store_true",
+                    help="N > 1: after the timed region also time the replicated all-reduce schedule (a second set of communicators)")
     ap.add_argument("--no-defer-join", action="store_true",
                     help="every step ends with the caller's stream waiting for the engine's side stream (rounds 1-4)")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -450,8 +452,11 @@ def main():
                          "tensors": int(chk.numel()), "ranks": world, "identical": bool(torch.equal(lo_, hi_)),
                          "finite": bool(all(torch.isfinite(p).all().item() for p in net.parameters()))}
     # N > 1: the north star names the ALL-REDUCE schedule; the default is the sharded optimizer -- time the other one beside it
+    # With more than one REAL rank this side measurement is opt-in (--replicated-ab): it tears the first plan's communicators down and
+    # brings up two more, which has never run on a multi-GPU node -- nothing after the headline's timed region may be able to take
+    # the line with it.  With one rank (--force-dp, what the one-GPU boxes can run) it stays on.
     replicated_ab = None
-    if (world > 1 or args.force_dp) and not emu and args.sharded and not args.no_extras:
+    if ((world > 1 and args.replicated_ab) or (world == 1 and args.force_dp)) and not emu and args.sharded and not args.no_extras:
         # (the first plan's communicator goes before the second comes up: never two live RCCL communicators in the process;
         #  `--force-dp --sharded` runs this block with ONE real RCCL rank, which is how it is exercised on the one-GPU boxes)
         if world > 1:
