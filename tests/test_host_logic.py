@@ -464,3 +464,24 @@ def test_svae_sampler_pack_plan():
             assert 1 <= len(p) <= 8
             assert sum(len(data[u]) - 1 for u in p) <= 600 or len(p) == 1
     assert len(SVAE_Sampler(500, data, None, pred_type="next", sparse=True)) == len(data)
+
+
+def test_with_next_look_ahead_and_evaluate_host_dispatch():
+    """train_epoch's one-batch look-ahead (`_with_next`) and evaluate()'s dispatch: anything but a device-resident DataSampler with
+    held-out rows and nDCG / Recall metrics takes the reference's host loop (evaluation.py:100-109)."""
+    from rectorch_amd.models import _with_next
+    from rectorch_amd import evaluation
+    assert list(_with_next([])) == []
+    assert list(_with_next([7])) == [(7, None)]
+    assert list(_with_next(iter("abc"))) == [("a", "b"), ("b", "c"), ("c", None)]
+
+    class FakeLoader:
+        def __iter__(self):
+            return iter(())
+    assert evaluation._device_plan(FakeLoader(), ["ndcg@10"]) is None          # not a resident DataSampler
+    from scipy.sparse import csr_matrix
+    from rectorch_amd.samplers import DataSampler
+    host = DataSampler(csr_matrix(np.eye(4)), csr_matrix(np.eye(4)), batch_size=2, shuffle=False)
+    if not host.resident:                                                      # (no HIP device here: the sampler stays on the host)
+        assert evaluation._device_plan(host, ["ndcg@10", "recall@5"]) is None
+    assert evaluation._device_plan(host, ["mrr@10"]) is None and evaluation._device_plan(host, ["ndcg@5000"]) is None
