@@ -298,7 +298,8 @@ def self_launch(n):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and os.environ.get("WORLD_SIZE", "1") in ("", "1") and "RTX_BENCH_SELF_LAUNCHED" not in os.environ:
+        # no launcher around this process (or one that says "one rank" while N were asked for): start the N ranks here
         sys.exit(self_launch(args.gpus))
     from rectorch_amd import parallel
     rank, world, local = parallel.init_from_env()
