@@ -246,10 +246,12 @@ int rtx_engine_dp_owned_rows(const rtx_engine* e, int32_t layer, int32_t* row_lo
 /* float32 -> bfloat16 (round to nearest even) of n contiguous elements: stages a gradient bucket for a bf16 all-reduce */
 int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* ABI 7 -- THIS step's loss without draining the stream (the reference's train_batch ends in `return loss.item()`,
- * models.py:835).  With the mailbox enabled the loss reduction of every training step ALSO stores {loss, step->step} into
- * coherent host memory owned by the engine; rtx_engine_wait_loss(step) spins on the host until the mailbox carries that step
- * count and returns its loss: the kernels behind the loss (weight gradients, Adam) keep running and the host can enqueue the next
- * step under them.  timeout_s <= 0: 60 s.  Steps must be waited for in order (the mailbox holds the LAST step's loss). */
+ * models.py:835).  With the mailbox enabled the loss reduction of every training step ALSO stores {loss, ticket, step->step} into
+ * coherent host memory owned by the engine (the ticket is the engine's own monotonic count of reductions: a step count that restarts
+ * or repeats cannot match a stale entry); rtx_engine_wait_loss(step) spins on the host until the mailbox carries the ticket of the
+ * LAST step enqueued, checks that this is step `step` (RTX_ESTATE otherwise) and returns its loss: the kernels behind the loss
+ * (weight gradients, Adam) keep running and the host can enqueue the next step under them.  timeout_s <= 0: 60 s.  Steps are
+ * waited for in order, each before the next is enqueued (the mailbox holds the LAST step's loss). */
 int rtx_engine_loss_mailbox(rtx_engine* e, int32_t enable);
 int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double timeout_s);
 /* ABI 7 -- announce the batch of the training step AFTER the next rtx_engine_train_step call (and its dropout stream: seed /

@@ -169,7 +169,8 @@ struct rtx_engine {
     int opt_dp_shard_min_elems = 1 << 20;   // sharded optimizer: weight matrices of at least this many elements are reduce-scattered /
                                 //   updated by rows / all-gathered, smaller ones all-reduced and replicated (tests lower it so that
                                 //   small golden networks exercise the sharded path with real data)
-    uint32_t* loss_mailbox = nullptr;   // coherent host memory {loss bits, sequence}: rtx_engine_loss_mailbox / rtx_engine_wait_loss
+    uint32_t* loss_mailbox = nullptr;   // coherent host memory {loss bits, ticket, step}: rtx_engine_loss_mailbox / rtx_engine_wait_loss
+    uint32_t loss_ticket = 0;           // ticket of the last loss reduction enqueued with the mailbox on (monotonic; never a step count)
     int opt_dp_one_comm = 0;    // 1: bucket A shares bucket B's communicator even when the plan brings a second one (ABI 5-6 schedule; A/B knob)
     int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
     int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
@@ -371,6 +372,24 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form 
     const int per = (pl.k_slices + s - 1) / s;
     pl.splits = (pl.k_slices + per - 1) / per;
     return pl;
+}
+
+// A deferred join folded into the first-layer product (RtxGemm::wait_word) makes EVERY workgroup of that grid spin until the side
+// stream has stored its number.  The side stream's remaining kernels (weight gradient + Adam, loss sum, the next batch's gather, the
+// store itself) must therefore be able to make progress beside a grid that is entirely resident and spinning.  Occupancy argument: the
+// register-staged 128 x 128 product takes 73 728 B of LDS per workgroup, i.e. at most TWO workgroups per CU whatever else limits it; a
+// grid of G workgroups leaves at least 2 * n_cus - G of those slots empty, and a CU with an empty slot has >= 86 KB of LDS, >= 28 wave
+// slots and >= 328 registers per lane and SIMD free -- room for a workgroup of any kernel the side stream runs (the largest, the 64 x 128
+// weight-gradient tile: 72 KB, 8 waves, <= 128 registers).  With fewer than 16 empty slots, or any other product kernel, the join is
+// the one-wave k_hop_wait in front of the step instead (resolve_join): a spinning wave that holds nothing.
+static bool fold_has_room(const rtx_engine* e, int Mp, int Np, int Kp)
+{
+    const GemmPlan pl = plan_gemm(e, Mp, Np, Kp, RTX_FORM_NT);
+    if (!pl.regstage || pl.cfg != RTX_TILE_128x128) return false;
+    const long groups = pl.splits > 1 ? pl.splits : (pl.m_tiles <= pl.n_tiles ? pl.n_tiles : pl.m_tiles);
+    const long gsize = pl.splits > 1 ? (long)pl.m_tiles * pl.n_tiles : (pl.m_tiles <= pl.n_tiles ? pl.m_tiles : pl.n_tiles);
+    const long grid = 8 * ((groups + 7) / 8) * gsize;   // (rtx_gemm_launch's grid: idle workgroups of the XCD padding exit at once, counted anyway)
+    return grid + 16 <= 2L * e->n_cus;
 }
 
 static size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
@@ -1282,6 +1301,13 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             RTX_CHECK(!dp->shard[li], RTX_EINVAL, "data parallel: Mult-DAE's norm regulariser (lam != 0) needs whole master matrices; attach with sharded = 0");
     // a join the previous step left open (RTX_STEP_DEFER_JOIN): decided below, once it is known how this step starts
     bool join_open = e->join_pending && e->shadows_valid;
+    // Until the wait for that join has really been enqueued (the one-wave kernel, or the first-layer product that carries it), every
+    // early return below -- a wrong batch size, a failed launch -- must leave the join OPEN: the next entry point (rtx_engine_join,
+    // predict, apply_adam, the next step) still has to wait for the side stream's weight kernel before it reads what that writes.
+    struct JoinGuard {
+        rtx_engine* e; bool armed;
+        ~JoinGuard() { if (armed) { e->join_pending = true; e->join_fold = false; } }
+    } join_guard{e, join_open};
     if (join_open) e->join_pending = false;
     RTX_TRY(ensure_shadows(e, st));
     RtxCsrView in = {}, tg = {};
@@ -1326,7 +1352,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             ++e->st_prefetch_hits;
             // this step starts with the first-layer product: the open join rides on it (run_forward; every workgroup checks the
             // number the side stream stored -- long ago -- before it touches the prefetched image)
-            if (join_open && e->opt_hop_fold && e->bf16) { e->join_fold = true; join_open = false; }
+            if (join_open && e->opt_hop_fold && e->bf16 && fold_has_room(e, Bp, e->L[0].outp, e->L[0].inp)) { e->join_fold = true; join_open = false; }
         }
     }
     if (join_open) {   // any other start: a one-wave kernel in front of the step
@@ -1334,6 +1360,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RTX_TRY(resolve_join(e, st));
     }
     RTX_TRY(run_forward(e, &in, &tg, B, 1, step, 1, 0, NL, e->Y, e->Ip, nullptr, nullptr, st));
+    join_guard.armed = false;   // the wait is on the stream (k_hop_wait above, or inside the first-layer product)
     if (dae_reg) {
         TIMED("sumsq");
         RTX_TRY(launch_sumsq(e, st));
@@ -1383,7 +1410,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         ScopedTimer tm(e, "reduce_loss", ws);
         const bool reg_in_loss = dae_reg && !(step->flags & RTX_STEP_NO_REG_IN_LOSS);
         return rtx_launch_reduce_loss(e->row_loss, B * rtx_dlogits_chunks(e->Ip), step->lam, reg_in_loss ? e->sumsq : nullptr, 2 * NL, loss_out,
-                                      loss_accum, ws, e->loss_mailbox, (uint32_t)step->step);
+                                      loss_accum, ws, e->loss_mailbox, e->loss_mailbox ? ++e->loss_ticket : 0u, (uint32_t)step->step);
     };
     // weight + bias gradient of layer li on stream ws: gW[out][in] = D[Bp][outp]^T x A[Bp][inp] (both read K-major); column
     // `in` of the product (the ones column of A) is the bias gradient
@@ -2101,6 +2128,7 @@ int rtx_engine_loss_mailbox(rtx_engine* e, int32_t enable)
         RTX_HIP(hipHostMalloc(&p, 64, hipHostMallocCoherent | hipHostMallocMapped));
         memset(p, 0, 64);
         e->loss_mailbox = (uint32_t*)p;
+        e->loss_ticket = 0;
     } else if (!enable && e->loss_mailbox) {
         RTX_HIP(hipDeviceSynchronize());
         (void)hipHostFree(e->loss_mailbox);
@@ -2115,15 +2143,21 @@ int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double t
     RTX_CHECK(e->loss_mailbox, RTX_ESTATE, "wait_loss: rtx_engine_loss_mailbox(e, 1) has not been called");
     volatile uint32_t* mb = e->loss_mailbox;
     const auto t0 = std::chrono::steady_clock::now();
+    // the word waited for is the engine's own ticket of the LAST reduction it enqueued (monotonic), not the caller's step count: a
+    // count that restarts (a reloaded checkpoint, a new optimizer on the same engine) or repeats (step 0 twice) cannot match an old entry
+    RTX_CHECK(e->loss_ticket != 0, RTX_ESTATE, "wait_loss: no training step has reported to the mailbox yet");
+    const uint32_t want = e->loss_ticket;
     for (unsigned spin = 0;; ++spin) {
-        if (__atomic_load_n(&mb[1], __ATOMIC_ACQUIRE) == (uint32_t)step) break;
+        if (__atomic_load_n(&mb[1], __ATOMIC_ACQUIRE) == want) break;
         if ((spin & 0x3ff) == 0x3ff) {
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            RTX_CHECK(el < (timeout_s > 0 ? timeout_s : 60.0), RTX_EHIP, "wait_loss: step %d did not report its loss within %.1f s (mailbox holds step %u)",
-                      step, el, (unsigned)mb[1]);
+            RTX_CHECK(el < (timeout_s > 0 ? timeout_s : 60.0), RTX_EHIP, "wait_loss: step %d did not report its loss within %.1f s (mailbox holds ticket %u of %u, step %u)",
+                      step, el, (unsigned)mb[1], (unsigned)want, (unsigned)mb[2]);
             if (el > 0.002) sched_yield();      // a long wait is a long kernel: stop burning the core
         }
     }
+    RTX_CHECK(__atomic_load_n(&mb[2], __ATOMIC_RELAXED) == (uint32_t)step, RTX_ESTATE,
+              "wait_loss: the mailbox holds the LAST step enqueued (step %u), not step %d -- steps are waited for in order", (unsigned)mb[2], step);
     const uint32_t bits = __atomic_load_n(&mb[0], __ATOMIC_RELAXED);
     memcpy(loss_host, &bits, 4);
     return RTX_OK;

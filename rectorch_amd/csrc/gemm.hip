@@ -73,19 +73,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
     // [stage][A rows | B rows]; all LDS in one array (a second __shared__ object de-pipelines, cdna guide)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
-    if (p.wait_word) {   // a cross-stream dependency folded into this kernel (rtx_gemm.h); no LDS: every wave's first lane polls for itself
-        if ((threadIdx.x & 63) == 0) {
-            int waited = 0;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while ((int)(__hip_atomic_load(p.wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_seq) < 0) {
-                waited = 1;
-                __builtin_amdgcn_s_sleep(4);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) __builtin_trap();   // 20 s: the producer is gone
-            }
-            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (p.wait_word) rtx_fold_wait(p.wait_word, p.wait_seq);   // a cross-stream dependency folded into this kernel (rtx_gemm.h)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;

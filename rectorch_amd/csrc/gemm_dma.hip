@@ -107,19 +107,7 @@ __global__ __launch_bounds__((WM* WN + LW) * 64, (WM * WN + LW + 3) / 4) void rt
     const unsigned long long t_entry = __builtin_readcyclecounter(), r_entry = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (p.hop_word && blockIdx.x == 0 && tid == 0) __hip_atomic_store(p.hop_word, p.hop_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (p.wait_word) {   // a cross-stream dependency folded into this kernel (rtx_gemm.h); no LDS: every wave's first lane polls for itself
-        if ((threadIdx.x & 63) == 0) {
-            int waited = 0;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while ((int)(__hip_atomic_load(p.wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.wait_seq) < 0) {
-                waited = 1;
-                __builtin_amdgcn_s_sleep(4);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) __builtin_trap();   // 20 s: the producer is gone
-            }
-            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (p.wait_word) rtx_fold_wait(p.wait_word, p.wait_seq);   // a cross-stream dependency folded into this kernel (rtx_gemm.h)
 
     const int lw = LW ? wave - NW : wave;   // index among the DMA-issuing waves
     const int wm = wave / WN, wn = wave % WN;

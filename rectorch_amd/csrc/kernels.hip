@@ -470,11 +470,12 @@ __device__ float block_lse(const float* y, int I, float* red)
     return M + logf(S);
 }
 
-// `mailbox` (optional): two 32-bit words of COHERENT HOST memory, {loss, sequence}: the loss, then -- released at system scope --
-// the sequence number of this step.  A host that wants THIS step's loss (the reference's `return loss.item()`) spins on the
-// sequence word instead of draining the stream (rtx_engine_wait_loss).
+// `mailbox` (optional): three 32-bit words of COHERENT HOST memory, {loss, ticket, tag}: the loss and the caller's tag (the step
+// count), then -- released at system scope -- the engine's ticket of this reduction (monotonic over the engine's life, so a step
+// counter that restarts or repeats can never match a stale entry).  A host that wants THIS step's loss (the reference's
+// `return loss.item()`) spins on the ticket word instead of draining the stream (rtx_engine_wait_loss).
 __global__ __launch_bounds__(256) void k_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int nt,
-                                                     float* loss_out, float* loss_accum, uint32_t* mailbox, uint32_t seq)
+                                                     float* loss_out, float* loss_accum, uint32_t* mailbox, uint32_t seq, uint32_t tag)
 {
     __shared__ float red[4];
     // fixed summation order -> bit-reproducible loss for a given batch
@@ -488,15 +489,16 @@ __global__ __launch_bounds__(256) void k_reduce_loss(const float* row_loss, int 
         if (loss_accum) loss_accum[0] += s;
         if (mailbox) {
             __hip_atomic_store(mailbox, __float_as_uint(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
 int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int n_tensors, float* loss_out,
-                           float* loss_accum, hipStream_t stream, uint32_t* mailbox, uint32_t seq)
+                           float* loss_accum, hipStream_t stream, uint32_t* mailbox, uint32_t seq, uint32_t tag)
 {
-    hipLaunchKernelGGL(k_reduce_loss, dim3(1), dim3(256), 0, stream, row_loss, B, lam, sumsq, n_tensors, loss_out, loss_accum, mailbox, seq);
+    hipLaunchKernelGGL(k_reduce_loss, dim3(1), dim3(256), 0, stream, row_loss, B, lam, sumsq, n_tensors, loss_out, loss_accum, mailbox, seq, tag);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

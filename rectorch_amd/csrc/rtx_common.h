@@ -105,6 +105,24 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* dst, float a,
     u.y = pack_bf16x2(c, d);
     *(uint2*)dst = u;
 }
+
+// Consumer side of a cross-stream dependency folded into a kernel's prologue (rtx_gemm.h: RtxGemm::wait_word).  The guide's hand-off
+// form (MI355X_MICROARCH.md, "Consumer, always"): ONE lane polls the word with relaxed agent-scope loads, then ONE agent-scope
+// acquire -- unconditionally: the ordering must not rest on WHEN the number was stored relative to this kernel's dispatch -- then a
+// workgroup barrier, then plain loads (the fence invalidates this CU's L1, which is what every wave of the workgroup reads through).
+// Bounded: a producer that never arrives traps after 20 s instead of hanging the device.
+__device__ __forceinline__ void rtx_fold_wait(const unsigned* word, unsigned seq)
+{
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000000ull) __builtin_trap();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------

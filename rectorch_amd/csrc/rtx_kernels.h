@@ -200,7 +200,7 @@ struct RtxLossArgs {
 };
 // loss_out[0] = sum(row_loss[0..B)) + lam * sum_t sqrt(sumsq[t]);  loss_accum[0] += the same (nullable)
 int rtx_launch_reduce_loss(const float* row_loss, int B, float lam, const float* sumsq, int n_tensors,
-                           float* loss_out, float* loss_accum, hipStream_t stream, uint32_t* mailbox = nullptr, uint32_t seq = 0);
+                           float* loss_out, float* loss_accum, hipStream_t stream, uint32_t* mailbox = nullptr, uint32_t seq = 0, uint32_t tag = 0);
 // Loss AND its gradient w.r.t. the logits in one pass over Y (reference models.py:813-815 + autograd of log_softmax):
 //   lse_b from the strip partials the logits GEMM left (or, without them, a first pass over the row),
 //   row-loss partials (their fixed-order sum is the loss),  D[b][i] = (s_b * softmax(Y_b)_i - t_bi) * inv_batch  (T = bf16 / f32, zero padding)

@@ -99,10 +99,23 @@ def evaluate(model, test_loader, metric_list):
     top-k kernel on the GPU (3.6 M users/s against 8 K through the host loop), so ``model.train(...)``'s default
     ``valid_func=ValidFunc(evaluate)`` no longer spends its time copying score matrices.  Everything else -- other metrics, host
     samplers, models without the device path, ``model.device_metrics = False`` -- takes the reference's loop
-    (:func:`evaluate_host`); the two agree to 1e-12 (``test_evaluate_device_equals_host_evaluate``)."""
-    if getattr(model, "device_metrics", True) and _device_plan(test_loader, metric_list) is not None and hasattr(model, "_predict_tuple"):
+    (:func:`evaluate_host`); the two agree to 1e-12 (``test_evaluate_device_equals_host_evaluate``).  A subclass that overrides
+    ``predict`` always takes the host loop (its override is what the reference would call).  Ties: among EQUAL scores the device
+    top-k keeps the lower item index where numpy's argpartition order is unspecified; metrics differ only if a held-out item ties
+    with a non-held-out one exactly at rank k."""
+    if (getattr(model, "device_metrics", True) and _device_plan(test_loader, metric_list) is not None and hasattr(model, "_predict_tuple")
+            and _predict_is_ours(model)):
         return evaluate_device(model, test_loader, metric_list)
     return evaluate_host(model, test_loader, metric_list)
+
+
+def _predict_is_ours(model):
+    """True when ``model.predict`` is the framework's own method.  The reference always scores through ``model.predict``
+    (evaluation.py:100-109), so a user subclass that overrides it (re-ranking, filtering, an ensemble) must be evaluated through
+    that override: the device route calls the engine's scorer directly and would silently bypass it."""
+    fn = getattr(type(model), "predict", None)
+    mod = getattr(fn, "__module__", "") or ""
+    return "predict" not in vars(model) and mod.startswith(__name__.rsplit(".", 1)[0] + ".")
 
 
 def _device_plan(test_loader, metric_list):

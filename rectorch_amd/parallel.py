@@ -327,12 +327,21 @@ class NativePlan:
         if transport == "rccl":
             self.comm = self._new_comm()
             if self.two_comms:
-                self.comm_side = self._new_comm()
+                try:
+                    self.comm_side = self._new_comm()
+                except BaseException:
+                    self._destroy_comm("comm")       # do not leak the first communicator when the second cannot be built
+                    raise
         elif transport == "torch":
             self._ops = self._torch_ops(group)
             if self.two_comms:
                 # (a collective call: every rank of `group` builds the side group, in the same order)
                 ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+                # torch.distributed.new_group must be entered by EVERY process of the default group, also those outside `ranks`:
+                # a plan on a real subgroup would hang here.  Such a plan keeps one process group (two_comms=False) or uses the
+                # engine's own RCCL transport, whose communicators are built among the plan's ranks only.
+                assert len(ranks) == dist.get_world_size(), \
+                    "NativePlan(transport='torch', two_comms=True) on a subgroup: pass two_comms=False (or RTX_DP_ONE_COMM=1), or transport='rccl'"
                 self._side_group = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
                 self._ops_side = self._torch_ops(self._side_group)
         elif transport == "local":
@@ -486,6 +495,17 @@ class NativePlan:
                     _all_gather_blocks(buf, self.rank, self.world, self.group, native)
                 t.view(-1).copy_(buf[:rows * cols])
 
+    def _destroy_comm(self, name):
+        h = getattr(self, name, None)
+        if h is not None and h.value:
+            try:
+                from . import _lib
+                torch.cuda.synchronize()
+                _lib.lib().rtx_comm_destroy(h)
+            except Exception:
+                pass
+        setattr(self, name, None)
+
     def close(self):
         """detach the engines that use this plan, then destroy the engine's RCCL communicator (every rank, while its peers are
         still alive: before ``dist.destroy_process_group()`` / interpreter exit)."""
@@ -497,15 +517,7 @@ class NativePlan:
             except Exception:
                 pass
         for name in ("comm_side", "comm"):
-            h = getattr(self, name, None)
-            if h is not None and h.value:
-                try:
-                    from . import _lib
-                    torch.cuda.synchronize()
-                    _lib.lib().rtx_comm_destroy(h)
-                except Exception:
-                    pass
-            setattr(self, name, None)
+            self._destroy_comm(name)
         sg = getattr(self, "_side_group", None)
         if sg is not None:
             try:

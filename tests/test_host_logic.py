@@ -19,14 +19,13 @@ from rectorch_amd.parallel import shard_rows
 from rectorch_amd import utils
 
 HAS_GPU = torch.cuda.is_available()
-# rows a22 / a23 of the scope table are host numpy in the reference and here: their known-answer tests run in the CPU suite AND,
-# as a second test item, in the GPU box's `-m gpu` run (so the driver's GPU test record covers them too)
-BOTH_SUITES = pytest.mark.parametrize("suite", ["cpu", pytest.param("gpu-box", marks=pytest.mark.gpu)])
+# rows a22 / a23 of the scope table are host numpy in the reference and here: their known-answer tests belong to the CPU suite only
+# (rounds 3-5 repeated them under the gpu mark; the GPU record now counts device tests alone -- the device side of these rows is
+# test_evaluate_device_equals_host_evaluate / the top-k tests in test_gpu_parity.py)
 
 
 # ------------------------------------------------------------------ metrics (reference tests/test_metrics.py:14-82)
-@BOTH_SUITES
-def test_metrics_reference_kats(suite):
+def test_metrics_reference_kats():
     scores = np.array([[4., 3., 2., 1.]])
     gt1, gt2 = np.array([[1., 1., 0., 0.]]), np.array([[0., 0., 1., 1.]])
     assert Metrics.ndcg_at_k(scores, gt1, 2) == np.array([1.])
@@ -44,8 +43,7 @@ def test_metrics_reference_kats(suite):
     assert set(res) == {"ndcg@2", "recall@2", "ndcg_at_k"}          # unknown metric skipped
 
 
-@BOTH_SUITES
-def test_metrics_golden_g6(suite):
+def test_metrics_golden_g6():
     g = load_golden("g6_metrics")
     mets = ["ndcg@100", "ndcg@10", "recall@50", "recall@20", "hit@5", "mrr@10", "ndcg@1000"]
     res = Metrics.compute(g["scores"], g["heldout"], mets)
@@ -69,8 +67,7 @@ class FakeSampler(Sampler):
             yield scores[i], gt[i]
 
 
-@BOTH_SUITES
-def test_evaluate_and_validfunc(suite):
+def test_evaluate_and_validfunc():
     res = evaluate(FakeModel(), FakeSampler(), ["ndcg@3", "recall@2"])
     assert isinstance(res, dict) and set(res) == {"ndcg@3", "recall@2"}
     assert res['ndcg@3'][0] == 1. and abs(res['ndcg@3'][1] - 0.3065735964) < 1e-7

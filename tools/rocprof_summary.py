@@ -145,5 +145,41 @@ def pmcjson(directory):
                       "dominant": "mean over the weight-gradient + Adam launches (rtx_dw_tn / rtx_dw_tn_group)"}, indent=1))
 
 
+def diag(directory):
+    """tools/pmc_diag.sh: every counter of every pass, pivoted per (kernel, grid): one line per kernel, one column per counter,
+    plus the ratios that answer "what bounds it": L2 hit rate, bytes requested by the L1s (TCP_TCC_*_REQ x 64 B / 128 B as noted),
+    share of wave-cycles parked / issue-stalled / issuing."""
+    import glob
+    import os
+    by, order = {}, []
+    for f in sorted(glob.glob(os.path.join(directory, "diag_g*.txt"))):
+        for name, ctr, grid, calls, val, us in _read_pmc_table(f):
+            d = by.setdefault((name, grid), {})
+            d[ctr] = val
+            d.setdefault("_us", []).append(us)
+            if ctr not in order:
+                order.append(ctr)
+    keys = sorted(by, key=lambda k: -sum(by[k]["_us"]) / len(by[k]["_us"]))
+    print("# per-kernel counters (avg per launch; kernels serialised under --pmc).  us = mean traced duration over the passes")
+    for k in keys:
+        d = by[k]
+        us = sum(d["_us"]) / len(d["_us"])
+        print("%s grid=%d  avg_us=%.2f" % (k[0][:70], k[1], us))
+        for c in order:
+            if c in d:
+                print("    %-36s %18.1f" % (c, d[c]))
+        g = d.get
+        if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+            print("    %-36s %18.4f" % ("L2_hit_rate", g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
+        if g("TCP_TCC_READ_REQ_sum") is not None:
+            rd = g("TCP_TCC_READ_REQ_sum")
+            print("    %-36s %18.1f  (x64 B = %.1f MB, x128 B = %.1f MB; %.2f / %.2f TB/s)" % ("L1->L2 read requests", rd, rd * 64 / 1e6, rd * 128 / 1e6,
+                                                                                         rd * 64 / us / 1e6, rd * 128 / us / 1e6))
+        if g("SQ_WAVE_CYCLES"):
+            wc = g("SQ_WAVE_CYCLES")
+            print("    %-36s parked %.3f  issue-stalled %.3f  issuing %.3f" % ("share of wave-cycles", (g("SQ_WAIT_ANY") or 0) / wc,
+                                                                                 (g("SQ_WAIT_INST_ANY") or 0) / wc, (g("SQ_ACTIVE_INST_ANY") or 0) / wc))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline, "mfma": mfma, "pmcjson": pmcjson}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline, "mfma": mfma, "pmcjson": pmcjson, "diag": diag}[sys.argv[1]](sys.argv[2])
