@@ -131,6 +131,7 @@ struct rtx_engine {
     bool gather_done = false;         // run_forward: A[0] / tsum already hold this batch (a prefetch hit)
     int opt_prefetch = 1;             // 0: announced batches are ignored (A/B knob)
     int st_prefetch_hits = 0, st_prefetch_issued = 0;
+    int st_join_folds = 0;             // deferred joins resolved INSIDE a first-layer product (get_option "join_folds")
     int opt_gather_scatter = 1;       // 0: k_gather rewrites the whole image every batch (rounds 1-3)
     // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
     hipStream_t side = nullptr;
@@ -1352,7 +1353,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
             ++e->st_prefetch_hits;
             // this step starts with the first-layer product: the open join rides on it (run_forward; every workgroup checks the
             // number the side stream stored -- long ago -- before it touches the prefetched image)
-            if (join_open && e->opt_hop_fold && e->bf16 && fold_has_room(e, Bp, e->L[0].outp, e->L[0].inp)) { e->join_fold = true; join_open = false; }
+            if (join_open && e->opt_hop_fold && e->bf16 && fold_has_room(e, Bp, e->L[0].outp, e->L[0].inp)) { e->join_fold = true; join_open = false; ++e->st_join_folds; }
         }
     }
     if (join_open) {   // any other start: a one-wave kernel in front of the step
@@ -2266,6 +2267,7 @@ int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
     else if (k == "dp_collectives") *value = e->dp.st_collectives;
     else if (k == "dp_one_comm") *value = e->opt_dp_one_comm;
     else if (k == "prefetch") *value = e->opt_prefetch;
+    else if (k == "join_folds") *value = e->st_join_folds;             // deferred joins that rode on a first-layer product
     else if (k == "prefetch_hits") *value = e->st_prefetch_hits;       // steps that started from a prefetched batch image
     else if (k == "prefetch_issued") *value = e->st_prefetch_issued;
     else if (k == "dp_two_comms") *value = e->dp.on && e->dp.two_comms;   // bucket A's collectives have a communicator of their own

@@ -11,7 +11,9 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-#define RTX_LDS_ROW 144  // 128 B of K + 16 B pad: conflict-free ds_read_b128 fragment reads
+// LDS row = KB bytes of K + 16 B pad: conflict-free ds_read_b128 fragment reads for KB = 128 (36-dword stride) and KB = 64 (20-dword
+// stride: rows r = 0..15 of a lane group start at banks 20 r mod 64 = 0,20,40,60,16,36,56,12,32,52,8,28,48,4,24,44 -- 16 disjoint quads)
+#define RTX_LDS_ROW_OF(KB) ((KB) + 16)
 
 template <typename T> struct Mma;
 
@@ -53,23 +55,29 @@ template <> struct Mma<float> {
 // WM x WN waves; every wave owns a 64 x (32*NB) block of C (2 x NB MFMA 32x32 accumulators).
 // 128x128 = 2x2 waves, 256x128 = 4x2, 128x256 = 2x4.  (256x256 was tried as 4x2 waves of 64x128 and as 4x4 waves of
 // 64x64: both spill accumulators at their VGPR budgets with this source structure, so it is not shipped.)
-template <int WM, int WN, int NB> struct TileCfg {
+// KB: bytes of K per row and slice.  128 everywhere but the logits product (K = hidden width, 10 slices): at 128 its 128 x 128 tile needs
+// 73.7 KB of LDS -- two workgroups per CU, 512 slots for 632 tiles: a second, quarter-full round (measured: each workgroup lives 14 us, the
+// kernel 28).  At KB = 64 a workgroup takes 41 KB and <= 168 registers: THREE per CU, 768 slots, every tile resident at once.
+template <int WM, int WN, int NB, int KB = 128> struct TileCfg {
     static constexpr int NT = WM * WN * 64;       // threads
     static constexpr int BM = WM * 64;            // tile rows
     static constexpr int BN = WN * NB * 32;       // tile columns
-    static constexpr int RPP = NT / 8;            // rows staged per pass (8 lanes x 16 B cover one 128-B row slice)
+    static constexpr int LPR = KB / 16;           // lanes per row slice (16 B each)
+    static constexpr int RPP = NT / LPR;          // rows staged per pass
     static constexpr int PA = BM / RPP;           // staging passes for A (2 or 4)
     static constexpr int PB = BN / RPP;           // staging passes for B (2 or 4)
-    static constexpr int STAGE = (BM + BN) * RTX_LDS_ROW;
+    static constexpr int ROW = RTX_LDS_ROW_OF(KB);
+    static constexpr int STAGE = (BM + BN) * ROW;
     static_assert(PA == 2 || PA == 4, "PA");
     static_assert(PB == 2 || PB == 4, "PB");
 };
 
-template <typename T, int EPI, int WM, int WN, int NB>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2) void rtx_gemm_nt(const RtxGemm p)
+template <typename T, int EPI, int WM, int WN, int NB, int KB = 128>
+__global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)) void rtx_gemm_nt(const RtxGemm p)
 {
-    using Cfg = TileCfg<WM, WN, NB>;
+    using Cfg = TileCfg<WM, WN, NB, KB>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, RPP = Cfg::RPP, PA = Cfg::PA, PB = Cfg::PB, STAGE = Cfg::STAGE;
+    constexpr int RTX_LDS_ROW = Cfg::ROW, LPR_ST = Cfg::LPR;
     // [stage][A rows | B rows]; all LDS in one array (a second __shared__ object de-pipelines, cdna guide)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
@@ -120,13 +128,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
             if (tm >= p.m_tiles) return;
         }
     }
-    const int per = (p.k_slices + p.splits - 1) / p.splits;
+    const int k_sl = p.k_slices * (128 / KB);      // (p.k_slices counts 128-byte slices)
+    const int per = (k_sl + p.splits - 1) / p.splits;
     const int ks0 = split * per;
-    const int ks1 = min(ks0 + per, p.k_slices);
+    const int ks1 = min(ks0 + per, k_sl);
     const int nk = ks1 - ks0;
 
     const size_t rowA = (size_t)p.lda * sizeof(T), rowB = (size_t)p.ldb * sizeof(T);
-    const int st_row = tid >> 3, st_ch = tid & 7;  // staging: 8 lanes x 16 B = one 128-B row slice
+    const int st_row = tid / LPR_ST, st_ch = tid % LPR_ST;  // staging: LPR lanes x 16 B = one KB-byte row slice
     const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * BM + st_row) * rowA + st_ch * 16;
     const unsigned char* gB = (const unsigned char*)p.B + ((size_t)tn * BN + st_row) * rowB + st_ch * 16;
     const int lds_a = st_row * RTX_LDS_ROW + st_ch * 16;
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#define RTX_GL(R, X, q, base, row, ks) R##X##q = *(const uint4*)((base) + (size_t)(q) * RPP * (row) + (size_t)(ks) * 128);
+#define RTX_GL(R, X, q, base, row, ks) R##X##q = *(const uint4*)((base) + (size_t)(q) * RPP * (row) + (size_t)(ks) * KB);
 #define RTX_GLOAD(R, ks)                                                    \
     RTX_GL(R, a, 0, gA, rowA, ks) RTX_GL(R, a, 1, gA, rowA, ks)             \
     if (PA == 4) { RTX_GL(R, a, 2, gA, rowA, ks) RTX_GL(R, a, 3, gA, rowA, ks) } \
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)
     {                                                                                                         \
         const unsigned char* sA = smem + (st) * STAGE + (wm * 64 + r) * RTX_LDS_ROW + g * 16;                 \
         const unsigned char* sB = smem + (st) * STAGE + (BM + wn * (NB * 32) + r) * RTX_LDS_ROW + g * 16;     \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < KB / 32; ++kk) {                                              \
             const uint4 a0 = *(const uint4*)(sA + kk * 32);                                                   \
             const uint4 a1 = *(const uint4*)(sA + 32 * RTX_LDS_ROW + kk * 32);                                \
             _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                  \
@@ -371,6 +380,12 @@ static void launch_shape(const RtxGemm& g, int epilogue, dim3 grid, hipStream_t 
 
 template <typename T> static void launch_type(const RtxGemm& g, int epilogue, dim3 grid, hipStream_t stream)
 {
+    if constexpr (sizeof(T) == 2) {
+        if (g.tile_shape == RTX_TILE_128x128_K32) {   // (rtx_gemm_launch has checked: bias epilogue)
+            hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_BIAS_ROWS, 2, 2, 2, 64>), grid, dim3(256), 0, stream, g);
+            return;
+        }
+    }
     switch (g.tile_shape) {
     case RTX_TILE_256x128: launch_shape<T, 4, 2, 2>(g, epilogue, grid, stream); break;
     case RTX_TILE_128x256: launch_shape<T, 2, 4, 2>(g, epilogue, grid, stream); break;
@@ -393,7 +408,9 @@ int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t strea
                       g.ldc16 >= (long)g.n_tiles * bn16,
                   RTX_EINVAL, "gemm: half-precision logits need the bias epilogue, bf16 operands and an 8-byte aligned [M][ldc16 >= N_pad] image");
     }
-    RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x256, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
+    RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x128_K32, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
+    RTX_CHECK(g.tile_shape != RTX_TILE_128x128_K32 || (dtype == RTX_DT_BF16 && epilogue == RTX_EPI_BIAS_ROWS), RTX_EINVAL,
+              "gemm: the 64-byte-slice tile exists for bf16 operands with the bias epilogue only");
     // 1-D grid laid out for the XCD-aware mapping in the kernel: 8 * ceil(groups / 8) * group_size workgroups
     const int tiles = g.m_tiles * g.n_tiles;
     int groups, gsize;

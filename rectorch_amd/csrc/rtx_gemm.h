@@ -42,6 +42,7 @@ enum RtxTileShape {     // workgroup tile of C; 128x128 runs 4 waves, the others
     RTX_TILE_128x128 = 0,
     RTX_TILE_256x128 = 1,
     RTX_TILE_128x256 = 2,
+    RTX_TILE_128x128_K32 = 3,   // bf16 + RTX_EPI_BIAS_ROWS only: 64-byte K slices, 41 KB of LDS -> three workgroups per CU (the logits product)
 };
 void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
 

@@ -27,6 +27,8 @@ and small layers stay replicated (all-reduce + identical update).
 Small layers are coalesced into one message (``min_bucket_bytes``).  Works with any torch.distributed
 backend: "nccl" (= RCCL on ROCm) for device tensors, "gloo" for the CPU tests of the plan itself.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -495,6 +497,80 @@ class NativePlan:
                     _all_gather_blocks(buf, self.rank, self.world, self.group, native)
                 t.view(-1).copy_(buf[:rows * cols])
 
+    def self_check(self, sizes=None, timeout_s=30.0):
+        """right after the communicators come up -- before any timed or training step -- run one all-reduce, one
+        reduce-scatter and one all-gather of the REAL bucket sizes on every communicator, each on a stream of its own and all of
+        them in flight at once (the way the step uses them), and compare every element with a host-computed result.  A first-ever
+        multi-rank RCCL problem (a rank that never joins, a wrong ring, a communicator pair that deadlocks when both are busy) then
+        surfaces as ONE clear exception within ``timeout_s`` instead of a hang inside the first training step.
+
+        ``sizes``: element counts (bucket A, bucket B) in the plan's exchange dtype; default 2^20 each.  Returns a dict with what
+        was moved.  Transports other than "rccl" have nothing of their own to check (torch.distributed / threads / emulation)."""
+        import threading
+        import numpy as np
+        from . import _lib
+        if self.transport != "rccl":
+            return {"checked": False, "transport": self.transport}
+        W, R = self.world, self.rank
+        dt = self.comm_dtype if self.comm_dtype in (torch.float32, torch.bfloat16) else torch.float32
+        code = _lib.RTX_BF16 if dt == torch.bfloat16 else _lib.RTX_FP32
+        esz = 2 if dt == torch.bfloat16 else 4
+        comms = [("main", self.comm)] + ([("side", self.comm_side)] if self.comm_side is not None else [])
+        sizes = list(sizes) if sizes else [1 << 20] * len(comms)
+        sizes = (sizes + sizes[-1:] * len(comms))[:len(comms)]
+        L = _lib.lib()
+        work, report = [], {"checked": True, "world": W, "dtype": str(dt).replace("torch.", ""), "comms": []}
+        for ci, ((name, comm), n) in enumerate(zip(comms, sizes)):
+            n = max(W * 64, (int(n) + W * 64 - 1) // (W * 64) * (W * 64))        # world equal, 128-byte aligned blocks
+            idx = torch.arange(n, device="cuda", dtype=torch.int64)
+            # small integers: their sums over <= 64 ranks are exact in bfloat16 and float32 alike
+            def pattern(r, salt):
+                return ((idx * 7 + r * 13 + salt) % 5 - 2)
+            st = torch.cuda.Stream()
+            a = pattern(R, ci).to(dt)
+            b = pattern(R, ci + 3).to(dt)
+            c = torch.full((n,), -1.0, device="cuda", dtype=dt)
+            blk = n // W
+            c[R * blk:(R + 1) * blk] = float(R + 1)
+            want_a = sum(pattern(r, ci) for r in range(W)).to(torch.float32)
+            want_b = sum(pattern(r, ci + 3) for r in range(W)).to(torch.float32)[R * blk:(R + 1) * blk]
+            want_c = (torch.arange(n, device="cuda") // blk + 1).to(torch.float32)
+            torch.cuda.current_stream().synchronize()
+            work.append((name, comm, st, n, a, b, c, want_a, want_b, want_c, blk))
+        err = []
+
+        def issue_and_wait():
+            try:
+                for name, comm, st, n, a, b, c, *_ in work:      # everything enqueued first: all communicators busy at once
+                    sp = C.c_void_p(st.cuda_stream)
+                    _lib.check(L.rtx_comm_allreduce(comm, C.c_void_p(a.data_ptr()), n, code, sp))
+                    _lib.check(L.rtx_comm_reduce_scatter(comm, C.c_void_p(b.data_ptr()), n, code, sp))
+                    _lib.check(L.rtx_comm_allgather(comm, C.c_void_p(c.data_ptr()), n * esz, sp))
+                for _, _, st, *_ in work:
+                    st.synchronize()
+            except BaseException as ex:       # noqa: BLE001 -- reported by the caller's thread
+                err.append(ex)
+
+        import ctypes as C
+        th = threading.Thread(target=issue_and_wait, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            raise RuntimeError("data-parallel self-check: rank %d of %d: the first collectives (all-reduce, reduce-scatter, all-gather on %d "
+                               "communicator(s) at once) did not complete within %.0f s -- a peer rank has not joined, or RCCL cannot run the two "
+                               "communicators concurrently on this node (try RTX_DP_ONE_COMM=1)" % (R, W, len(work), timeout_s))
+        if err:
+            raise RuntimeError("data-parallel self-check: rank %d of %d: %r" % (R, W, err[0]))
+        for name, comm, st, n, a, b, c, want_a, want_b, want_c, blk in work:
+            bad_a = int((a.to(torch.float32) != want_a).sum().item())
+            bad_b = int((b[R * blk:(R + 1) * blk].to(torch.float32) != want_b).sum().item())
+            bad_c = int((c.to(torch.float32) != want_c).sum().item())
+            if bad_a or bad_b or bad_c:
+                raise RuntimeError("data-parallel self-check: rank %d of %d, communicator '%s', %d elements: %d wrong after all-reduce, %d after "
+                                   "reduce-scatter, %d after all-gather" % (R, W, name, n, bad_a, bad_b, bad_c))
+            report["comms"].append({"name": name, "elements": n, "bytes_per_collective": n * esz})
+        return report
+
     def _destroy_comm(self, name):
         h = getattr(self, name, None)
         if h is not None and h.value:
@@ -795,6 +871,12 @@ def attach(model, group=None, min_bucket_bytes=4 << 20, fixed_global_batch=None,
                 plan, transport = None, "torch"
         if plan is None:
             plan = NativePlan(dist.get_rank(group), world, sharded, comm_dtype, group, "torch", shard_min_elems, two_comms)
+        elif os.environ.get("RTX_DP_SELF_CHECK", "1") != "0":
+            # both communicators are up: one all-reduce + reduce-scatter + all-gather of the step's real bucket sizes on each, all in
+            # flight at once, checked against host-computed sums -- a multi-rank RCCL problem is a clear error here, not a hang in step 1
+            n_a = params[-2].numel() + params[-1].numel()                  # bucket A: the decoder matrix and its bias
+            n_b = sum(p.numel() for p in params) - n_a                     # bucket B: everything else
+            plan.self_check_report = plan.self_check(sizes=(n_b, n_a))     # ("main" carries bucket B, "side" bucket A)
         if fixed_global_batch is not None:
             plan.global_batch = lambda local, _g=int(fixed_global_batch): _g
         st.reducer = plan

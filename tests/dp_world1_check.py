@@ -39,6 +39,12 @@ def run(g, comm_dtype, bucket_adam, min_bucket, sharded=False, numerics="fp32", 
             assert len(red.buckets()) >= 2 and bool(red.shard_layers) == sharded
         else:
             assert red.native and red.transport == "rccl" and red.sharded == sharded
+            # the start-up self-check of the communicators ran (one all-reduce + reduce-scatter + all-gather of the real bucket sizes on
+            # each communicator, both busy at once, against host-computed sums) -- the only part of a first multi-rank run that a
+            # one-GPU box can exercise: same calls, same streams, world 1
+            rep = red.self_check_report
+            assert rep["checked"] and rep["world"] == 1 and len(rep["comms"]) == (2 if red.comm_side is not None else 1), rep
+            assert all(c["elements"] >= 64 for c in rep["comms"]), rep
     losses = []
     for t in range(g["xs"].shape[0]):
         model._rtx.inject = (dev(g["mask_%d" % t], torch.uint8), dev(g["eps_%d" % t]))

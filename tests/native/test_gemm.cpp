@@ -359,6 +359,41 @@ static int run_logits16_case(int M, int N, int K, int M_real, int N_real, int sh
     return bad != 0;
 }
 
+// the logits product as the training step launches it: half-precision logits + log-sum-exp strip partials
+static void perf_logits16(int M, int N, int K, int shape)
+{
+    bf16_t *A, *B;
+    float* bias;
+    _Float16* C16;
+    float2* part;
+    std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+    for (auto& v : hA) v = f32_to_bf16(frand());
+    for (auto& v : hB) v = f32_to_bf16(frand() * 0.1f);
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&C16, (size_t)M * N * 2));
+    CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&part, (size_t)M * (N / 64) * 8));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(bias, 0, N * 4));
+    RtxGemm g = {};
+    g.A = A; g.B = B; g.lda = K; g.ldb = K;
+    int bm, bn;
+    rtx_gemm_tile_dims(shape, &bm, &bn);
+    g.tile_shape = shape; g.m_tiles = M / bm; g.n_tiles = N / bn; g.k_slices = K * 2 / 128; g.splits = 1;
+    g.ldc = N; g.bias = bias; g.M_real = M - 12; g.N_real = N - 116; g.lse_part = part; g.lse_ld = N / 64; g.C16 = C16; g.ldc16 = N;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) rtx_gemm_launch(g, RTX_DT_BF16, RTX_EPI_BIAS_ROWS, 0);
+    CK(hipEventRecord(e0, 0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) rtx_gemm_launch(g, RTX_DT_BF16, RTX_EPI_BIAS_ROWS, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1000.0 / it;
+    printf("[perf logits16+lse] bf16 M=%d N=%d K=%d tile%d: %.1f us  %.1f TFLOP/s\n", M, N, K, shape, us, 2.0 * M * N * K / us * 1e-6);
+    hipFree(A); hipFree(B); hipFree(C16); hipFree(bias); hipFree(part);
+}
+
 // ---- weight gradient in TN form, fused with Adam (dw_adam.hip) -------------------------------------------------------------------
 static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_real, int K_real, float lam, float wd, int keep)
 {
@@ -680,6 +715,99 @@ static int run_dw_cases()
     return fails;
 }
 
+// the fused epilogue's hardware sqrt / rcp (dw_adam.hip dw_finish4) isolated from operand rounding.  100 Adam
+// steps of rtx_dw_tn<..., ADAM> on fresh bf16 operands each step; the gradient the epilogue used leaves through `gkeep`, and the
+// EXACT update (k_adam's expressions: IEEE sqrtf and division, float32, torch.optim.Adam semantics -- reference models.py:768-770)
+// is applied by a kernel of this file to a second copy of (p, m, v) from the SAME gradient bits.  The two copies never exchange
+// values: the drift accumulates as it would in training.  Bounds: after 100 steps the parameters differ by at most 2e-6 of the
+// distance an update of size lr per step can cover (measured: 2e-8 absolute = 5e-7 of the motion); the moments carry no approximation
+// (last-bit differences from FMA contraction are bounded at rounding level).
+__global__ void k_exact_adam(float* p, float* m, float* v, const float* g, size_t n, float step_size, float bc2_sqrt, float b1, float b2, float eps)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gg = g[i];
+    const float m1 = m[i] + (gg - m[i]) * (1.f - b1);
+    const float v1 = v[i] * b2 + (1.f - b2) * gg * gg;
+    const float denom = sqrtf(v1) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (m1 / denom);
+    m[i] = m1;
+    v[i] = v1;
+}
+
+static int run_adam_approx_isolation(int cfg)
+{
+    const int M_real = 130, N_real = 600, K_real = 500, STEPS = 100;
+    const int Mp = rtx_pad(M_real), Np = rtx_pad(N_real), Kp = rtx_pad_batch(K_real);
+    const size_t P = (size_t)M_real * N_real;
+    std::vector<float> hp(P);
+    for (auto& w : hp) w = frand() * 0.05f;
+    bf16_t *D, *X, *sh;
+    float *p, *m, *v, *gk, *gb, *xp, *xm, *xv;
+    CK(hipMalloc(&D, (size_t)Kp * Mp * 2)); CK(hipMalloc(&X, (size_t)Kp * Np * 2));
+    CK(hipMalloc(&p, P * 4)); CK(hipMalloc(&m, P * 4)); CK(hipMalloc(&v, P * 4)); CK(hipMalloc(&gk, P * 4)); CK(hipMalloc(&gb, Mp * 4));
+    CK(hipMalloc(&xp, P * 4)); CK(hipMalloc(&xm, P * 4)); CK(hipMalloc(&xv, P * 4));
+    CK(hipMalloc(&sh, (size_t)Mp * Np * 2));
+    CK(hipMemcpy(p, hp.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemset(m, 0, P * 4)); CK(hipMemset(v, 0, P * 4));
+    CK(hipMemcpy(xp, hp.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemset(xm, 0, P * 4)); CK(hipMemset(xv, 0, P * 4));
+    const float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    std::vector<bf16_t> hD((size_t)Kp * Mp, 0), hX((size_t)Kp * Np, 0);
+    std::vector<float> gp(P), gm(P), gv(P), ep(P), em(P), ev(P);
+    double worst_growth = 0, prev = 0;
+    for (int step = 1; step <= STEPS; ++step) {
+        // gradients of realistic spread: most entries small (sqrt(v) near eps matters), every 17th row 100x larger
+        for (int k = 0; k < K_real; ++k) {
+            for (int mm = 0; mm < M_real; ++mm) hD[(size_t)k * Mp + mm] = f32_to_bf16(frand() * (mm % 17 == 0 ? 2e-2f : 2e-4f));
+            for (int n = 0; n < N_real; ++n) hX[(size_t)k * Np + n] = f32_to_bf16(frand());
+            hX[(size_t)k * Np + N_real] = f32_to_bf16(1.f);
+        }
+        CK(hipMemcpy(D, hD.data(), hD.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
+        RtxDw d = {};
+        d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
+        d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+        d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
+        const float step_size = (float)(lr / (1.0 - pow((double)b1, step))), bc2 = (float)sqrt(1.0 - pow((double)b2, step));
+        d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.gkeep = gk; d.adam.sh = sh; d.adam.ld_sh = Np;
+        d.adam.step_size = step_size; d.adam.bc2_sqrt = bc2; d.adam.beta1 = b1; d.adam.beta2 = b2; d.adam.eps = eps;
+        if (rtx_dw_launch(d, RTX_DW_ADAM, cfg, 0)) { printf("[adam-approx] launch failed: %s\n", rtx_last_error_str()); return 1; }
+        hipLaunchKernelGGL(k_exact_adam, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, 0, xp, xm, xv, gk, P, step_size, bc2, b1, b2, eps);
+        CK(hipDeviceSynchronize());
+        if (step % 10 == 0 || step == 1) {
+            CK(hipMemcpy(gp.data(), p, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ep.data(), xp, P * 4, hipMemcpyDeviceToHost));
+            double dd = 0;
+            for (size_t i = 0; i < P; ++i) dd = fmax(dd, fabs((double)gp[i] - ep[i]));
+            worst_growth = fmax(worst_growth, (dd - prev) / (step == 1 ? 1 : 10));
+            prev = dd;
+        }
+    }
+    CK(hipMemcpy(gp.data(), p, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gm.data(), m, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gv.data(), v, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ep.data(), xp, P * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(em.data(), xm, P * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ev.data(), xv, P * 4, hipMemcpyDeviceToHost));
+    double drift = 0, moved = 0, dm = 0, dv = 0, mx_m = 0, mx_v = 0;
+    long moment_bits = 0;
+    for (size_t i = 0; i < P; ++i) {
+        drift = fmax(drift, fabs((double)gp[i] - ep[i]));
+        moved = fmax(moved, fabs((double)ep[i] - hp[i]));
+        if (memcmp(&gm[i], &em[i], 4) || memcmp(&gv[i], &ev[i], 4)) ++moment_bits;
+        dm = fmax(dm, fabs((double)gm[i] - em[i])); mx_m = fmax(mx_m, fabs((double)em[i]));
+        dv = fmax(dv, fabs((double)gv[i] - ev[i])); mx_v = fmax(mx_v, fabs((double)ev[i]));
+    }
+    // each step's update is <= ~lr; 1-ulp sqrt and rcp put it off by <= ~3e-7 of itself, plus float32 roundings of the parameter
+    // (|p| <= 0.15 -> spacing <= 1.5e-8) that can fall differently in the two copies.  The moments carry no approximation; they may
+    // still differ in their last bits because the compiler contracts  m + (g - m)(1 - b1)  and  v b2 + (1 - b2) g g  into different
+    // fused multiply-adds in the two kernels: bounded at float32 rounding level of the tensors' scale.
+    const double total_bound = 2e-6 * lr * STEPS + 1.5e-8 * 10;
+    const bool ok = drift <= total_bound && dm <= 1e-6 * mx_m && dv <= 4e-6 * mx_v;
+    printf("[adam-approx-isolation] cfg%d %dx%d K=%d, %d steps: max |p_fused - p_exact| %.3e (bound %.3e; parameters moved by up to %.3e -> %.1e of the motion), "
+           "largest growth per step %.2e; moments: max |dm| %.1e of max |m| %.1e, max |dv| %.1e of max |v| %.1e (%ld of %zu words differ in their last bits: "
+           "FMA contraction) -> %s\n",
+           cfg, M_real, N_real, K_real, STEPS, drift, total_bound, moved, drift / fmax(moved, 1e-30), worst_growth, dm, mx_m, dv, mx_v, moment_bits, 2 * P, ok ? "ok" : "FAIL");
+    hipFree(D); hipFree(X); hipFree(p); hipFree(m); hipFree(v); hipFree(gk); hipFree(gb); hipFree(sh); hipFree(xp); hipFree(xm); hipFree(xv);
+    return ok ? 0 : 1;
+}
+
 // ---- "mfmaclk": what the matrix pipes deliver from registers alone, and the shader clock they run at (round 4) -----------------
 // Every wave issues independent-accumulator MFMAs with register operands for a few hundred microseconds: no LDS, no memory.  Per
 // workgroup: shader-clock cycles and the 100-MHz real-time counter across the loop -> the clock under sustained matrix load; from
@@ -890,6 +1018,24 @@ int main(int argc, char** argv)
         printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
         return fails ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "adamiso")) {
+        fails += run_adam_approx_isolation(RTX_DW_64x128);
+        fails += run_adam_approx_isolation(RTX_DW_128x128);
+        printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
+        return fails ? 1 : 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "logits")) {   // round 6: the logits product, 128-byte slices (2 workgroups/CU) vs 64-byte slices (3/CU)
+        fails += run_case<bf16_t>("bias-k32", 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, RTX_TILE_128x128_K32);
+        fails += run_case<bf16_t>("bias-wide-k32", 256, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 250, 2300, RTX_TILE_128x128_K32);
+        fails += run_case<bf16_t>("bias-odd-k32", 128, 256, 192, 1, RTX_EPI_BIAS_ROWS, 77, 131, RTX_TILE_128x128_K32);
+        fails += run_logits16_case(512, 768, 640, 410, 701, RTX_TILE_128x128_K32, 1.f);
+        fails += run_logits16_case(256, 2304, 128, 250, 2300, RTX_TILE_128x128_K32, 4000.f);
+        for (int rep = 0; rep < 3; ++rep)
+            for (int shape : {0, 3, 1}) perf_logits16(512, 20224, 640, shape);
+        for (int shape : {0, 3}) perf_logits16(4096, 17920, 640, shape);
+        printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
+        return fails ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "big")) {   // only the big-tile GEMM lines (round 3)
         for (int cfg : {RTX_DMA_256x256, RTX_DMA_256x256_W4, RTX_DMA_512x128}) {
             for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
@@ -923,6 +1069,12 @@ int main(int argc, char** argv)
         fails += run_case<float>("bias", 512, 768, 320, 1, RTX_EPI_BIAS_ROWS, 410, 701, shape);
         fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
     }
+    // the 64-byte-slice tile (three workgroups per CU): bias epilogue only, float32 and half logits, ragged edges, K of one slice
+    fails += run_case<bf16_t>("bias-k32", 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, RTX_TILE_128x128_K32);
+    fails += run_case<bf16_t>("bias-wide-k32", 256, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 250, 2300, RTX_TILE_128x128_K32);
+    fails += run_case<bf16_t>("bias-odd-k32", 128, 256, 192, 1, RTX_EPI_BIAS_ROWS, 77, 131, RTX_TILE_128x128_K32);
+    fails += run_logits16_case(512, 768, 640, 410, 701, RTX_TILE_128x128_K32, 1.f);
+    fails += run_logits16_case(256, 2304, 128, 250, 2300, RTX_TILE_128x128_K32, 4000.f);
     fails += tr_probe();
     for (int cfg = 0; cfg < 6; ++cfg) {   // 128x128 (4 waves, 3 stages), 512x128 and 256x256 (8 waves, 2 stages), 128x128 (2 stages), 256x256 on 4 waves, 256x256 on 8 + 4 loader waves
         for (int form : {RTX_FORM_NT, RTX_FORM_NN}) {
@@ -936,6 +1088,7 @@ int main(int argc, char** argv)
         fails += run_dma_case("bias-wide", RTX_FORM_NT, cfg, 512, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 500, 2300, 0);
     }
     fails += run_dw_cases();
+    fails += run_adam_approx_isolation(RTX_DW_64x128);
     for (int form : {RTX_FORM_NN, RTX_FORM_TN}) {
         fails += run_f32_case("store", form, 256, 384, 352, 1, RTX_EPI_STORE, 256, 384);
         fails += run_f32_case("splitk3", form, 256, 384, 352, 3, RTX_EPI_STORE, 256, 384);

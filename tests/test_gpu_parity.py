@@ -1106,13 +1106,33 @@ def test_loss_mailbox_returns_this_steps_loss(numerics):
                 assert losses[-1] == float(model._rtx.loss_buf[0].item())
         eng = net._rtx_engines[numerics]
         assert bool(getattr(eng, "_mailbox", False)) == mailbox
-        if mailbox:
-            with pytest.raises(_lib.RtxError, match="did not report its loss"):
-                eng.wait_loss(10 ** 6, timeout_s=0.05)
         out.append((losses, [p.detach().cpu().numpy().copy() for p in net._param_list()]))
+        if mailbox:
+            # a step that never ran: the mailbox belongs to the LAST step enqueued (keyed by the engine's own ticket), said at once
+            with pytest.raises(_lib.RtxError, match="holds the LAST step enqueued"):
+                eng.wait_loss(10 ** 6, timeout_s=0.05)
+            # a step count that RESTARTS on the same engine (a new trainer = a new optimizer around the same network, as after
+            # reloading a checkpoint): step 1 of the new trainer must not be answered by the mailbox entry of the old trainer's step 1
+            from rectorch_amd.models import MultiVAE
+            model2 = MultiVAE(net, beta=0.2, anneal_steps=0, learning_rate=1e-3, numerics=numerics)
+            model2.loss_mailbox = True
+            assert net._rtx_engines[numerics] is eng
+            for rb in list(DataSampler(X, batch_size=B, shuffle=False).iter_rows())[:2]:
+                got = model2.train_batch(rb)
+                torch.cuda.synchronize()
+                assert got == float(model2._rtx.loss_buf[0].item()) and got != losses[0]
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for a, b in zip(out[0][1], out[1][1]):
         assert np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+def test_stress_folded_hops_under_foreign_load():
+    """20 000 steps at the flagship shape with prefetch + deferred (folded) join + folded fork while a second
+    process hammers the same GPU; an integer checksum of all parameters every 1 000 steps equals, bit for bit, the one of the same
+    run on the plain event-only schedule (tests/stress_sync_check.py).  Reference semantics: models.py:409-419 (a step sees the
+    previous step's completed update)."""
+    out = subprocess.run([os.sys.executable, os.path.join(ROOT, "tests", "stress_sync_check.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "STRESS OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
 def test_prefetched_batches_equal_self_gathered_batches():
@@ -1794,7 +1814,10 @@ def test_ml20m_shape_b500_two_steps_vs_oracle(numerics):
             assert em < 5e-5 and ev < 5e-5, (k, em, ev)
         else:
             assert frac < 5e-3 and float(d.mean()) < 1.2e-5, (k, frac, float(d.mean()))
-            assert em < 2.5e-2 and ev < 2.5e-2, (k, em, ev)
+            # (round 6: tightened from 2.5e-2 towards what is achieved; the approximate sqrt / rcp of the fused epilogue has no part in it --
+            #  tests/native/test_gemm.cpp run_adam_approx_isolation holds that to 5e-7 of the parameters' motion -- this is operand rounding)
+            # achieved on MI355X: exp_avg <= 1.3e-2 (the 200 -> 600 decoder matrix; 5e-3 elsewhere), exp_avg_sq <= 5.7e-3
+            assert em < 2e-2 and ev < 1e-2, (k, em, ev)
     assert model._rtx.adam_step == 2
     if not fp32:
         assert bool(net._rtx_engines[numerics].get_option("last_sparse_in")) == sparse_in
