@@ -72,7 +72,9 @@ template <int WM, int WN, int NB, int KB = 128> struct TileCfg {
     static_assert(PB == 2 || PB == 4, "PB");
 };
 
-template <typename T, int EPI, int WM, int WN, int NB, int KB = 128>
+// ABL (measurement builds only, tests/native/test_gemm.cpp "ablate"): 1 = no global loads in the loop, 2 = no LDS stores, 4 = no MFMAs (fragment reads
+// kept alive), 8 = no fragment reads and no MFMAs, 16 = no barriers, 32 = no epilogue stores.  0 in every shipped instantiation.
+template <typename T, int EPI, int WM, int WN, int NB, int KB = 128, int ABL = 0, int SCH = 0>
 __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (WM * WN) / 4 : 2)) void rtx_gemm_nt(const RtxGemm p)
 {
     using Cfg = TileCfg<WM, WN, NB, KB>;
@@ -155,28 +157,52 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
 
 #define RTX_GL(R, X, q, base, row, ks) R##X##q = *(const uint4*)((base) + (size_t)(q) * RPP * (row) + (size_t)(ks) * KB);
 #define RTX_GLOAD(R, ks)                                                    \
+    if (!(ABL & 1) || (ks) == ks0)                                           \
+    RTX_GLOAD_(R, ks)
+#define RTX_GLOAD_(R, ks) {                                                 \
     RTX_GL(R, a, 0, gA, rowA, ks) RTX_GL(R, a, 1, gA, rowA, ks)             \
     if (PA == 4) { RTX_GL(R, a, 2, gA, rowA, ks) RTX_GL(R, a, 3, gA, rowA, ks) } \
     RTX_GL(R, b, 0, gB, rowB, ks) RTX_GL(R, b, 1, gB, rowB, ks)             \
-    if (PB == 4) { RTX_GL(R, b, 2, gB, rowB, ks) RTX_GL(R, b, 3, gB, rowB, ks) }
+    if (PB == 4) { RTX_GL(R, b, 2, gB, rowB, ks) RTX_GL(R, b, 3, gB, rowB, ks) } }
 #define RTX_LS(R, X, q, off, st) *(uint4*)(smem + (st) * STAGE + (off) + (q) * RPP * RTX_LDS_ROW) = R##X##q;
 #define RTX_LSTORE(R, st)                                                   \
+    if (!(ABL & 2))                                                          \
+    RTX_LSTORE_(R, st)
+#define RTX_LSTORE_(R, st) {                                                \
     RTX_LS(R, a, 0, lds_a, st) RTX_LS(R, a, 1, lds_a, st)                   \
     if (PA == 4) { RTX_LS(R, a, 2, lds_a, st) RTX_LS(R, a, 3, lds_a, st) }  \
     RTX_LS(R, b, 0, lds_b, st) RTX_LS(R, b, 1, lds_b, st)                   \
-    if (PB == 4) { RTX_LS(R, b, 2, lds_b, st) RTX_LS(R, b, 3, lds_b, st) }
+    if (PB == 4) { RTX_LS(R, b, 2, lds_b, st) RTX_LS(R, b, 3, lds_b, st) } }
 #define RTX_COMPUTE(st)                                                                                       \
-    {                                                                                                         \
+    if (!(ABL & 8)) {                                                                                         \
         const unsigned char* sA = smem + (st) * STAGE + (wm * 64 + r) * RTX_LDS_ROW + g * 16;                 \
         const unsigned char* sB = smem + (st) * STAGE + (BM + wn * (NB * 32) + r) * RTX_LDS_ROW + g * 16;     \
+        if (SCH == 1) {                                                                                       \
+            /* every fragment read of the slice in flight before the first MFMA (ablation, round 6: the reads' LATENCY chain -- */ \
+            /* read, wait, multiply, read ... -- was half of this loop's time; the matrix pipe was never the limit) */         \
+            uint4 fa[KB / 32][2], fb[KB / 32][NB];                                                            \
+            _Pragma("unroll") for (int kk = 0; kk < KB / 32; ++kk) {                                          \
+                fa[kk][0] = *(const uint4*)(sA + kk * 32);                                                    \
+                fa[kk][1] = *(const uint4*)(sA + 32 * RTX_LDS_ROW + kk * 32);                                 \
+                _Pragma("unroll") for (int j = 0; j < NB; ++j) fb[kk][j] = *(const uint4*)(sB + j * 32 * RTX_LDS_ROW + kk * 32); \
+            }                                                                                                 \
+            _Pragma("unroll") for (int kk = 0; kk < KB / 32; ++kk)                                            \
+                _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                              \
+                    if (ABL & 4) { asm volatile("" ::"v"(fa[kk][0].x), "v"(fa[kk][1].w), "v"(fb[kk][j].x)); continue; } \
+                    Mma<T>::run(acc[0][j], fa[kk][0], fb[kk][j]);                                             \
+                    Mma<T>::run(acc[1][j], fa[kk][1], fb[kk][j]);                                             \
+                }                                                                                             \
+        } else {                                                                                              \
         _Pragma("unroll") for (int kk = 0; kk < KB / 32; ++kk) {                                              \
             const uint4 a0 = *(const uint4*)(sA + kk * 32);                                                   \
             const uint4 a1 = *(const uint4*)(sA + 32 * RTX_LDS_ROW + kk * 32);                                \
             _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                  \
                 const uint4 b = *(const uint4*)(sB + j * 32 * RTX_LDS_ROW + kk * 32);                         \
+                if (ABL & 4) { asm volatile("" ::"v"(a0.x), "v"(a0.w), "v"(a1.x), "v"(a1.w), "v"(b.x), "v"(b.w)); continue; } \
                 Mma<T>::run(acc[0][j], a0, b);                                                                \
                 Mma<T>::run(acc[1][j], a1, b);                                                                \
             }                                                                                                 \
+        }                                                                                                     \
         }                                                                                                     \
     }
 
@@ -184,16 +210,17 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
     // two register sets.  The steady-state loop issues its loads UNCONDITIONALLY: with a branch around a load,
     // hipcc's waitcnt pass merges the "issued" and "not issued" states and falls back to vmcnt(0) before the LDS
     // stores, which drains the younger prefetch every slice (seen in the .s; it cost the whole second stage).
+#define RTX_SYNC() do { if (!(ABL & 16)) __syncthreads(); } while (0)
     if (nk == 1) {
         RTX_GLOAD(r, ks0)
         RTX_LSTORE(r, 0)
-        __syncthreads();
+        RTX_SYNC();
         RTX_COMPUTE(0)
     } else if (nk > 1) {
         RTX_GLOAD(r, ks0)
         RTX_LSTORE(r, 0)
         RTX_GLOAD(r, ks0 + 1)
-        __syncthreads();
+        RTX_SYNC();
         int t = 0;
         for (; t + 3 < nk; t += 2) {
             // LDS stage 0 = slice t, set r = slice t+1 (in flight)
@@ -201,27 +228,30 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (the scheduler sinks it otherwise)
             RTX_COMPUTE(0)
             RTX_LSTORE(r, 1)
-            __syncthreads();
+            RTX_SYNC();
             // LDS stage 1 = slice t+1, set s = slice t+2 (in flight)
             RTX_GLOAD(r, ks0 + t + 3)
             __builtin_amdgcn_sched_barrier(0);
             RTX_COMPUTE(1)
             RTX_LSTORE(s, 0)
-            __syncthreads();
+            RTX_SYNC();
         }
         // 2 or 3 slices left: stage 0 = slice t, set r = slice t+1
         const bool three = (nk - t) == 3;
         if (three) { RTX_GLOAD(s, ks0 + t + 2) }
         RTX_COMPUTE(0)
         RTX_LSTORE(r, 1)
-        __syncthreads();
+        RTX_SYNC();
         RTX_COMPUTE(1)
         if (three) {
             RTX_LSTORE(s, 0)
-            __syncthreads();
+            RTX_SYNC();
             RTX_COMPUTE(0)
         }
     }
+#undef RTX_SYNC
+#undef RTX_GLOAD_
+#undef RTX_LSTORE_
 #undef RTX_GL
 #undef RTX_GLOAD
 #undef RTX_LS
@@ -344,7 +374,7 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
                 const float v = acc[i][j][e];
                 float* dst = cp + (long)dr * ld + j * 32;
                 if (EPI == RTX_EPI_STORE) {
-                    *dst = v;
+                    if (!(ABL & 32) || v == 12345.678f) *dst = v;
                 } else {  // RTX_EPI_GRAD
                     if (row < p.M_real) {
                         if (col < p.N_real)
@@ -357,6 +387,40 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
         }
     }
 }
+
+#ifdef RTX_GEMM_ABLATE
+template <int ABL> static void abl_launch(const RtxGemm& g, dim3 grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((rtx_gemm_nt<bf16_t, RTX_EPI_STORE, 2, 2, 2, 128, ABL>), grid, dim3(256), 0, st, g);
+}
+// measurement: the register-staged 128 x 128 split-K product with parts of its loop removed (ABL mask above)
+int rtx_gemm_ablate_launch(const RtxGemm& g, int abl, hipStream_t st)
+{
+    const int tiles = g.m_tiles * g.n_tiles;
+    const dim3 grid((unsigned)(8 * ((g.splits + 7) / 8) * tiles));
+    if (abl == 100) { hipLaunchKernelGGL((rtx_gemm_nt<bf16_t, RTX_EPI_STORE, 2, 2, 2, 128, 0, 1>), grid, dim3(256), 0, st, g); RTX_HIP(hipGetLastError()); return RTX_OK; }
+    if (abl == 107) { hipLaunchKernelGGL((rtx_gemm_nt<bf16_t, RTX_EPI_STORE, 2, 2, 2, 128, 7, 1>), grid, dim3(256), 0, st, g); RTX_HIP(hipGetLastError()); return RTX_OK; }
+    if (abl == 103) { hipLaunchKernelGGL((rtx_gemm_nt<bf16_t, RTX_EPI_STORE, 2, 2, 2, 128, 3, 1>), grid, dim3(256), 0, st, g); RTX_HIP(hipGetLastError()); return RTX_OK; }
+    switch (abl) {
+    case 0: abl_launch<0>(g, grid, st); break;
+    case 1: abl_launch<1>(g, grid, st); break;
+    case 2: abl_launch<2>(g, grid, st); break;
+    case 3: abl_launch<3>(g, grid, st); break;
+    case 4: abl_launch<4>(g, grid, st); break;
+    case 8: abl_launch<8>(g, grid, st); break;
+    case 11: abl_launch<11>(g, grid, st); break;
+    case 16: abl_launch<16>(g, grid, st); break;
+    case 32: abl_launch<32>(g, grid, st); break;
+    case 36: abl_launch<36>(g, grid, st); break;
+    case 7: abl_launch<7>(g, grid, st); break;
+    case 39: abl_launch<39>(g, grid, st); break;
+    case 63: abl_launch<63>(g, grid, st); break;
+    default: return RTX_EINVAL;
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+#endif
 
 void rtx_gemm_tile_dims(int shape, int* bm, int* bn)
 {

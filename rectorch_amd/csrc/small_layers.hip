@@ -45,7 +45,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_fwd_hidden(const RtxSmallFwdArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 32;
+    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 32;
     sf_u32x4 fa[KS], fb0[KS], fb1[KS];
     sf_load<KS>(fa, a.A, a.lda, r0, lane);
     sf_load<KS>(fb0, a.W, a.ldw, c0, lane);
@@ -77,7 +77,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 16;
+    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 16;
     const int j = c0 + (lane & 15);
     sf_f32x4 mu = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
     float eps[4] = {0.f, 0.f, 0.f, 0.f};
@@ -125,7 +125,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_bwd_hidden(const RtxSmallBwdArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 32;
+    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 32;
     sf_u32x4 fa[KS], fb0[KS], fb1[KS];
     sf_load<KS>(fa, a.D, a.ld, r0, lane);
     sf_load<KS>(fb0, a.WT, a.ld, c0, lane);
@@ -155,7 +155,7 @@ template <int KS>
 __global__ __launch_bounds__(256) void k_bwd_head(const RtxSmallBwdArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * 4 + wave) * 16, c0 = blockIdx.x * 16;
+    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 16;
     const int j = c0 + (lane & 15);
     sf_u32x4 fa[KS], fb[KS];
     sf_load<KS>(fa, a.D, a.ld, r0, lane);
@@ -188,22 +188,31 @@ __global__ __launch_bounds__(256) void k_bwd_head(const RtxSmallBwdArgs a)
 
 bool rtx_small_fwd_ok(int K) { return K >= 128 && K <= 1024 && K % 128 == 0; }
 
+// waves (16 batch rows each) per workgroup.  Rounds 3-5 launched 64-row workgroups (4 waves): a B = 500 layer was 104-160 workgroups, i.e.
+// ~100 CUs each pulling 120-480 KB of fragments through a 64 B/clk L1 while the rest of the chip idled.  One wave per workgroup is 4x the
+// workgroups: every CU takes a share (the B fragments the four waves used to share come from L2 either way).  Round 6, one box, alternating:
+// 251.6 / 255.8 / 251.6 us per step with 4 waves, 248.3 / 251.7 / 247.0 with 1, 248.6 / 249.9 / 247.9 with 2 (knob "small_waves").
+static int g_small_waves = 1;
+void rtx_small_set_waves(int w) { g_small_waves = (w == 1 || w == 2 || w == 4) ? w : 1; }
+
 template <int KS>
 static void small_fwd_launch(const RtxSmallFwdArgs& a, hipStream_t stream)
 {
+    const int w = g_small_waves;
     if (a.Z > 0)
-        hipLaunchKernelGGL(k_fwd_head<KS>, dim3(a.Np / 16, a.Bp / 64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_fwd_head<KS>, dim3(a.Np / 16, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
     else
-        hipLaunchKernelGGL(k_fwd_hidden<KS>, dim3(a.Np / 32, a.Bp / 64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_fwd_hidden<KS>, dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
 }
 
 template <int KS>
 static void small_bwd_launch(const RtxSmallBwdArgs& a, hipStream_t stream)
 {
+    const int w = g_small_waves;
     if (a.Z > 0)
-        hipLaunchKernelGGL(k_bwd_head<KS>, dim3((a.Z + 15) / 16, a.Bp / 64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_bwd_head<KS>, dim3((a.Z + 15) / 16, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
     else
-        hipLaunchKernelGGL(k_bwd_hidden<KS>, dim3(a.Np / 32, a.Bp / 64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_bwd_hidden<KS>, dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
 }
 
 int rtx_launch_small_bwd(const RtxSmallBwdArgs& a, hipStream_t stream)

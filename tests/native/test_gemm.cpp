@@ -1,6 +1,9 @@
 // Native (no Python) check of the MFMA GEMM against a double-precision host loop, plus a first
 // throughput reading on the three GEMM shapes of the ml-20m training step.  Runs in seconds.
 #include "../../rectorch_amd/csrc/rtx_gemm.h"
+#ifdef RTX_GEMM_ABLATE
+int rtx_gemm_ablate_launch(const RtxGemm& g, int abl, hipStream_t st);
+#endif
 
 #include <math.h>
 #include <stdlib.h>
@@ -715,6 +718,138 @@ static int run_dw_cases()
     return fails;
 }
 
+// ---- what the optimizer state's ACCESS PATTERN costs, without any of the kernel around it ---------------------
+// The fused weight-gradient + Adam kernel reads and rewrites p / exp_avg / exp_avg_sq (3 float32 arrays in place) and writes the bf16
+// compute copy: six address streams + one, as 64 x 128 tiles of a row-major [M][N] tensor (a tile row = 512 contiguous bytes; rows
+// 2400 B or 80 432 B apart), 512 threads per workgroup, one float4 per thread and 16-row pass, every load of a thread issued before
+// its first store -- dw_adam.hip's epilogue exactly.  This kernel does ONLY that, for NA = 1, 2, 3 arrays (2, 4, 6 streams), with and
+// without the bf16 copy, non-temporal or default cache policy, and -- the comparison -- the same bytes walked as FLAT contiguous
+// 32-KB chunks per workgroup (what a plain multi-tensor Adam does).  The float4 copy figure of the hardware guide (6.29 TB/s) is the
+// NA = 1 flat line.
+template <int NA, bool SH, bool NT, bool FLAT, int TN = 128, bool XM = true>
+__global__ __launch_bounds__(512, 2) void k_state_stream(float* a0, float* a1, float* a2, bf16_t* sh, int M, int N, int ld_sh, int m_tiles, int n_tiles)
+{
+    typedef __attribute__((ext_vector_type(4))) float f4;
+    typedef f4 f4u __attribute__((aligned(4)));
+    float* arr[3] = {a0, a1, a2};
+    const int tid = threadIdx.x;
+    f4 v[NA][4];
+    size_t off[4];
+    bool on[4];
+    if (FLAT) {
+        const size_t total = (size_t)M * N;
+        const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+        // XM (flat): every XCD walks ONE contiguous eighth of the array (the tile kernels' order) instead of chunks dealt round-robin
+        const size_t chunk = XM ? (size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3) : (size_t)blockIdx.x;
+        const size_t base = chunk * 8192;     // 8192 floats = 32 KB per workgroup and array
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { off[q] = base + (size_t)(q * 512 + tid) * 4; on[q] = off[q] + 4 <= total; }
+    } else {
+        const int total = m_tiles * n_tiles, per_xcd = (total + 7) / 8;
+        const int id = XM ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        if (id >= total) return;
+        int tm, tn;
+        if (n_tiles <= m_tiles) { tm = id / n_tiles; tn = id % n_tiles; } else { tn = id / m_tiles; tm = id % m_tiles; }
+        constexpr int TPR = TN / 4, RPP = 512 / TPR, TM = 8192 / TN;      // threads per tile row, rows per pass, tile rows
+        const int rowl = tid / TPR, col = tn * TN + (tid % TPR) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = tm * TM + q * RPP + rowl;
+            on[q] = row < M && col + 4 <= N;
+            off[q] = (size_t)min(row, M - 1) * N + min(col, N - 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            v[k][q] = NT ? __builtin_nontemporal_load((const f4u*)(arr[k] + off[q])) : *(const f4u*)(arr[k] + off[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!on[q]) continue;
+        f4 acc = v[0][q];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const f4 w = v[k][q] * 1.0001f + 1e-9f;
+            acc += w;
+            if (NT) __builtin_nontemporal_store(w, (f4u*)(arr[k] + off[q])); else *(f4u*)(arr[k] + off[q]) = w;
+        }
+        if (SH) {
+            const size_t r = off[q] / N, c = off[q] % N;      // (tile mapping: the element's own row / column; flat: the same arithmetic the flat Adam does)
+            store4<bf16_t>(sh + r * ld_sh + (c & ~(size_t)3), acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+}
+
+template <int NA, bool SH, bool NT, bool FLAT, int TN = 128, bool XM = true>
+static double state_stream_once(float** arr, bf16_t* sh, int M, int N, int set, size_t set_stride)
+{
+    const int Np = rtx_pad(N), m_tiles = (M + 8192 / TN - 1) / (8192 / TN), n_tiles = (N + TN - 1) / TN;
+    const unsigned grid = FLAT ? (unsigned)(((size_t)M * N + 8191) / 8192) : (unsigned)(8 * ((m_tiles * n_tiles + 7) / 8));
+    hipLaunchKernelGGL((k_state_stream<NA, SH, NT, FLAT, TN, XM>), dim3(grid), dim3(512), 0, 0, arr[0] + set * set_stride, arr[1] + set * set_stride,
+                       arr[2] + set * set_stride, sh, M, N, Np, m_tiles, n_tiles);
+    return 0;
+}
+
+template <int NA, bool SH, bool NT, bool FLAT, int TN = 128, bool XM = true>
+static void state_stream_case(float** arr, bf16_t* sh, int M, int N, size_t set_stride, int sets)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < sets; ++i) state_stream_once<NA, SH, NT, FLAT, TN, XM>(arr, sh, M, N, i, set_stride);
+    CK(hipDeviceSynchronize());
+    const int it = 12;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < it; ++i) state_stream_once<NA, SH, NT, FLAT, TN, XM>(arr, sh, M, N, i % sets, set_stride);   // rotating sets: cold in the 256-MB cache
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1000.0 / it, bytes = (double)M * N * (8.0 * NA + (SH ? 2.0 : 0.0));
+    char shape[32];
+    snprintf(shape, sizeof shape, "%dx%d tiles", 8192 / TN, TN);
+    if (!XM) strcat(shape, FLAT ? "" : " rr");
+    printf("[state-stream] %5dx%-5d %-17s %s: %d arrays read + rewritten in place (%d streams)%s: %6.1f us  %5.2f TB/s\n", M, N, FLAT ? (XM ? "flat, XCD-contig" : "flat 32-KB chunks") : shape,
+           NT ? "nt   " : "plain", NA, 2 * NA, SH ? " + bf16 copy" : "            ", us, bytes / us * 1e-6);
+}
+
+static void run_state_stream()
+{
+    const int shapes[2][2] = {{20108, 600}, {600, 20108}};
+    const size_t P = (size_t)20108 * 600, stride = (P + 1023) / 1024 * 1024;
+    const int sets = 3;                                        // 3 x 3 x 48 MB: no set is still in the 256-MB cache when its turn comes again
+    float* arr[3];
+    bf16_t* sh;
+    for (int k = 0; k < 3; ++k) { CK(hipMalloc(&arr[k], stride * sets * 4)); CK(hipMemset(arr[k], 0, stride * sets * 4)); }
+    CK(hipMalloc(&sh, (size_t)rtx_pad(20108) * rtx_pad(20108 > 600 ? 600 : 600) * 2 + (size_t)rtx_pad(600) * rtx_pad(20108) * 2));
+    for (int rep = 0; rep < 1; ++rep)
+        for (auto& shp : shapes) {
+            const int M = shp[0], N = shp[1];
+            state_stream_case<1, false, true, true, 128, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<1, false, false, true, 128, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<2, false, true, true, 128, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, false, true, true, 128, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, true, 128, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, true, 128, true>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, false, 128, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, false, 1024, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<1, false, true, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<2, false, true, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, false, true, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, false, false, false>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, false>(arr, sh, M, N, stride, sets);
+            // the same 8192 elements per workgroup as tiles with longer rows (what a workgroup owning several adjacent MFMA tiles would touch per epilogue pass)
+            state_stream_case<3, true, true, false, 256>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, false, 512>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, false, 1024>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, true, false, 2048>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, false, false, 512>(arr, sh, M, N, stride, sets);
+            state_stream_case<3, true, false, false, 2048>(arr, sh, M, N, stride, sets);
+        }
+    for (int k = 0; k < 3; ++k) hipFree(arr[k]);
+    hipFree(sh);
+}
+
 // the fused epilogue's hardware sqrt / rcp (dw_adam.hip dw_finish4) isolated from operand rounding.  100 Adam
 // steps of rtx_dw_tn<..., ADAM> on fresh bf16 operands each step; the gradient the epilogue used leaves through `gkeep`, and the
 // EXACT update (k_adam's expressions: IEEE sqrtf and division, float32, torch.optim.Adam semantics -- reference models.py:768-770)
@@ -1017,6 +1152,51 @@ int main(int argc, char** argv)
         fails = run_dw_cases();
         printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
         return fails ? 1 : 0;
+    }
+#ifdef RTX_GEMM_ABLATE
+    if (argc > 1 && !strcmp(argv[1], "ablate")) {   // round 6: where the first-layer product's 22 us go (parts of the loop removed; results are wrong by design)
+        const int M = 512, N = 640, K = 20224, splits = 24;
+        bf16_t *A, *B;
+        float* C;
+        std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+        for (auto& v : hA) v = f32_to_bf16(frand());
+        for (auto& v : hB) v = f32_to_bf16(frand());
+        CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&C, (size_t)splits * M * N * 4));
+        CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+        RtxGemm g = {};
+        g.A = A; g.B = B; g.lda = K; g.ldb = K; g.tile_shape = 0; g.m_tiles = M / 128; g.n_tiles = N / 128; g.k_slices = K * 2 / 128;
+        g.splits = splits; g.C = C; g.ldc = N; g.slab_stride = (long)M * N; g.M_real = M; g.N_real = N;
+        const int masks[] = {0, 100, 3, 103, 7, 107, 1, 2, 4, 8, 11, 16, 32, 63};
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep)
+            for (int mk : masks) {
+                for (int i = 0; i < 3; ++i) rtx_gemm_ablate_launch(g, mk, 0);
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 20; ++i) rtx_gemm_ablate_launch(g, mk, 0);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (mk >= 100) { printf("[ablate fwd1 512x640x20224 / 24] HOISTED fragment reads, mask %d: %.1f us\n", mk - 100, ms * 50.0); continue; }
+                printf("[ablate fwd1 512x640x20224 / 24] mask %2d (%s%s%s%s%s%s): %.1f us\n", mk, mk & 1 ? "no-gload " : "", mk & 2 ? "no-ldswrite " : "", mk & 4 ? "no-mfma " : "",
+                       mk & 8 ? "no-ldsread+mfma " : "", mk & 16 ? "no-barrier " : "", mk & 32 ? "no-store " : "", ms * 50.0);
+            }
+        return 0;
+    }
+#endif
+    if (argc > 1 && !strcmp(argv[1], "skinny")) {   // round 6: the two K = n_items products on every kernel that can run them
+        for (int rep = 0; rep < 2; ++rep) {
+            perf_case<bf16_t>("fwd1 regstage", 512, 640, 20224, 24, RTX_EPI_STORE, 0);
+            for (int sp : {12, 16, 20, 23}) perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_128x128_S2, 512, 640, 20224, sp, RTX_EPI_STORE);
+            for (int sp : {12, 16, 20, 23}) perf_dma("dH3", RTX_FORM_NN, RTX_DMA_128x128_S2, 512, 640, 20224, sp, RTX_EPI_STORE);
+            for (int sp : {8, 12}) perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_128x128, 512, 640, 20224, sp, RTX_EPI_STORE);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "streams")) {   // round 6: the optimizer state's access pattern alone (2 / 4 / 6 streams, tiles vs flat)
+        run_state_stream();
+        return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "adamiso")) {
         fails += run_adam_approx_isolation(RTX_DW_64x128);
