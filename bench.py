@@ -574,9 +574,13 @@ def main():
                      "frac": (achieved / (HBM_PEAK_TBS * 1000.0)) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": kbytes, "avg_us": kus, "launches_timed": kn,
                      "avg_us_event_bracket": locals().get("kus_bracket"), "event_bracket_overhead_us": locals().get("bracket_overhead_us"),
+                     # the same fraction from the RAW event bracket (nothing subtracted): the two are printed side by side so that they
+                     # cannot drift apart unnoticed; the rocprofv3 --stats average of the same command (profiles/) is the third witness
+                     "frac_raw_bracket": ((kbytes / (locals().get("kus_bracket") * 1e-6) / 1e9) / (HBM_PEAK_TBS * 1000.0))
+                                         if (kbytes and locals().get("kus_bracket")) else None,
                      "timing": "HIP events on the stream each launch runs on, inside the timed region; avg_us = mean bracket minus the mean EMPTY "
                                "bracket recorded right behind each timed one (two event records with nothing between them); "
-                               "profiles/r5_bench_kernel_stats.txt is the rocprofv3 summary of the same command",
+                               "profiles/r6_bench_kernel_stats.txt is the rocprofv3 summary of the same command",
                      "timed_every": args.kernel_timing_every},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
                           "frac_of_hbm_peak": step_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000.0),

@@ -661,6 +661,12 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     f16x8_t yy[NV];
 #pragma unroll
     for (int u = 0; u < NV; ++u) yy[u] = *(const f16x8_t*)(y16 + (size_t)min(j0 + tid + u * 256, n8 - 1) * 8);
+    // (round 6) everything the tail of this kernel needs -- the row's target sum, the first 256 latent means / log-variances of the KL
+    // term -- is requested here too: loaded where it is used, each was one more dependent round trip at the very end of the kernel
+    const float tsum_b = L.tsum[b];
+    float kl_m0 = 0.f, kl_lv0 = 0.f;
+    const bool kl_here = L.mu32 && part_y == 0;
+    if (kl_here && tid < L.Z) { kl_m0 = L.mu32[(size_t)b * L.Z + tid]; kl_lv0 = L.lv32[(size_t)b * L.Z + tid]; }
     float2 pr0 = make_float2(-INFINITY, 0.f), pr1 = make_float2(-INFINITY, 0.f);     // this thread's strip partials (n_strips <= 512 here)
     if (tid < L.n_strips) pr0 = L.part[(size_t)b * L.part_ld + tid];
     if (tid + 256 < L.n_strips) pr1 = L.part[(size_t)b * L.part_ld + tid + 256];
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
         lse = M + logf(S);
         __syncthreads();          // (red is reused by the sums below)
     }
-    const float sc = L.tsum[b] * L.inv_batch;
+    const float sc = tsum_b * L.inv_batch;
     // (3) the target's stored entries, while their logits are still in place: <t, y>, and the corrected gradient parked in LDS
     float dot = 0.f;
     if (tid < nt) {               // the entries requested at kernel entry
@@ -748,8 +754,9 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
     // (6) row loss: -<t, y> / B + s lse / B + beta KL / B, all in partial 0 of the row (the others are zero)
     dot = block_sum(dot, red);
     float kl = 0.f;
-    if (L.mu32 && part_y == 0) {
-        for (int j = tid; j < L.Z; j += 256) {
+    if (kl_here) {
+        if (tid < L.Z) kl += 1.f + kl_lv0 - kl_m0 * kl_m0 - expf(kl_lv0);
+        for (int j = tid + 256; j < L.Z; j += 256) {
             const float m = L.mu32[(size_t)b * L.Z + j], lv = L.lv32[(size_t)b * L.Z + j];
             kl += 1.f + lv - m * m - expf(lv);
         }
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(256) void k_dlogits_row(const RtxDlogitsArgs a)
         float part = -dot * L.inv_batch;
         if (part_y == 0) {
             L.lse[b] = lse;
-            part += L.tsum[b] * lse * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
+            part += tsum_b * lse * L.inv_batch + L.beta * (-0.5f * kl) * L.inv_batch;
         }
         L.row_loss[(size_t)b * chunks + part_y] = part;
     } else if (part_y == 0 && tid >= S && tid < chunks) {

@@ -138,6 +138,7 @@ void rtx_gemm_dma_set_skip(int v);   // measurement only (gemm_dma.hip g_gd_skip
 void rtx_gemm_dma_set_stamps(unsigned long long* dev);   // measurement hook: 32 device entries (gemm_dma.hip)
 void rtx_dw_set_stamps(unsigned long long* dev);   // measurement hooks (dw_adam.hip g_dw_stamps / g_dw_skip): 8 entries per workgroup
 void rtx_dw_set_skip(int mask);
+void rtx_dw_set_lds_pad(int bytes);   // measurement: unused LDS added to every single-matrix launch (occupancy throttle)
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6

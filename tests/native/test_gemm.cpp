@@ -1148,6 +1148,13 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "dwperf")) {   // the two n_items x 600 launches of the step, warm and cold
+        for (int rep = 0; rep < 3; ++rep) {
+            perf_dw("dW4+adam", 0, RTX_DW_ADAM, 20108, 600, 500, 3);
+            perf_dw("dW1+adam", 0, RTX_DW_ADAM, 600, 20108, 500, 3);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "dw")) {   // only the weight-gradient (+ Adam) kernels
         fails = run_dw_cases();
         printf("%s (%d failing cases)\n", fails ? "GEMM TESTS FAILED" : "GEMM TESTS PASSED", fails);
