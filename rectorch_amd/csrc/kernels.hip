@@ -994,6 +994,67 @@ __global__ __launch_bounds__(256) void k_adam(const RtxAdamArgs a)
         // transposed copy to produce, the tensor is walked as ONE contiguous array instead: float4 everywhere, and the
         // compute copy gets its (row, column) back from the flat index.
         const long n = (long)t.rows * t.cols;
+        if ((long)local * 4096 + 4096 <= n) {
+            // a whole 4096-element tile (all but the tensor's last): EVERY load of the four passes is issued before the first update is
+            // computed -- one round trip per tile, as the 2-D walk below does.  Round 6: this walk now serves every tensor without a
+            // transposed copy, also rows of whole float4s.  The state-stream micro-benchmark (tests/native/test_gemm.cpp "streams")
+            // measures the same six streams at 5.9-6.2 TB/s walked flat and at 3.8-4.7 TB/s as 64 x 128 tiles (64 x 64 here: worse).
+            float4 P4[4], M4[4], V4[4], G4[4];
+            const long f0 = (long)local * 4096 + tid * 4;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const long f = f0 + pass * 1024;
+                P4[pass] = *(const float4*)(t.p + f);
+                if (a.update) {
+                    M4[pass] = *(const float4*)(t.m + f);
+                    V4[pass] = *(const float4*)(t.v + f);
+                    if (t.g16) {
+                        const uint2 u = *(const uint2*)(t.g16 + f);
+                        G4[pass] = make_float4(bf16_to_f32((bf16_t)(u.x & 0xffff)), bf16_to_f32((bf16_t)(u.x >> 16)),
+                                               bf16_to_f32((bf16_t)(u.y & 0xffff)), bf16_to_f32((bf16_t)(u.y >> 16)));
+                    } else {
+                        G4[pass] = *(const float4*)(t.g + f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const long f = f0 + pass * 1024;
+                float pv[4] = {P4[pass].x, P4[pass].y, P4[pass].z, P4[pass].w};
+                if (a.update) {
+                    const float gv[4] = {G4[pass].x, G4[pass].y, G4[pass].z, G4[pass].w};
+                    float mv[4] = {M4[pass].x, M4[pass].y, M4[pass].z, M4[pass].w};
+                    float vv[4] = {V4[pass].x, V4[pass].y, V4[pass].z, V4[pass].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float g = gv[e] * a.grad_scale + reg * pv[e];
+                        if (a.weight_decay != 0.f) g += a.weight_decay * pv[e];
+                        const float m = mv[e] + (g - mv[e]) * (1.f - a.beta1);
+                        const float v = vv[e] * a.beta2 + (1.f - a.beta2) * g * g;
+                        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+                        pv[e] = pv[e] - a.step_size * (m / denom);
+                        mv[e] = m;
+                        vv[e] = v;
+                    }
+                    *(float4*)(t.p + f) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                    *(float4*)(t.m + f) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                    *(float4*)(t.v + f) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+                if (t.sh) {
+                    int r = (int)(f / t.cols), c = (int)(f - (long)r * t.cols);
+                    if ((t.cols & 3) == 0) {      // the four elements share a row, ld_sh is a multiple of 128: one 8- / 16-byte store
+                        store4<T>((T*)t.sh + (size_t)r * t.ld_sh + c, pv[0], pv[1], pv[2], pv[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ((T*)t.sh)[(size_t)r * t.ld_sh + c] = Elem<T>::from(pv[e]);
+                            if (++c == t.cols) { c = 0; ++r; }
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const long f = (long)local * 4096 + pass * 1024 + tid * 4;
@@ -1187,7 +1248,8 @@ int rtx_launch_adam(RtxAdamArgs& a, int is_bf16, hipStream_t stream)
         const RtxAdamTensor& tk = a.t[k];
         const bool aligned = (((uintptr_t)tk.p | (uintptr_t)tk.m | (uintptr_t)tk.v | (uintptr_t)tk.g | (uintptr_t)tk.g16) & 15) == 0;
         // ... and a bias (one row) always: a handful of 4096-element tiles instead of one 64-column tile per workgroup
-        a.t[k].flat = (!tk.shT && aligned && (((tk.cols & 3) != 0 && tk.rows > 1) || tk.rows == 1)) ? 1 : 0;
+        // (round 6: every tensor without a transposed copy -- rows of whole float4s too: the flat walk streams at the rate of a copy, tiles do not)
+        a.t[k].flat = (!tk.shT && aligned && ((long)tk.rows * tk.cols & 3) == 0) || (!tk.shT && aligned && (((tk.cols & 3) != 0 && tk.rows > 1) || tk.rows == 1)) ? 1 : 0;
         if (a.t[k].flat) tiles += (int)(((long)tk.rows * tk.cols + 4095) / 4096);
         else tiles += ((a.t[k].rows + 63) / 64) * ((a.t[k].cols + 63) / 64);
     }
