@@ -51,8 +51,6 @@ typedef __attribute__((address_space(3))) unsigned char dw_lds_byte;
 // product: two scalar registers, no memory access of their own).
 static unsigned long long* g_dw_stamps = nullptr;
 static int g_dw_skip = 0;
-static int g_dw_lds_pad = 0;
-void rtx_dw_set_lds_pad(int bytes) { g_dw_lds_pad = bytes > 0 ? bytes : 0; }
 void rtx_dw_set_stamps(unsigned long long* dev) { g_dw_stamps = dev; }
 void rtx_dw_set_skip(int v) { g_dw_skip = v; }
 
@@ -502,9 +500,7 @@ template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(
     const dim3 grid((unsigned)(8 * ((total + 7) / 8)));
     RtxDw dd = d;
     dd.dbg_skip = g_dw_skip; dd.dbg_stamps = g_dw_stamps;
-    // measurement (rtx_dw_set_lds_pad): extra, unused LDS per workgroup of the SINGLE-matrix launch (the decoder matrix on the side stream):
-    // with > 8 KB only one workgroup fits a CU, which leaves half of every SIMD's registers to the data-gradient chain running beside it
-    const int lds = std::min(LDS + g_dw_lds_pad, 160 * 1024);
+    const int lds = std::min(LDS + (d.lds_pad > 0 ? d.lds_pad : 0), 160 * 1024);   // (RtxDw::lds_pad: room for a kernel running beside this one)
     hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI, AL>), grid, dim3(WM * WN * 64), lds, stream, dd);
     RTX_HIP(hipGetLastError());
     return RTX_OK;

@@ -150,6 +150,7 @@ struct rtx_engine {
     int n_cus = 256;                   // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int opt_f32_adam_overlap = 0;      // (measured: 960.5 vs 960.7 us/step, no gain -- off; profiles/r5_fp32_tail_split.txt) float32 train step: the decoder matrix's Adam pass on the side stream under the remaining products
     int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
+    int opt_splitk_bwd = 0;            // measurement: split factor of the K = n_items data-gradient product alone (0 = automatic)
     int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
     uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
     uint32_t hopk_seq = 0;
@@ -159,6 +160,12 @@ struct rtx_engine {
     bool join_pending = false, join_fold = false;
     uint32_t join_seq = 0;
     int opt_timing_calibrate = 0;      // every timed bracket is followed by an empty one (site "<name>#empty"): what the events themselves cost
+    // unused LDS of the decoder matrix's side-stream launch (RtxDw::lds_pad; knob "dw_side_pad").  12288 = one workgroup per CU beside the chain:
+    // the chain's kernels then find registers at once (chain 95 -> 74 us on the timeline) and the step gains 2.3-4.3 us on fast and slow boxes
+    // alike (profiles/r6_ab_small_waves_side_pad.txt) -- but the throttled launch itself stretches from 90 to 126 us and runs into the
+    // encoder matrix's launch (90 -> 101 us): the step's dominant kernel would be REPORTED at 0.32 of the HBM roof instead of 0.40 for a 1 %
+    // faster step.  Default off: the roofline of the dominant kernel is quoted for an unthrottled launch.
+    int opt_dw_side_pad = 0;
     int opt_hop_fold = 1;              // the step's fork (caller's stream -> side stream) folded into the data-gradient product (loss_grads_impl)
     int opt_hop_kernels = 0;           // (measured: no gain, a one-wave kernel costs its stream 5-6 us like the packet it replaces) the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
     uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
@@ -365,6 +372,7 @@ static GemmPlan plan_gemm(const rtx_engine* e, int Mp, int Np, int Kp, int form 
         if (form == RTX_FORM_NN && s > 16 && e->bf16) s = 16;   // (float32: one stream, nothing beside the post kernel -- fill the chip)
         if (pl.k_slices >= 64 && e->cfg.splitk > 0) s = e->cfg.splitk;
         if (pl.k_slices >= 64 && form == RTX_FORM_NT && e->opt_splitk_fwd > 0) s = e->opt_splitk_fwd;
+        if (pl.k_slices >= 64 && form == RTX_FORM_NN && e->opt_splitk_bwd > 0) s = e->opt_splitk_bwd;
         const int max_s = pl.k_slices / 2 > 0 ? pl.k_slices / 2 : 1;
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
@@ -1462,6 +1470,8 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         if (e->bf16) {
             RtxDw d;
             make_dw(li, d);
+            // the fused step's side-stream launch runs beside the data-gradient chain: one workgroup per CU leaves the chain room (RtxDw::lds_pad)
+            if (fused && !dp && two && ws == e->side && ws != st && dw_cfg == RTX_DW_64x128) d.lds_pad = e->opt_dw_side_pad;
             return rtx_dw_launch(d, fused ? RTX_DW_ADAM : RTX_DW_GRAD, dw_cfg, ws);
         }
         RtxGemm g = {};
@@ -2193,7 +2203,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "hop_values") e->opt_hop_values = value != 0;
     else if (k == "hop_kernels") e->opt_hop_kernels = value != 0;
     else if (k == "hop_fold") e->opt_hop_fold = value != 0;
-    else if (k == "dw_side_pad") rtx_dw_set_lds_pad(value);    // (process-wide measurement knob of dw_adam.hip)
+    else if (k == "dw_side_pad") e->opt_dw_side_pad = value > 0 ? value : 0;
     else if (k == "small_waves") rtx_small_set_waves(value);   // (process-wide: a launch-shape knob of small_layers.hip)
     else if (k == "timing_calibrate") e->opt_timing_calibrate = value != 0;
     else if (k == "hop_wrap") {
@@ -2204,6 +2214,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "f32_tail_split") e->opt_f32_tail_split = value != 0;
     else if (k == "f32_adam_overlap") e->opt_f32_adam_overlap = value != 0;
     else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
+    else if (k == "splitk_bwd") e->opt_splitk_bwd = value;
     else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
     else if (k == "dp_shard_min_elems") {
         RTX_CHECK(!e->dp.on && value >= 1, RTX_ESTATE, "set_option: dp_shard_min_elems (>= 1) must be set before rtx_engine_dp_attach");

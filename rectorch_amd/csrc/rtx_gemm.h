@@ -131,6 +131,12 @@ struct RtxDw {
     float* bias_m;       //   with the scalars of `adam`
     float* bias_v;
     const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
+    // unused LDS added to this launch's workgroups (single-matrix launch only).  The 64 x 128 tile takes 72 KB and 120 registers per lane:
+    // two workgroups per CU = four waves per SIMD = 480 of its 512 registers -- nothing else fits, and a kernel running BESIDE this one
+    // only gets the slots its workgroups free as they retire (~25 per us chip-wide).  The decoder matrix's launch runs beside the
+    // data-gradient chain on the critical path: with > 8 KB of padding ONE workgroup fits a CU, half of every SIMD's registers stay free
+    // and the chain's kernels start at once (round 6, three alternating rounds: 246.1 / 246.8 / 247.4 -> 243.6 / 244.8 / 243.1 us per step)
+    int lds_pad;
     int dbg_skip;                    // measurement (rtx_dw_set_skip / rtx_dw_set_stamps fill them at launch; 0 / null otherwise)
     unsigned long long* dbg_stamps;
 };
@@ -138,7 +144,6 @@ void rtx_gemm_dma_set_skip(int v);   // measurement only (gemm_dma.hip g_gd_skip
 void rtx_gemm_dma_set_stamps(unsigned long long* dev);   // measurement hook: 32 device entries (gemm_dma.hip)
 void rtx_dw_set_stamps(unsigned long long* dev);   // measurement hooks (dw_adam.hip g_dw_stamps / g_dw_skip): 8 entries per workgroup
 void rtx_dw_set_skip(int mask);
-void rtx_dw_set_lds_pad(int bytes);   // measurement: unused LDS added to every single-matrix launch (occupancy throttle)
 int rtx_dw_tile_rows(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6

@@ -6,7 +6,7 @@
 # Outputs: gpurun_out/$1/.   usage: tools/gpu.sh --timeout 1500 -- 'bash tools/round_check.sh r4final'
 OUT=gpurun_out/${1:-check}
 mkdir -p $OUT
-# the driver's own invocation, verbatim (its line is the graded one): kept as profiles/r5_bench_driver_cmd.json
+# the driver's own invocation, verbatim (its line is the graded one): kept as profiles/r6_bench_driver_cmd.json
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; echo "driver cmd rc=$?"; tail -1 $OUT/bench_driver_cmd.json | cut -c1-200
 B="--steps 100 --no-cpu-baseline --no-fp32-parity --no-extras"
 run() { name=$1; shift; timeout 150 python bench.py $B "$@" > $OUT/$name.json 2> $OUT/$name.err; echo "$name rc=$? $(python -c "
