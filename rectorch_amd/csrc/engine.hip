@@ -2204,6 +2204,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "hop_kernels") e->opt_hop_kernels = value != 0;
     else if (k == "hop_fold") e->opt_hop_fold = value != 0;
     else if (k == "dw_side_pad") e->opt_dw_side_pad = value > 0 ? value : 0;
+    else if (k == "small_kw") rtx_small_set_kw(value);         // (process-wide: K split of small_layers.hip's kernels over waves)
     else if (k == "small_waves") rtx_small_set_waves(value);   // (process-wide: a launch-shape knob of small_layers.hip)
     else if (k == "timing_calibrate") e->opt_timing_calibrate = value != 0;
     else if (k == "hop_wrap") {

@@ -248,7 +248,10 @@ int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipSt
 // tiles = many workgroups.  (Round 1 also wrote every result transposed through LDS; the K-major operand
 // reads of the weight-gradient kernel made those copies unnecessary.)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE>
+// BURST: slab loads in flight per thread (16 or 32).  The 32-deep burst costs 153 registers; beside the decoder matrix's weight kernel, which
+// leaves a CU only what its retiring workgroups free (240 registers per SIMD lane at a time), ONE such workgroup fits per
+// retirement.  <= 16 slabs (the data-gradient product's) take the 16-deep form: < 120 registers, two workgroups per retirement.
+template <typename T, int MODE, int BURST = 32>
 __global__ __launch_bounds__(256) void k_post(const RtxPostArgs a)
 {
     const int tid = threadIdx.x;
@@ -258,12 +261,12 @@ __global__ __launch_bounds__(256) void k_post(const RtxPostArgs a)
     // runs beside a streaming weight kernel, where a dependent load costs 3-5 us: 25 slabs four at a time made this kernel 32 us).
     // Same order of additions as a plain loop (masked slabs add +0).
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < a.splits; s0 += 32) {
-        float4 t[32];
+    for (int s0 = 0; s0 < a.splits; s0 += BURST) {
+        float4 t[BURST];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) t[k] = *(const float4*)(C + (size_t)min(s0 + k, a.splits - 1) * a.slab_stride);
+        for (int k = 0; k < BURST; ++k) t[k] = *(const float4*)(C + (size_t)min(s0 + k, a.splits - 1) * a.slab_stride);
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
+        for (int k = 0; k < BURST; ++k) {
             const bool on = s0 + k < a.splits;
             c.x += on ? t[k].x : 0.f; c.y += on ? t[k].y : 0.f; c.z += on ? t[k].z : 0.f; c.w += on ? t[k].w : 0.f;
         }
@@ -295,7 +298,8 @@ int rtx_launch_post(const RtxPostArgs& a, int mode, int is_bf16, hipStream_t str
 {
     RTX_CHECK(a.Np % 64 == 0 && a.Bp % 16 == 0 && a.ldc % 4 == 0, RTX_EINVAL, "post: bad padding");
     const dim3 block(256), grid(a.Np / 64, a.Bp / 16);
-#define RTX_P(T, M) hipLaunchKernelGGL((k_post<T, M>), grid, block, 0, stream, a)
+#define RTX_P(T, M) do { if (a.splits <= 16) hipLaunchKernelGGL((k_post<T, M, 16>), grid, block, 0, stream, a); \
+                         else hipLaunchKernelGGL((k_post<T, M, 32>), grid, block, 0, stream, a); } while (0)
     if (is_bf16) {
         if (mode == RTX_POST_FWD) RTX_P(bf16_t, RTX_POST_FWD);
         else RTX_P(bf16_t, RTX_POST_BWD);

@@ -109,6 +109,7 @@ struct RtxSmallFwdArgs {
     uint64_t seed, offset;
 };
 bool rtx_small_fwd_ok(int K);
+void rtx_small_set_kw(int kw);      // measurement knob: waves that share the K range of a 16-row block (1 or 2)
 void rtx_small_set_waves(int w);   // measurement knob: 16-row waves per workgroup of the one-launch hidden layers (1, 2 or 4)
 int rtx_launch_small_fwd(const RtxSmallFwdArgs& a, hipStream_t stream);
 // backward through a hidden layer (Z == 0: conventions of k_post backward) or the VAE head (Z > 0: of k_vae_bwd):

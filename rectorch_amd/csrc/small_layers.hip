@@ -17,6 +17,7 @@
 // Operands: A [Bp][K] bf16 row-major (K-contiguous; column `in` = 1, beyond it 0), W [outp][K] bf16 compute copy (row n =
 // output feature n; its column `in` is zero, so the ones column adds nothing in the forward product).
 #include "rtx_kernels.h"
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 sf_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float sf_f32x4;
@@ -40,19 +41,46 @@ __device__ __forceinline__ sf_f32x4 sf_dot(const sf_u32x4 (&a)[KS], const sf_u32
     return acc;   // element i: row (lane >> 4) * 4 + i, column lane & 15
 }
 
-// ---- hidden layer: R / O32 [Bp][Np] = act(A W^T + bias), conventions of k_post (forward) -------------------------------
-template <int KS>
-__global__ __launch_bounds__(256) void k_fwd_hidden(const RtxSmallFwdArgs a)
+// K split over KW waves of a workgroup (round 6, an experiment kept as a knob).  The one-burst scheme costs registers in proportion to K:
+// 188-284 per lane at K = 640.  Hypothesis: beside the decoder matrix's weight kernel a CU has only the registers that kernel's retiring
+// workgroups free (240 per SIMD lane at a time), so smaller waves would start sooner.  With KW = 2 / 4 every wave loads and
+// multiplies a half / quarter of the fragments (108-176 / 70-100 registers); wave kw > 0 parks its partial accumulators in LDS, wave 0 adds
+// them in the fixed order kw = 1 .. KW - 1 and runs the epilogue (sums of several MFMA chains: last bits differ from KW = 1).  Result: no
+// change in the step (numbers at g_small_kw below) -- the hypothesis is refuted at this granularity.
+template <int NACC>
+__device__ __forceinline__ void sf_combine(sf_f32x4 (&acc)[NACC], int kw, int KW, int row_wave, int lane, float* red)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 32;
-    sf_u32x4 fa[KS], fb0[KS], fb1[KS];
-    sf_load<KS>(fa, a.A, a.lda, r0, lane);
-    sf_load<KS>(fb0, a.W, a.ldw, c0, lane);
-    sf_load<KS>(fb1, a.W, a.ldw, c0 + 16, lane);
+    // red: [row_wave][kw - 1][NACC][64 lanes][4]
+    if (KW == 1) return;
+    if (kw > 0) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) *(sf_f32x4*)(red + ((((size_t)row_wave * (KW - 1) + (kw - 1)) * NACC + t) * 64 + lane) * 4) = acc[t];
+    }
+    __syncthreads();
+    if (kw == 0) {
+        for (int k = 1; k < KW; ++k)
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) acc[t] += *(const sf_f32x4*)(red + ((((size_t)row_wave * (KW - 1) + (k - 1)) * NACC + t) * 64 + lane) * 4);
+    }
+}
+
+// ---- hidden layer: R / O32 [Bp][Np] = act(A W^T + bias), conventions of k_post (forward) -------------------------------
+template <int KS, int KW>
+__global__ __launch_bounds__(KW == 4 ? 512 : 256) void k_fwd_hidden(const RtxSmallFwdArgs a)
+{
+    constexpr int KH = KS / KW;
+    extern __shared__ float sf_red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row_wave = wave / KW, kw = wave % KW;
+    const int r0 = (blockIdx.y * ((blockDim.x >> 6) / KW) + row_wave) * 16, c0 = blockIdx.x * 32;
+    sf_u32x4 fa[KH], fb0[KH], fb1[KH];
+    sf_load<KH>(fa, a.A + kw * KH * 32, a.lda, r0, lane);
+    sf_load<KH>(fb0, a.W + kw * KH * 32, a.ldw, c0, lane);
+    sf_load<KH>(fb1, a.W + kw * KH * 32, a.ldw, c0 + 16, lane);
     __builtin_amdgcn_sched_barrier(0);   // every load is in flight before the first MFMA waits (the scheduler would interleave
                                          // them twelve at a time to save registers: a pipeline paced by the memory latency)
-    const sf_f32x4 acc[2] = {sf_dot<KS>(fa, fb0), sf_dot<KS>(fa, fb1)};
+    sf_f32x4 acc[2] = {sf_dot<KH>(fa, fb0), sf_dot<KH>(fa, fb1)};
+    sf_combine<2>(acc, kw, KW, row_wave, lane, sf_red);
+    if (kw != 0) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = c0 + t * 16 + (lane & 15);
@@ -73,23 +101,25 @@ __global__ __launch_bounds__(256) void k_fwd_hidden(const RtxSmallFwdArgs a)
 }
 
 // ---- VAE head: [mu | logvar] = A W^T + bias; z = mu + eps exp(logvar / 2) (eval: z = mu); conventions of k_vae_fwd -----
-template <int KS>
-__global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
+template <int KS, int KW>
+__global__ __launch_bounds__(KW == 4 ? 512 : 256) void k_fwd_head(const RtxSmallFwdArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 16;
+    constexpr int KH = KS / KW;
+    extern __shared__ float sf_red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row_wave = wave / KW, kw = wave % KW;
+    const int r0 = (blockIdx.y * ((blockDim.x >> 6) / KW) + row_wave) * 16, c0 = blockIdx.x * 16;
     const int j = c0 + (lane & 15);
-    sf_f32x4 mu = {0.f, 0.f, 0.f, 0.f}, lv = {0.f, 0.f, 0.f, 0.f};
+    sf_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // mu, logvar
     float eps[4] = {0.f, 0.f, 0.f, 0.f};
     const float bm = j < a.Z ? a.bias[j] : 0.f, bl = j < a.Z ? a.bias[a.Z + j] : 0.f;
     if (c0 < a.Z) {   // (a tile beyond the latent width only carries the ones column / zero padding of the next operand)
-        sf_u32x4 fa[KS], fm[KS], fl[KS];
-        sf_load<KS>(fa, a.A, a.lda, r0, lane);
-        sf_load<KS>(fm, a.W, a.ldw, c0, lane);
-        sf_load<KS>(fl, a.W, a.ldw, a.Z + c0, lane);
+        sf_u32x4 fa[KH], fm[KH], fl[KH];
+        sf_load<KH>(fa, a.A + kw * KH * 32, a.lda, r0, lane);
+        sf_load<KH>(fm, a.W + kw * KH * 32, a.ldw, c0, lane);
+        sf_load<KH>(fl, a.W + kw * KH * 32, a.ldw, a.Z + c0, lane);
         // the noise (Philox + Box-Muller, ~200 instructions per element) is drawn while the operands are in flight
         // (pure ALU here: a load in this stretch makes the compiler wait for ALL loads at the branch; injected noise is read below)
-        if (a.training && !a.eps_in) {
+        if (kw == 0 && a.training && !a.eps_in) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int b = r0 + (lane >> 4) * 4 + i;
@@ -97,9 +127,12 @@ __global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mu = sf_dot<KS>(fa, fm);
-        lv = sf_dot<KS>(fa, fl);
+        acc[0] = sf_dot<KH>(fa, fm);
+        acc[1] = sf_dot<KH>(fa, fl);
     }
+    sf_combine<2>(acc, kw, KW, row_wave, lane, sf_red);   // (every wave of the workgroup reaches the barrier: c0 is per workgroup)
+    if (kw != 0) return;
+    const sf_f32x4 mu = acc[0], lv = acc[1];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int b = r0 + (lane >> 4) * 4 + i;
@@ -121,23 +154,27 @@ __global__ __launch_bounds__(256) void k_fwd_head(const RtxSmallFwdArgs a)
 }
 
 // ---- backward through a hidden layer: Dout [Bp][Np] = (D W)[b][n] x (1 - o[b][n]^2), conventions of k_post (backward) ------
-template <int KS>
-__global__ __launch_bounds__(256) void k_bwd_hidden(const RtxSmallBwdArgs a)
+template <int KS, int KW>
+__global__ __launch_bounds__(KW == 4 ? 512 : 256) void k_bwd_hidden(const RtxSmallBwdArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 32;
-    sf_u32x4 fa[KS], fb0[KS], fb1[KS];
-    sf_load<KS>(fa, a.D, a.ld, r0, lane);
-    sf_load<KS>(fb0, a.WT, a.ld, c0, lane);
-    sf_load<KS>(fb1, a.WT, a.ld, c0 + 16, lane);
+    constexpr int KH = KS / KW;
+    extern __shared__ float sf_red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row_wave = wave / KW, kw = wave % KW;
+    const int r0 = (blockIdx.y * ((blockDim.x >> 6) / KW) + row_wave) * 16, c0 = blockIdx.x * 32;
+    sf_u32x4 fa[KH], fb0[KH], fb1[KH];
+    sf_load<KH>(fa, a.D + kw * KH * 32, a.ld, r0, lane);
+    sf_load<KH>(fb0, a.WT + kw * KH * 32, a.ld, c0, lane);
+    sf_load<KH>(fb1, a.WT + kw * KH * 32, a.ld, c0 + 16, lane);
     float o[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            o[t][i] = a.tanh_act ? a.O32[(size_t)(r0 + (lane >> 4) * 4 + i) * a.Np + c0 + t * 16 + (lane & 15)] : 0.f;
+            o[t][i] = (a.tanh_act && kw == 0) ? a.O32[(size_t)(r0 + (lane >> 4) * 4 + i) * a.Np + c0 + t * 16 + (lane & 15)] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
-    const sf_f32x4 acc[2] = {sf_dot<KS>(fa, fb0), sf_dot<KS>(fa, fb1)};
+    sf_f32x4 acc[2] = {sf_dot<KH>(fa, fb0), sf_dot<KH>(fa, fb1)};
+    sf_combine<2>(acc, kw, KW, row_wave, lane, sf_red);
+    if (kw != 0) return;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = c0 + t * 16 + (lane & 15);
@@ -151,23 +188,30 @@ __global__ __launch_bounds__(256) void k_bwd_hidden(const RtxSmallBwdArgs a)
 }
 
 // ---- backward through the VAE head: dz = D W; Dout [Bp][Np] = [dmu | dlogvar | 0], conventions of k_vae_bwd ------------
-template <int KS>
-__global__ __launch_bounds__(256) void k_bwd_head(const RtxSmallBwdArgs a)
+template <int KS, int KW>
+__global__ __launch_bounds__(KW == 4 ? 512 : 256) void k_bwd_head(const RtxSmallBwdArgs a)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16, c0 = blockIdx.x * 16;
+    constexpr int KH = KS / KW;
+    extern __shared__ float sf_red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row_wave = wave / KW, kw = wave % KW;
+    const int r0 = (blockIdx.y * ((blockDim.x >> 6) / KW) + row_wave) * 16, c0 = blockIdx.x * 16;
     const int j = c0 + (lane & 15);
-    sf_u32x4 fa[KS], fb[KS];
-    sf_load<KS>(fa, a.D, a.ld, r0, lane);
-    sf_load<KS>(fb, a.WT, a.ld, c0, lane);
-    float mu[4], lv[4], ep[4];
+    sf_u32x4 fa[KH], fb[KH];
+    sf_load<KH>(fa, a.D + kw * KH * 32, a.ld, r0, lane);
+    sf_load<KH>(fb, a.WT + kw * KH * 32, a.ld, c0, lane);
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, lv[4] = {0.f, 0.f, 0.f, 0.f}, ep[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kw == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // (clamped addresses, masked below: no branch around the loads)
-        const size_t at = (size_t)min(r0 + (lane >> 4) * 4 + i, a.B - 1) * a.Z + min(j, a.Z - 1);
-        mu[i] = a.mu32[at]; lv[i] = a.lv32[at]; ep[i] = a.eps32[at];
+        for (int i = 0; i < 4; ++i) {   // (clamped addresses, masked below: no branch around the loads)
+            const size_t at = (size_t)min(r0 + (lane >> 4) * 4 + i, a.B - 1) * a.Z + min(j, a.Z - 1);
+            mu[i] = a.mu32[at]; lv[i] = a.lv32[at]; ep[i] = a.eps32[at];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
-    const sf_f32x4 dz = sf_dot<KS>(fa, fb);
+    sf_f32x4 acc[1] = {sf_dot<KH>(fa, fb)};
+    sf_combine<1>(acc, kw, KW, row_wave, lane, sf_red);
+    if (kw != 0) return;
+    const sf_f32x4 dz = acc[0];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int b = r0 + (lane >> 4) * 4 + i;
@@ -194,25 +238,42 @@ bool rtx_small_fwd_ok(int K) { return K >= 128 && K <= 1024 && K % 128 == 0; }
 // 251.6 / 255.8 / 251.6 us per step with 4 waves, 248.3 / 251.7 / 247.0 with 1, 248.6 / 249.9 / 247.9 with 2 (knob "small_waves").
 static int g_small_waves = 1;
 void rtx_small_set_waves(int w) { g_small_waves = (w == 1 || w == 2 || w == 4) ? w : 1; }
+// K split over this many waves per 16-row block (sf_combine; knob "small_kw").  Measured in round 6 (three alternating rounds, one box):
+// 1: 251.4 / 248.1 / 246.6 us per step, 2: 249.1 / 248.3 / 246.5, 4: 247.3 / 247.9 / 255.4 -- the registers a wave needs are NOT what makes
+// these kernels queue beside the weight kernel (188 -> 108 -> 70 changes nothing).  Default 1: one MFMA chain per output, the bits of rounds 3-5.
+static int g_small_kw = 1;
+void rtx_small_set_kw(int kw) { g_small_kw = (kw == 2 || kw == 4) ? kw : 1; }
 
 template <int KS>
 static void small_fwd_launch(const RtxSmallFwdArgs& a, hipStream_t stream)
 {
-    const int w = g_small_waves;
-    if (a.Z > 0)
-        hipLaunchKernelGGL(k_fwd_head<KS>, dim3(a.Np / 16, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
-    else
-        hipLaunchKernelGGL(k_fwd_hidden<KS>, dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
+    const int kw = g_small_kw, w = kw > 1 ? std::min(g_small_waves, 2) : g_small_waves;   // (256 threads at KW <= 2, 512 at KW = 4)
+    const size_t lds = (size_t)w * (kw - 1) * 2 * 64 * 4 * sizeof(float);
+    if (a.Z > 0) {
+        if (kw == 4) hipLaunchKernelGGL((k_fwd_head<KS, 4>), dim3(a.Np / 16, a.Bp / (16 * w)), dim3(64 * w * 4), lds, stream, a);
+        else if (kw == 2) hipLaunchKernelGGL((k_fwd_head<KS, 2>), dim3(a.Np / 16, a.Bp / (16 * w)), dim3(64 * w * 2), lds, stream, a);
+        else hipLaunchKernelGGL((k_fwd_head<KS, 1>), dim3(a.Np / 16, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
+    } else {
+        if (kw == 4) hipLaunchKernelGGL((k_fwd_hidden<KS, 4>), dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w * 4), lds, stream, a);
+        else if (kw == 2) hipLaunchKernelGGL((k_fwd_hidden<KS, 2>), dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w * 2), lds, stream, a);
+        else hipLaunchKernelGGL((k_fwd_hidden<KS, 1>), dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
+    }
 }
 
 template <int KS>
 static void small_bwd_launch(const RtxSmallBwdArgs& a, hipStream_t stream)
 {
-    const int w = g_small_waves;
-    if (a.Z > 0)
-        hipLaunchKernelGGL(k_bwd_head<KS>, dim3((a.Z + 15) / 16, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
-    else
-        hipLaunchKernelGGL(k_bwd_hidden<KS>, dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
+    const int kw = g_small_kw, w = kw > 1 ? std::min(g_small_waves, 2) : g_small_waves;
+    const size_t lds = (size_t)w * (kw - 1) * 2 * 64 * 4 * sizeof(float);
+    if (a.Z > 0) {
+        if (kw == 4) hipLaunchKernelGGL((k_bwd_head<KS, 4>), dim3((a.Z + 15) / 16, a.Bp / (16 * w)), dim3(64 * w * 4), lds, stream, a);
+        else if (kw == 2) hipLaunchKernelGGL((k_bwd_head<KS, 2>), dim3((a.Z + 15) / 16, a.Bp / (16 * w)), dim3(64 * w * 2), lds, stream, a);
+        else hipLaunchKernelGGL((k_bwd_head<KS, 1>), dim3((a.Z + 15) / 16, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
+    } else {
+        if (kw == 4) hipLaunchKernelGGL((k_bwd_hidden<KS, 4>), dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w * 4), lds, stream, a);
+        else if (kw == 2) hipLaunchKernelGGL((k_bwd_hidden<KS, 2>), dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w * 2), lds, stream, a);
+        else hipLaunchKernelGGL((k_bwd_hidden<KS, 1>), dim3(a.Np / 32, a.Bp / (16 * w)), dim3(64 * w), 0, stream, a);
+    }
 }
 
 int rtx_launch_small_bwd(const RtxSmallBwdArgs& a, hipStream_t stream)

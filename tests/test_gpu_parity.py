@@ -1691,6 +1691,19 @@ def test_bf16_fast_paths_match_the_generic_kernels(case):
     assert np.array_equal(np.isneginf(fast[2]), np.isneginf(slow[2]))
     fin = np.isfinite(slow[2])
     assert rel(fast[2][fin], slow[2][fin]) < 5e-3
+    # round 6: the launch shapes of the one-launch hidden layers -- 16-row waves per workgroup (1 is the default, 4 the form of rounds
+    # 3-5) and the K range of a block shared by 2 or 4 waves (partial accumulators combined through LDS) -- against the same generic chain
+    try:
+        for knobs in ({"small_waves": 4}, {"small_kw": 2}, {"small_kw": 4, "small_waves": 2}):
+            alt = run({"sparse_in": 0, **knobs})
+            for a, b in zip(alt[0], slow[0]):
+                assert abs(a - b) < 2e-4 * abs(b), (case, knobs, alt[0], slow[0])
+            for a, b in zip(alt[1], slow[1]):
+                d = np.abs(a - b)
+                assert float(d.max()) <= 6.1e-3 and float(np.mean(d > 2e-5)) < 1e-2, (case, knobs, float(d.max()), float(np.mean(d > 2e-5)))
+            assert rel(alt[2][fin], slow[2][fin]) < 5e-3, (case, knobs)
+    finally:
+        run({"small_waves": 1, "small_kw": 1})      # (process-wide knobs: back to the defaults for the tests that follow)
 
 
 def test_batch_image_by_scatter_equals_the_full_rewrite():
