@@ -248,9 +248,9 @@ int rtx_launch_csr_to_dense(const RtxCsrView& v, int B, int I, float* out, hipSt
 // tiles = many workgroups.  (Round 1 also wrote every result transposed through LDS; the K-major operand
 // reads of the weight-gradient kernel made those copies unnecessary.)
 // ------------------------------------------------------------------------------------------------
-// BURST: slab loads in flight per thread (16 or 32).  The 32-deep burst costs 153 registers; beside the decoder matrix's weight kernel, which
-// leaves a CU only what its retiring workgroups free (240 registers per SIMD lane at a time), ONE such workgroup fits per
-// retirement.  <= 16 slabs (the data-gradient product's) take the 16-deep form: < 120 registers, two workgroups per retirement.
+// BURST: slab loads in flight per thread (16 or 32): 88 or 153 registers.  <= 16 slabs (the data-gradient product's) take the 16-deep form.
+// (Built to test whether register occupancy is what makes this kernel queue beside the weight kernel: it is not -- DESIGN 4.1 -- but the
+// smaller form costs nothing.)
 template <typename T, int MODE, int BURST = 32>
 __global__ __launch_bounds__(256) void k_post(const RtxPostArgs a)
 {

@@ -131,11 +131,9 @@ struct RtxDw {
     float* bias_m;       //   with the scalars of `adam`
     float* bias_v;
     const float* bias_sumsq;   // DAE: squared norm of the bias tensor (nullable)
-    // unused LDS added to this launch's workgroups (single-matrix launch only).  The 64 x 128 tile takes 72 KB and 120 registers per lane:
-    // two workgroups per CU = four waves per SIMD = 480 of its 512 registers -- nothing else fits, and a kernel running BESIDE this one
-    // only gets the slots its workgroups free as they retire (~25 per us chip-wide).  The decoder matrix's launch runs beside the
-    // data-gradient chain on the critical path: with > 8 KB of padding ONE workgroup fits a CU, half of every SIMD's registers stay free
-    // and the chain's kernels start at once (round 6, three alternating rounds: 246.1 / 246.8 / 247.4 -> 243.6 / 244.8 / 243.1 us per step)
+    // unused LDS added to this launch's workgroups (single-matrix launch only): with > 8 KB ONE 64 x 128 workgroup (72 KB) fits a CU instead of
+    // two.  Measurement knob of the decoder matrix's launch, which runs beside the data-gradient chain: halving what it keeps in flight
+    // takes the chain from 91 to 74 us and stretches the launch itself from 87 to 126 (engine option "dw_side_pad", default 0)
     int lds_pad;
     int dbg_skip;                    // measurement (rtx_dw_set_skip / rtx_dw_set_stamps fill them at launch; 0 / null otherwise)
     unsigned long long* dbg_stamps;
