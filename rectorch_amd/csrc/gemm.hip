@@ -84,6 +84,10 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     if (p.wait_word) rtx_fold_wait(p.wait_word, p.wait_seq);   // a cross-stream dependency folded into this kernel (rtx_gemm.h)
+    if (ABL & 64) {   // measurement: the second workgroup of a CU (odd wave slot of its SIMD) starts half a slice late: out of phase with the first
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID: wave_id in bits 3:0
+        if (hw & 1) __builtin_amdgcn_s_sleep(20);
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -137,6 +141,9 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
     const int nk = ks1 - ks0;
 
     const size_t rowA = (size_t)p.lda * sizeof(T), rowB = (size_t)p.ldb * sizeof(T);
+    // bytes between two K slices of one row: KB for a row-major operand; RtxGemm::a_slice_stride / b_slice_stride for a K-BLOCKED image
+    // ([K / slice][rows][slice]: lda = ldb = one slice, a slice of a tile is ONE contiguous run)
+    const size_t kstA = p.a_slice_stride ? (size_t)p.a_slice_stride : (size_t)KB, kstB = p.b_slice_stride ? (size_t)p.b_slice_stride : (size_t)KB;
     const int st_row = tid / LPR_ST, st_ch = tid % LPR_ST;  // staging: LPR lanes x 16 B = one KB-byte row slice
     const unsigned char* gA = (const unsigned char*)p.A + ((size_t)tm * BM + st_row) * rowA + st_ch * 16;
     const unsigned char* gB = (const unsigned char*)p.B + ((size_t)tn * BN + st_row) * rowB + st_ch * 16;
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
     // multiplied -- the loop is latency-bound otherwise (one slice of MFMA work is shorter than an L2 round trip)
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     uint4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+    uint4 ua0, ua1, ua2, ua3, ub0, ub1, ub2, ub3;   // SCH == 2: the third set (three slices ahead)
     f32x16_t acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-#define RTX_GL(R, X, q, base, row, ks) R##X##q = *(const uint4*)((base) + (size_t)(q) * RPP * (row) + (size_t)(ks) * KB);
+#define RTX_GL(R, X, q, base, row, ks) R##X##q = *(const uint4*)((base) + (size_t)(q) * RPP * (row) + (size_t)(ks) * ((row) == rowA ? kstA : kstB));
 #define RTX_GLOAD(R, ks)                                                    \
     if (!(ABL & 1) || (ks) == ks0)                                           \
     RTX_GLOAD_(R, ks)
@@ -211,6 +219,31 @@ __global__ __launch_bounds__(WM* WN * 64, KB == 64 ? 3 : ((WM * WN) / 4 > 2 ? (W
     // hipcc's waitcnt pass merges the "issued" and "not issued" states and falls back to vmcnt(0) before the LDS
     // stores, which drains the younger prefetch every slice (seen in the .s; it cost the whole second stage).
 #define RTX_SYNC() do { if (!(ABL & 16)) __syncthreads(); } while (0)
+    if (SCH == 2) {
+        // Depth 3 (round 6): THREE register sets rotate over the two LDS stages, so a slice's loads have three compute phases to land
+        // instead of two (the ablation puts ~5 of the first-layer product's 24 us on exposed load latency: a slice takes ~1 us per
+        // workgroup because its 256 row pieces come from as many DRAM pages).  Invariant at step t (t = 0 mod 6): LDS stage 0 = slice t,
+        // set r = slice t + 1, set s = slice t + 2 (in flight).  Every load is unconditional (clamped to the split's last slice: a branch
+        // around a load costs the younger prefetches, see above); the multiply and the LDS store of slices beyond the split are skipped.
+        if (nk > 0) {
+            RTX_GLOAD(r, ks0)
+            RTX_LSTORE(r, 0)
+            RTX_GLOAD(r, min(ks0 + 1, ks1 - 1))
+            RTX_GLOAD(s, min(ks0 + 2, ks1 - 1))
+            RTX_SYNC();
+#define RTX_STEP(U, R, st, k)                                                   \
+            RTX_GLOAD(U, min(ks0 + t + (k) + 3, ks1 - 1))                       \
+            __builtin_amdgcn_sched_barrier(0);                                  \
+            if (t + (k) < nk) { RTX_COMPUTE(st) }                               \
+            if (t + (k) + 1 < nk) { RTX_LSTORE(R, 1 - (st)) }                   \
+            RTX_SYNC();
+            for (int t = 0; t < nk; t += 6) {
+                RTX_STEP(u, r, 0, 0) RTX_STEP(r, s, 1, 1) RTX_STEP(s, u, 0, 2)
+                RTX_STEP(u, r, 1, 3) RTX_STEP(r, s, 0, 4) RTX_STEP(s, u, 1, 5)
+            }
+#undef RTX_STEP
+        }
+    } else
     if (nk == 1) {
         RTX_GLOAD(r, ks0)
         RTX_LSTORE(r, 0)
@@ -415,6 +448,7 @@ int rtx_gemm_ablate_launch(const RtxGemm& g, int abl, hipStream_t st)
     case 7: abl_launch<7>(g, grid, st); break;
     case 39: abl_launch<39>(g, grid, st); break;
     case 63: abl_launch<63>(g, grid, st); break;
+    case 64: abl_launch<64>(g, grid, st); break;
     default: return RTX_EINVAL;
     }
     RTX_HIP(hipGetLastError());
@@ -449,6 +483,11 @@ template <typename T> static void launch_type(const RtxGemm& g, int epilogue, di
             hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_BIAS_ROWS, 2, 2, 2, 64>), grid, dim3(256), 0, stream, g);
             return;
         }
+        if (g.tile_shape == RTX_TILE_128x128_D3) {    // three slices in flight (rtx_gemm_launch has checked: plain store or bias epilogue)
+            if (epilogue == RTX_EPI_STORE) hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_STORE, 2, 2, 2, 128, 0, 2>), grid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((rtx_gemm_nt<T, RTX_EPI_BIAS_ROWS, 2, 2, 2, 128, 0, 2>), grid, dim3(256), 0, stream, g);
+            return;
+        }
     }
     switch (g.tile_shape) {
     case RTX_TILE_256x128: launch_shape<T, 4, 2, 2>(g, epilogue, grid, stream); break;
@@ -472,7 +511,9 @@ int rtx_gemm_launch(const RtxGemm& g, int dtype, int epilogue, hipStream_t strea
                       g.ldc16 >= (long)g.n_tiles * bn16,
                   RTX_EINVAL, "gemm: half-precision logits need the bias epilogue, bf16 operands and an 8-byte aligned [M][ldc16 >= N_pad] image");
     }
-    RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x128_K32, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
+    RTX_CHECK(g.tile_shape >= RTX_TILE_128x128 && g.tile_shape <= RTX_TILE_128x128_D3, RTX_EINVAL, "gemm: bad tile shape %d", g.tile_shape);
+    RTX_CHECK(g.tile_shape != RTX_TILE_128x128_D3 || (dtype == RTX_DT_BF16 && (epilogue == RTX_EPI_STORE || epilogue == RTX_EPI_BIAS_ROWS)), RTX_EINVAL,
+              "gemm: the depth-3 tile exists for bf16 operands with the store / bias epilogues only");
     RTX_CHECK(g.tile_shape != RTX_TILE_128x128_K32 || (dtype == RTX_DT_BF16 && epilogue == RTX_EPI_BIAS_ROWS), RTX_EINVAL,
               "gemm: the 64-byte-slice tile exists for bf16 operands with the bias epilogue only");
     // 1-D grid laid out for the XCD-aware mapping in the kernel: 8 * ceil(groups / 8) * group_size workgroups

@@ -42,6 +42,7 @@ enum RtxTileShape {     // workgroup tile of C; 128x128 runs 4 waves, the others
     RTX_TILE_128x128 = 0,
     RTX_TILE_256x128 = 1,
     RTX_TILE_128x256 = 2,
+    RTX_TILE_128x128_D3 = 4,    // bf16, RTX_EPI_STORE / RTX_EPI_BIAS_ROWS: the 128 x 128 tile with THREE K slices in flight (three register sets)
     RTX_TILE_128x128_K32 = 3,   // bf16 + RTX_EPI_BIAS_ROWS only: 64-byte K slices, 41 KB of LDS -> three workgroups per CU (the logits product)
 };
 void rtx_gemm_tile_dims(int shape, int* bm, int* bn);
@@ -58,6 +59,7 @@ struct RtxGemm {
     const void* B;       // [N_pad][ldb]                 (NN / TN: [K_pad][ldb])
     int form;            // RtxForm (0 = NT)
     long lda, ldb;       // leading dimensions in elements
+    long a_slice_stride, b_slice_stride;   // rtx_gemm_launch (NT, register-staged): bytes between two 128-byte K slices of a row; 0 = row-major (128)
     int tile_shape;      // RtxTileShape; M_pad / N_pad must be multiples of the tile
     int m_tiles, n_tiles;
     int k_slices;        // total 128-byte K slices  (= K_pad * sizeof(T) / 128)

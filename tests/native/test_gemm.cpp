@@ -1173,7 +1173,7 @@ int main(int argc, char** argv)
         RtxGemm g = {};
         g.A = A; g.B = B; g.lda = K; g.ldb = K; g.tile_shape = 0; g.m_tiles = M / 128; g.n_tiles = N / 128; g.k_slices = K * 2 / 128;
         g.splits = splits; g.C = C; g.ldc = N; g.slab_stride = (long)M * N; g.M_real = M; g.N_real = N;
-        const int masks[] = {0, 100, 3, 103, 7, 107, 1, 2, 4, 8, 11, 16, 32, 63};
+        const int masks[] = {0, 64, 0, 64, 100, 3, 103, 7, 107, 1, 2, 4, 8, 11, 16, 32, 63};
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int rep = 0; rep < 2; ++rep)
@@ -1187,14 +1187,48 @@ int main(int argc, char** argv)
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 if (mk >= 100) { printf("[ablate fwd1 512x640x20224 / 24] HOISTED fragment reads, mask %d: %.1f us\n", mk - 100, ms * 50.0); continue; }
                 printf("[ablate fwd1 512x640x20224 / 24] mask %2d (%s%s%s%s%s%s): %.1f us\n", mk, mk & 1 ? "no-gload " : "", mk & 2 ? "no-ldswrite " : "", mk & 4 ? "no-mfma " : "",
-                       mk & 8 ? "no-ldsread+mfma " : "", mk & 16 ? "no-barrier " : "", mk & 32 ? "no-store " : "", ms * 50.0);
+                       mk & 8 ? "no-ldsread+mfma " : "", mk & 16 ? "no-barrier " : "", mk & 64 ? "second workgroup of a CU staggered by half a slice " : (mk & 32 ? "no-store " : ""), ms * 50.0);
             }
         return 0;
     }
 #endif
     if (argc > 1 && !strcmp(argv[1], "skinny")) {   // round 6: the two K = n_items products on every kernel that can run them
+        for (int K : {64, 128, 192, 256, 320, 384, 448, 704, 1408})
+            fails += run_case<bf16_t>("store-d3", 256, 256, K, 1, RTX_EPI_STORE, 256, 256, RTX_TILE_128x128_D3);
+        fails += run_case<bf16_t>("splitk11-d3", 256, 512, 1408, 11, RTX_EPI_STORE, 256, 512, RTX_TILE_128x128_D3);
+        fails += run_case<bf16_t>("bias-d3", 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, RTX_TILE_128x128_D3);
+        fails += run_logits16_case(512, 768, 640, 410, 701, RTX_TILE_128x128_D3, 1.f);
+        {   // round 6: the same product with K-BLOCKED operand images (a tile's slice = one contiguous 16-KB run): what the access pattern costs
+            const int M = 512, N = 640, K = 20224;
+            bf16_t *A, *B;
+            float* C;
+            CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)24 * M * N * 4));
+            CK(hipMemset(A, 0x11, (size_t)M * K * 2)); CK(hipMemset(B, 0x22, (size_t)N * K * 2));
+            for (int blocked = 0; blocked < 2; ++blocked)
+                for (int shape : {0, 4}) {
+                    RtxGemm g = {};
+                    g.A = A; g.B = B; g.tile_shape = shape; g.m_tiles = M / 128; g.n_tiles = N / 128; g.k_slices = K * 2 / 128;
+                    g.splits = 24; g.C = C; g.ldc = N; g.slab_stride = (long)M * N; g.M_real = M; g.N_real = N;
+                    if (blocked) { g.lda = 64; g.ldb = 64; g.a_slice_stride = (long)M * 128; g.b_slice_stride = (long)N * 128; }
+                    else { g.lda = K; g.ldb = K; }
+                    hipEvent_t e0, e1;
+                    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                    for (int i = 0; i < 3; ++i) rtx_gemm_launch(g, RTX_DT_BF16, RTX_EPI_STORE, 0);
+                    CK(hipEventRecord(e0, 0));
+                    for (int i = 0; i < 20; ++i) rtx_gemm_launch(g, RTX_DT_BF16, RTX_EPI_STORE, 0);
+                    CK(hipEventRecord(e1, 0));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    printf("[perf fwd1 layout] %s operands, tile%d, 24 slabs: %.1f us\n", blocked ? "K-BLOCKED [K/64][rows][64]" : "row-major                 ", shape, ms * 50.0);
+                }
+            hipFree(A); hipFree(B); hipFree(C);
+        }
         for (int rep = 0; rep < 2; ++rep) {
             perf_case<bf16_t>("fwd1 regstage", 512, 640, 20224, 24, RTX_EPI_STORE, 0);
+            perf_case<bf16_t>("fwd1 depth-3 ", 512, 640, 20224, 24, RTX_EPI_STORE, RTX_TILE_128x128_D3);
+            perf_logits16(512, 20224, 640, 0);
+            perf_logits16(512, 20224, 640, RTX_TILE_128x128_D3);
             for (int sp : {12, 16, 20, 23}) perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_128x128_S2, 512, 640, 20224, sp, RTX_EPI_STORE);
             for (int sp : {12, 16, 20, 23}) perf_dma("dH3", RTX_FORM_NN, RTX_DMA_128x128_S2, 512, 640, 20224, sp, RTX_EPI_STORE);
             for (int sp : {8, 12}) perf_dma("fwd1", RTX_FORM_NT, RTX_DMA_128x128, 512, 640, 20224, sp, RTX_EPI_STORE);
@@ -1256,6 +1290,14 @@ int main(int argc, char** argv)
         fails += run_case<float>("bias", 512, 768, 320, 1, RTX_EPI_BIAS_ROWS, 410, 701, shape);
         fails += run_case<float>("grad", 768, 512, 256, 1, RTX_EPI_GRAD, 700, 300, shape);
     }
+    // the depth-3 pipeline of the 128 x 128 tile: every slice count mod 6, split-K with short and empty last splits, both epilogues
+    for (int K : {64, 128, 192, 256, 320, 384, 448, 704, 1408})
+        fails += run_case<bf16_t>("store-d3", 256, 256, K, 1, RTX_EPI_STORE, 256, 256, RTX_TILE_128x128_D3);
+    fails += run_case<bf16_t>("splitk3-d3", 512, 768, 704, 3, RTX_EPI_STORE, 512, 768, RTX_TILE_128x128_D3);
+    fails += run_case<bf16_t>("splitk5-d3", 256, 256, 704, 5, RTX_EPI_STORE, 256, 256, RTX_TILE_128x128_D3);
+    fails += run_case<bf16_t>("splitk11-d3", 256, 512, 1408, 11, RTX_EPI_STORE, 256, 512, RTX_TILE_128x128_D3);
+    fails += run_case<bf16_t>("bias-d3", 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, RTX_TILE_128x128_D3);
+    fails += run_logits16_case(512, 768, 640, 410, 701, RTX_TILE_128x128_D3, 1.f);
     // the 64-byte-slice tile (three workgroups per CU): bias epilogue only, float32 and half logits, ragged edges, K of one slice
     fails += run_case<bf16_t>("bias-k32", 512, 768, 640, 1, RTX_EPI_BIAS_ROWS, 410, 701, RTX_TILE_128x128_K32);
     fails += run_case<bf16_t>("bias-wide-k32", 256, 2304, 64, 1, RTX_EPI_BIAS_ROWS, 250, 2300, RTX_TILE_128x128_K32);
