@@ -207,13 +207,19 @@ class Engine:
             setattr(s, k, v)
         return s
 
-    def forward(self, x, training=False, remove_train=False, seed=0, offset=0, mask=None, noise=None):
+    def forward(self, x, training=False, remove_train=False, seed=0, offset=0, mask=None, noise=None, out=None, want_latent=True):
+        """``out``: a float32 ``[>= batch, n_items]`` tensor to receive the scores (a loop over many batches reuses two of them instead
+        of allocating 40 MB per batch); ``want_latent=False`` skips the (mu, logvar) outputs of a VAE."""
         keep = []
         b = make_batch(x, keep=keep, n_items=self.n_items, n_in=self.n_in)
         dev = torch.device("cuda", torch.cuda.current_device())
-        logits = torch.empty((b.batch, self.n_items), dtype=torch.float32, device=dev)
+        if out is not None:
+            assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] >= b.batch and out.shape[1] == self.n_items
+            logits = out[:b.batch]
+        else:
+            logits = torch.empty((b.batch, self.n_items), dtype=torch.float32, device=dev)
         mu = logvar = None
-        if self.variant == "vae":
+        if self.variant == "vae" and want_latent:
             mu = torch.empty((b.batch, self.latent), dtype=torch.float32, device=dev)
             logvar = torch.empty_like(mu)
         st = self._step(seed, offset, mask, noise)
@@ -434,17 +440,22 @@ def sum_l2_norms(tensors):
     return out
 
 
-def topk_metrics(scores, heldout, rows, ks, want_topk=False):
+def topk_metrics(scores, heldout, rows, ks, want_topk=False, out=None):
     """nDCG@k and Recall@k for every k in ``ks`` (reference rectorch/metrics.py:136-147, 187-196) computed on the
     device from a score tensor ``[B, n_items]`` and the users' held-out rows of a resident :class:`CsrMatrix`.
-    Returns ``(ndcg [len(ks), B], recall [len(ks), B])`` as float64 device tensors (+ the sorted top-k item ids)."""
+    Returns ``(ndcg [len(ks), B], recall [len(ks), B])`` as float64 device tensors (+ the sorted top-k item ids).
+    ``out``: a pair of contiguous float64 ``[len(ks), B]`` tensors to write into (no allocation per batch)."""
     _lib.require_gpu()
     scores = scores.contiguous()
     B, n_items = scores.shape
     ks = [int(k) for k in ks]
     arr = (C.c_int32 * len(ks))(*ks)
-    ndcg = torch.empty((len(ks), B), dtype=torch.float64, device=scores.device)
-    recall = torch.empty_like(ndcg)
+    if out is not None:
+        ndcg, recall = out
+        assert ndcg.shape == (len(ks), B) and recall.shape == (len(ks), B) and ndcg.is_contiguous() and recall.is_contiguous() and ndcg.dtype == torch.float64
+    else:
+        ndcg = torch.empty((len(ks), B), dtype=torch.float64, device=scores.device)
+        recall = torch.empty_like(ndcg)
     kmax = min(max(ks), n_items)
     topk = torch.empty((B, kmax), dtype=torch.int32, device=scores.device) if want_topk else None
     check(lib().rtx_topk_metrics(_ptr(scores), n_items, B, n_items, heldout.handle, _ptr(rows), arr, len(ks),

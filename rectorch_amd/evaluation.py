@@ -147,29 +147,14 @@ def evaluate_device(model, test_loader, metric_list):
         return evaluate_host(model, test_loader, metric_list)
     ks = sorted({k for _, _, k in parsed})
     out = _PerUserResults(metric_list)
+    # (Round 6 measured two other forms of this loop, alternating in one process (code in the git history): the selection kernel of batch i on a second
+    # stream under the forward of batch i + 1, and on top of that the engine resolved once with two reused score buffers and one flat
+    # metrics buffer: +2-3 % at 500 users per batch in bf16, -3-4 % in float32 and at 2000 users.  The forward (~95 us per 500 users)
+    # and the selection kernel (41 us) contend for the same CUs, and the host is not the limit: the simple loop stays.)
     per_batch = []
-    # Round 6: the selection kernel of batch i runs on a second stream UNDER the forward pass of batch i + 1 (it only reads that
-    # batch's score tensor and the held-out rows; 41 of the 138 us a 500-user batch took).  ``model.eval_overlap = False`` keeps
-    # everything on the caller's stream.
-    main = torch.cuda.current_stream()
-    side = getattr(model, "_eval_side_stream", None) if getattr(model, "eval_overlap", True) else None
-    if side is None and getattr(model, "eval_overlap", True):
-        side = torch.cuda.Stream()
-        try:
-            model._eval_side_stream = side
-        except Exception:                                # noqa: BLE001 -- a model object that refuses attributes: a stream per call
-            pass
     for rb in test_loader.iter_rows():
         scores = model.predict(rb)[0]                    # HIP forward on the sparse rows, -inf at the train items
-        if side is None:
-            per_batch.append(topk_metrics(scores, rb.te, rb.rows, ks))
-            continue
-        side.wait_stream(main)                           # the scores exist
-        with torch.cuda.stream(side):
-            per_batch.append(topk_metrics(scores, rb.te, rb.rows, ks))
-        scores.record_stream(side)                       # (the caching allocator must not hand this block out again under the kernel)
-    if side is not None:
-        main.wait_stream(side)
+        per_batch.append(topk_metrics(scores, rb.te, rb.rows, ks))
     # ONE device -> host copy for the whole loader (the per-batch .cpu() of round 3 was a host sync per 500 users)
     if per_batch:
         ndcg = torch.cat([n for n, _ in per_batch], dim=1).cpu().numpy()

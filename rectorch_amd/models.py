@@ -409,7 +409,9 @@ class AETrainer(TorchNNTrainer):
         return s
 
     # ----------------------------------------------------------------------------------- prediction
-    def _predict_tuple(self, x, remove_train):
+    def _predict_engine(self, n):
+        """what every prediction starts with: the checks, eval mode and the engine of the predict numerics for batches of ``n`` rows
+        (``evaluate_device`` does this ONCE per loader instead of once per batch)"""
         _lib.require_gpu()
         self._join()         # (an epoch interrupted between two deferred-join steps: order this stream behind the side streams first)
         if self._rtx.masters_sharded and self.predict_numerics != self.numerics:
@@ -418,9 +420,12 @@ class AETrainer(TorchNNTrainer):
                                 "model.consolidate() on EVERY rank (it is a collective) before predict() in another numerics "
                                 "mode than the training one")
         self.network.eval()
+        return self.network.rtx_engine(self.predict_numerics, n)
+
+    def _predict_tuple(self, x, remove_train):
         x_in = self.network._as_input(x)
         n = len(x_in) if isinstance(x_in, RowBatch) else x_in.shape[0]
-        eng = self.network.rtx_engine(self.predict_numerics, n)
+        eng = self._predict_engine(n)
         if not isinstance(x_in, RowBatch) and tagged_rows(x_in) is None:
             # dense input: through the PyTorch-ROCm custom op (torch.ops.rectorch_hip.*, rectorch_amd/ops.py)
             from . import ops  # noqa: F401  (registers the ops)
