@@ -259,8 +259,9 @@ int rtx_engine_wait_loss(rtx_engine* e, int32_t step, float* loss_host, double t
  * engine's side stream under its last weight-gradient + Adam launch, into a second batch image; the step that is then given
  * exactly this batch (same csr / target_csr / row_ids pointers, batch, seed, offset, mask) starts with the first-layer product.
  * A hint only: any other batch is gathered by its own step.  The announced row ids must stay unchanged until that step.  NULL
- * cancels.  bf16 numerics, resident CSR batches, single-GPU fused step (the data-parallel step's side stream is busy with the
- * exchange).  The reference densifies every batch on the host (samplers.py:99-100). */
+ * cancels.  bf16 numerics, resident CSR batches; the single-GPU fused step gathers under its last weight kernel, the data-parallel
+ * step (rtx_engine_train_step_dp, since round 6) behind bucket A on its side stream.  The reference densifies every batch on the
+ * host (samplers.py:99-100). */
 int rtx_engine_set_next_batch(rtx_engine* e, const rtx_batch* next, const rtx_step* next_step);
 /* resolves a join left open by a step flagged RTX_STEP_DEFER_JOIN: `stream` continues only after everything that step put on
  * the engine's side stream (no-op when nothing is open) */

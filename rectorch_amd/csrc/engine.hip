@@ -1351,7 +1351,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         // kernel (the step's closing stream dependency ordered it before anything enqueued now): its image set becomes the
         // current one, the gather is skipped.  Anything else than exactly the announced batch / dropout stream: a normal step.
         const rtx_batch& pb = e->pre.b;
-        const bool hit = fuse && !dp && two && st == e->side_for && batch->csr && pb.csr == batch->csr && pb.row_ids == batch->row_ids &&
+        const bool hit = (fuse || (dp && e->bf16)) && two && st == e->side_for && batch->csr && pb.csr == batch->csr && pb.row_ids == batch->row_ids &&
                          pb.target_csr == batch->target_csr && !batch->x_dense && !batch->target_dense && pb.batch == batch->batch &&
                          e->pre.seed == step->seed && e->pre.offset == step->offset && e->pre.mask == step->dropout_mask;
         e->pre.valid = false;
@@ -1749,8 +1749,21 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         RTX_TRY(dp_bucket(0, b_hi, st, false));
         if (dp_side) {
             std::swap(e->L[NL - 1].Wsh, e->L[NL - 1].Wsh_alt);
-            // (the same form of dependency as the single-GPU step's join: stream values where the device has them, else the event)
-            RTX_TRY(stream_dependency(e, e->side, st, e->ev_done, 1));
+            // (round 6) the side stream has finished bucket A long before bucket B's exchange ends: the NEXT step's gather goes there,
+            // behind bucket A and in front of the join -- the data-parallel step then starts with its first-layer product as well
+            if (e->next.valid) RTX_TRY(prefetch_next(e));
+            if ((step->flags & RTX_STEP_DEFER_JOIN) && e->opt_hop_fold && e->bf16) {
+                // (round 6) as the single-GPU step: the side stream stores a number behind its last kernel, and whoever uses the engine
+                // next waits for it -- the next training step inside its first-layer product
+                RTX_TRY(ensure_hopk(e));
+                e->join_seq = ++e->hopk_seq;
+                hipLaunchKernelGGL(k_hop_set, dim3(1), dim3(64), 0, e->side, e->hopk_mem + 3, e->join_seq);
+                RTX_HIP(hipGetLastError());
+                e->join_pending = true;
+            } else {
+                // (the same form of dependency as the single-GPU step's join: stream values where the device has them, else the event)
+                RTX_TRY(stream_dependency(e, e->side, st, e->ev_done, 1));
+            }
         }
         e->shadows_valid = true;
     } else if (two && main_li >= 0) {

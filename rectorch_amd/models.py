@@ -326,10 +326,12 @@ class AETrainer(TorchNNTrainer):
         inj = self._rtx.inject or (None, None)     # (keep-mask uint8 [B, n_items], eps [B, latent]) for parity tests
         seed = st.pending_seed if st.pending_seed is not None else draw_seed()     # (drawn one step early for an announced batch)
         st.pending_seed = None
-        if (next_x is not None and red is None and self.numerics == "bf16" and self._rtx.inject is None and self.prefetch_batches
+        if (next_x is not None and (red is None or native) and self.numerics == "bf16" and self._rtx.inject is None and self.prefetch_batches
                 and isinstance(next_x, RowBatch)):
             st.pending_seed = draw_seed()
-            eng.set_next_batch(next_x, next_target, seed=st.pending_seed, offset=0)
+            # (data parallel, engine-scheduled: the gather rides behind bucket A on the engine's side stream; the dropout stream of a rank is
+            #  keyed by its rank, as the step itself keys it)
+            eng.set_next_batch(next_x, next_target, seed=st.pending_seed, offset=0 if red is None else red.rank)
         step = eng._step(seed=seed, offset=0 if red is None else red.rank, mask=inj[0], noise=inj[1],
                          beta=float(beta), lam=float(lam),
                          # (a rank's slice made by parallel.shard_batch knows the global batch: no collective, no host sync)
@@ -337,7 +339,7 @@ class AETrainer(TorchNNTrainer):
                          lr=float(g['lr']), beta1=float(g['betas'][0]), beta2=float(g['betas'][1]),
                          eps=float(g['eps']), weight_decay=float(g['weight_decay']), step=st.adam_step,
                          flags=(_lib.RTX_STEP_KEEP_GRADS if self.keep_grads else 0) |
-                               (_lib.RTX_STEP_DEFER_JOIN if defer_join and red is None and not want_loss and self.numerics == "bf16" else 0) |
+                               (_lib.RTX_STEP_DEFER_JOIN if defer_join and (red is None or native) and not want_loss and self.numerics == "bf16" else 0) |
                                (_lib.RTX_STEP_GRADS_BF16 if direct16 else 0) |
                                # data parallel: the (rank-independent) DAE regulariser enters the summed loss once
                                (_lib.RTX_STEP_NO_REG_IN_LOSS if red is not None and red.rank != 0 else 0))

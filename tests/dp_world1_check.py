@@ -109,6 +109,34 @@ def main():
         l32, p32 = run(g, torch.float32, True, 256, sharded=sharded, numerics="bf16", engine="native")   # float32 exchange of bf16 numerics
         for k, a, b in zip(keys, p32, one_params):
             assert float(np.max(np.abs(a - b))) < 1e-6, ("bf16 numerics, float32 exchange = the fused single-GPU step", sharded, k, float(np.max(np.abs(a - b))))
+    # ---- round 6: the data-parallel step with the NEXT batch announced (gathered behind bucket A on the engine's side stream) ends
+    #      with the same bits as the step that gathers for itself, and really starts from the prefetched image
+    from rectorch_amd.utils import synth_interactions, hash_state_dict
+    from rectorch_amd.samplers import DataSampler
+    I, H, L, B = 3000, 600, 200, 128
+    X = synth_interactions(5 * B, I, mu=3.5, sigma=0.9, dmax=I // 2, seed=21)
+    sd = hash_state_dict([I, H, L], [L, H, I], "vae", 4)
+    outs = []
+    for announce in (False, True):
+        for sharded in (False, True):
+            net = MultiVAE_net([L, H, I], dropout=0.5)
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+            net.to("cuda")
+            model = MultiVAE(net, beta=0.2, anneal_steps=0, learning_rate=1e-3, numerics="bf16")
+            plan = parallel.attach(model, comm_dtype=torch.bfloat16, sharded=sharded, engine="native", fixed_global_batch=B)
+            torch.manual_seed(77)
+            rbs = [parallel.shard_batch(rb, 0, 1) for rb in DataSampler(X, batch_size=B, shuffle=False).iter_rows()]
+            for t in range(8):
+                model._fused_step(rbs[t % len(rbs)], None, want_loss=False, next_x=rbs[(t + 1) % len(rbs)] if announce else None)
+            model._gather_sharded_state()
+            torch.cuda.synchronize()
+            eng = net._rtx_engines["bf16"]
+            hits = eng.get_option("prefetch_hits")
+            assert (hits >= 7) if announce else (hits == 0), (announce, sharded, hits)
+            outs.append([p.detach().cpu().numpy().copy() for p in net._param_list()])
+            plan.close()
+    for a, b in zip(outs[0] + outs[1], outs[2] + outs[3]):
+        assert np.array_equal(a.view(np.int32), b.view(np.int32)), "data-parallel steps from prefetched batches must equal self-gathered ones bit for bit"
     dist.destroy_process_group()
     print("DP_WORLD1_OK")
 
