@@ -357,7 +357,7 @@ int rtx_svae_train_pack(rtx_svae* s, const int32_t* items, int32_t total_steps, 
  * Adam inside the weight-gradient kernels), "two_stream" (0/1: the two big ones on a second stream beside the
  * data-gradient chain), "side_low_prio" (0/1: that stream at the lowest priority; before the first step), "lse_fuse" (0/1:
  * log-sum-exp partials from the logits GEMM epilogue), "nt_regstage" (0/1: the big NT contractions on the register-staged GEMM
- * instead of the LDS-DMA one), "dw_cfg" (0..3: tile configuration of the weight-gradient kernel), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic), "in_on_main" (0/1: the encoder matrix's weight kernel on
+ * instead of the LDS-DMA one), "dw_cfg" (0..7: tile configuration of the weight-gradient kernel, RtxDwCfg in csrc/rtx_gemm.h; 0 = 64 x 128, the default), "splitk" (split factor of the K = n_items GEMMs, 0 = automatic), "in_on_main" (0/1: the encoder matrix's weight kernel on
  * the caller's stream behind the chain), "sparse_in" (0/1, default 0 since round 4, bf16: the first encoder layer as a sparse VALU
  * product over the batch's stored entries -- spmm_in.hip -- instead of the dense MFMA split-K GEMM; needs a CSR batch,
  * n_items + cond_dim <= 20 480 and at most ~4000 expected 64-entry chunks per batch), "small_fwd" / "small_bwd" (0/1, bf16: hidden

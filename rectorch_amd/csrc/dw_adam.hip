@@ -195,18 +195,26 @@ __device__ __forceinline__ float dw_dae_reg(const RtxDw& p)
     return 0.f;
 }
 
-// WM x WN waves; a wave owns 32 x (128 / WN) of the tile (NJ = 4 / WN accumulators): tile = (32 WM) x 128
+// WM x WN waves; a wave owns 32 x (TNC / WN) of the tile (NJ = TNC / 32 / WN accumulators): tile = (32 WM) x TNC
+// TNC = 128, or 256 (round 6: the optimizer state of a tile row is then ONE KB per array and wave instruction instead of two
+// 512-byte pieces of two rows -- tests/native/test_gemm.cpp "streams": the access pattern alone 57 vs 64 us on the encoder matrix)
 // AL = false (fused Adam only): rows of N_real % 4 != 0 floats (dw_f32x4_u above)
-template <int WM, int WN, int NS, int EPI, bool AL = true>
+// KS: batch rows per K slice (64; 32 for the 256-column tile, whose 64-row slice would be 36 KB: four 18-KB stages keep two
+// workgroups on a CU with three slices ahead)
+template <int WM, int WN, int NS, int EPI, bool AL = true, int TNC = 128, int KS = 64>
 __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   // bid: workgroup number within this problem's grid
 {
-    constexpr int NW = WM * WN, NTH = NW * 64, TM = WM * 32, NJ = 4 / WN;
-    constexpr int SA = TM * 2, SBB = 256;                       // bytes of one k-row of the A / B slice images
-    constexpr int ABYTES = 64 * SA, STAGE = ABYTES + 64 * SBB;  // 4 / 8 / 16 KB + 16 KB
-    constexpr int QA = (ABYTES / 1024 + NW - 1) / NW, QB = 16 / NW, LPS = QA + QB;
-    constexpr int RPP = NTH / 32, NP = TM / RPP;                // tile rows per epilogue pass, passes
-    static_assert(WN * NJ == 4 && (ABYTES / 1024) % NW == 0 && 16 % NW == 0, "tile shape: whole DMA instructions per wave");
-    static_assert(TM * 128 * 4 <= NS * STAGE, "the parked gradient tile must fit in the stages");
+    constexpr int NW = WM * WN, NTH = NW * 64, TM = WM * 32, NJ = TNC / 32 / WN;
+    constexpr int SA = TM * 2, SBB = TNC * 2;                   // bytes of one k-row of the A / B slice images
+    constexpr int ABYTES = KS * SA, STAGE = ABYTES + KS * SBB;  // 4 / 8 / 16 KB + 16 / 32 KB (KS = 64)
+    constexpr int PCA = ABYTES / 1024;                          // 1-KB DMA pieces of an A slice
+    // (eight waves on a 32-row tile: four pieces for eight waves -- waves 4 .. 7 fetch pieces 0 .. 3 a second time, to the same place, so that
+    //  every wave has the same number of operations in flight and the counted vmcnt waits below hold for all of them)
+    constexpr int QA = (PCA + NW - 1) / NW, QB = (KS * SBB / 1024) / NW, LPS = QA + QB;
+    constexpr int TPR = TNC / 4;                                // epilogue: threads per tile row (16 B each)
+    constexpr int RPP = NTH / TPR, NP = TM / RPP;               // tile rows per epilogue pass, passes
+    static_assert(WN * NJ * 32 == TNC && (PCA % NW == 0 || NW % PCA == 0) && PCA >= 1 && (KS * SBB / 1024) % NW == 0 && (KS == 64 || KS == 32), "tile shape: whole DMA instructions per wave");
+    static_assert(TM * TNC * 4 <= NS * STAGE, "the parked gradient tile must fit in the stages");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,7 +243,7 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
     const unsigned char* gA[QA];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-        const int o = (wave + q * NW) * 1024 + lane * 16;   // physical byte of this lane's piece in the A slice image
+        const int o = ((wave + q * NW) % PCA) * 1024 + lane * 16;   // physical byte of this lane's piece in the A slice image
         const int rr = o / SA, ww = o % SA;
         const int cc = (SA >= 256) ? ((ww >> 6) ^ (rr & 3)) : (SA == 128) ? ((ww >> 6) ^ ((rr >> 1) & 1)) : 0;
         gA[q] = (const unsigned char*)p.A + (size_t)rr * rowA + (size_t)tm * TM * 2 + (cc << 6) + (ww & 63);
@@ -246,29 +254,32 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
         const int o = (wave + q * NW) * 1024 + lane * 16;
         const int rr = o / SBB, ww = o % SBB;
         const int cc = (ww >> 6) ^ (rr & 3);
-        gB[q] = (const unsigned char*)p.B + (size_t)rr * rowB + (size_t)tn * 256 + (cc << 6) + (ww & 63);
+        // (TNC = 256 on a row of an odd number of 128-column blocks: the last tile's upper half lies beyond the row -- its lanes fetch
+        //  the row's last 16 bytes instead, values that only reach accumulator columns >= N_pad, which the epilogue drops)
+        const size_t cb = (size_t)tn * SBB + (cc << 6) + (ww & 63);
+        gB[q] = (const unsigned char*)p.B + (size_t)rr * rowB + (TNC > 128 ? (cb < rowB ? cb : rowB - 16) : cb);
     }
     dw_lds_byte* lbase = (dw_lds_byte*)smem;
     auto load_slice = [&](int stage, int t) __attribute__((always_inline)) {
         dw_lds_byte* sb = lbase + stage * STAGE + wave * 1024;
 #pragma unroll
         for (int q = 0; q < QA; ++q)
-            __builtin_amdgcn_global_load_lds((const void*)(gA[q] + (size_t)t * 64 * rowA),
-                                             (void __attribute__((address_space(3)))*)(sb + q * NW * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(gA[q] + (size_t)t * KS * rowA),
+                                             (void __attribute__((address_space(3)))*)(lbase + stage * STAGE + ((wave + q * NW) % PCA) * 1024), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < QB; ++q)
-            __builtin_amdgcn_global_load_lds((const void*)(gB[q] + (size_t)t * 64 * rowB),
+            __builtin_amdgcn_global_load_lds((const void*)(gB[q] + (size_t)t * KS * rowB),
                                              (void __attribute__((address_space(3)))*)(sb + ABYTES + q * NW * 1024), 16, 0, 0);
     };
     const bool dma_first = (skip & 16) != 0;
     if (dma_first && !(skip & 1)) {
-        load_slice(0, 0);
-        if (NS == 3) load_slice(1, 1);
+#pragma unroll
+        for (int i = 0; i < (NS >= 3 ? NS - 1 : 1); ++i) load_slice(i, i);
     }
 
     // ---- optimizer state of this tile: issued before anything else, consumed after the K walk -------------------------
-    const int col4 = (tid & 31) * 4, rowl = tid >> 5;
-    const int col = tn * 128 + col4;
+    const int col4 = (tid % TPR) * 4, rowl = tid / TPR;
+    const int col = tn * TNC + col4;
     dw_f32x4 pv[NP], mv[NP], vv[NP];
     if (skip & 2) {
 #pragma unroll
@@ -303,9 +314,9 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
 #ifndef DW_EARLY_PASSES
 #define DW_EARLY_PASSES (NP / 2)   // (measurement builds: 0 .. NP)
 #endif
-    constexpr int NPH = (DW_SPLIT_PMV && EPI == RTX_DW_ADAM && NS == 3 && NP >= 2) ? (DW_EARLY_PASSES < NP ? DW_EARLY_PASSES : NP) : NP;   // passes loaded up front
+    constexpr int NPH = (DW_SPLIT_PMV && EPI == RTX_DW_ADAM && NS >= 3 && NP >= 2) ? (DW_EARLY_PASSES < NP ? DW_EARLY_PASSES : NP) : NP;   // passes loaded up front
     constexpr int HL = 3 * (NP - NPH);                                                               // late load instructions per thread
-    const bool late = HL > 0 && !(skip & 3) && p.k_slices >= 3;
+    const bool late = HL > 0 && !(skip & 3) && p.k_slices * (64 / KS) >= NS;
     if (!(skip & 2)) {
         if constexpr (EPI == RTX_DW_ADAM) {
             load_state(std::integral_constant<int, 0>(), std::integral_constant<int, NPH>());
@@ -350,19 +361,22 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
         }                                                                                                                \
     }
 
-    const int nk = (skip & 1) ? 0 : p.k_slices;   // >= 2
+    const int nk = (skip & 1) ? 0 : p.k_slices * (64 / KS);   // >= 2 (KS = 32: >= 4)
     if (!dma_first && nk) {
-        load_slice(0, 0);
-        if (NS == 3) load_slice(1, 1);
+#pragma unroll
+        for (int i = 0; i < (NS >= 3 ? NS - 1 : 1); ++i) load_slice(i, i);
     }
     if (stamps && tid == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
         // my pieces of slice t have landed.  Younger operations that may still fly: slice t + 1's pieces (LPS), and -- in the last two
         // iterations -- the late half of the optimizer state (HL), issued behind the last slice's DMA; p / m / v's first half is older
-        if (NS == 3 && nk - t > 2) dw_wait_vm<LPS>();
-        else if (NS == 3 && nk - t == 2) { if (late) dw_wait_vm<LPS + HL>(); else dw_wait_vm<LPS>(); }
-        else { if (late && NS == 3) dw_wait_vm<HL>(); else dw_wait_vm<0>(); }
+        // (NS - 2 younger slices in the steady state; rem - 1 of them in the last NS - 1 iterations, where the late loads fly as well)
+        const int rem = nk - t;
+        if (NS >= 3 && rem > NS - 1) dw_wait_vm<(NS >= 3 ? NS - 2 : 0) * LPS>();
+        else if (NS >= 4 && rem == 3) { if (late) dw_wait_vm<2 * LPS + HL>(); else dw_wait_vm<2 * LPS>(); }
+        else if (NS >= 3 && rem == 2) { if (late) dw_wait_vm<LPS + HL>(); else dw_wait_vm<LPS>(); }
+        else { if (late && NS >= 3) dw_wait_vm<HL>(); else dw_wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();         // everybody's have; everybody is done reading slice t-1
         if (stamps && tid == 0 && t == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();
         if (t + NS - 1 < nk) {                // refill the stage slice t-1 just released
@@ -379,12 +393,14 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
             DW_FRAG(y, 1)
             dw_wait_lgkm<NR>();
             DW_MMA(x)
-            DW_FRAG(x, 2)
-            dw_wait_lgkm<NR>();
-            DW_MMA(y)
-            DW_FRAG(y, 3)
-            dw_wait_lgkm<NR>();
-            DW_MMA(x)
+            if constexpr (KS == 64) {
+                DW_FRAG(x, 2)
+                dw_wait_lgkm<NR>();
+                DW_MMA(y)
+                DW_FRAG(y, 3)
+                dw_wait_lgkm<NR>();
+                DW_MMA(x)
+            }
             dw_wait_lgkm<0>();
             DW_MMA(y)
         }
@@ -402,7 +418,7 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tile[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * 128 + (wn * NJ + j) * 32 + r] = acc[j][e];
+        for (int e = 0; e < 16; ++e) tile[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * g) * TNC + (wn * NJ + j) * 32 + r] = acc[j][e];
     __syncthreads();
     if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
     const bool nostore = (skip & 4) != 0;
@@ -414,7 +430,7 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int lr = q * RPP + rowl;
-        const dw_f32x4 g4 = *(const dw_f32x4*)(tile + lr * 128 + col4);
+        const dw_f32x4 g4 = *(const dw_f32x4*)(tile + lr * TNC + col4);
         if constexpr (EPI == RTX_DW_ADAM && !AL) {
             dw_f32x4 a, b, c;
 #pragma unroll
@@ -436,10 +452,10 @@ __device__ __forceinline__ void dw_tile(const RtxDw& p, const unsigned bid)   //
     }
 }
 
-template <int WM, int WN, int NS, int EPI, bool AL = true>
+template <int WM, int WN, int NS, int EPI, bool AL = true, int TNC = 128, int KS = 64>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn(const RtxDw p)
 {
-    dw_tile<WM, WN, NS, EPI, AL>(p, blockIdx.x);
+    dw_tile<WM, WN, NS, EPI, AL, TNC, KS>(p, blockIdx.x);
 }
 
 // Several matrices in ONE launch (same K, same tile configuration, same epilogue): problem k owns the workgroups
@@ -451,26 +467,26 @@ struct RtxDwGroup {
     unsigned first[RTX_DW_GROUP_MAX + 1];
     RtxDw p[RTX_DW_GROUP_MAX];
 };
-template <int WM, int WN, int NS, int EPI, bool AL = true>
+template <int WM, int WN, int NS, int EPI, bool AL = true, int TNC = 128, int KS = 64>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * (WM >= 4 ? 1 : 2)) / 256) void rtx_dw_tn_group(const RtxDwGroup g)
 {
     int k = 0;
 #pragma unroll
     for (int q = 1; q < RTX_DW_GROUP_MAX; ++q)
         if (q < g.n && blockIdx.x >= g.first[q]) k = q;
-    dw_tile<WM, WN, NS, EPI, AL>(g.p[k], blockIdx.x - g.first[k]);   // (AL = false serves the aligned problems of the group as well)
+    dw_tile<WM, WN, NS, EPI, AL, TNC, KS>(g.p[k], blockIdx.x - g.first[k]);   // (AL = false serves the aligned problems of the group as well)
 }
 
 // (Round 4 ran this launch as a PERSISTENT grid -- 512 resident workgroups pulling tiles from per-XCD counters, to close the ~5 us a
 // slot stays empty between two workgroups.  It was 1.5x SLOWER (104-115 vs 70-76 us): resident workgroups fall into lock step -- all
 // load, all multiply, all store -- and HBM serves pure read / pure write bursts at 4.6 / 4.3 TB/s against 6.3 for the mix that the
 // per-tile launch's dispatch jitter maintains; in the step it also held the LDS the chain's kernels need.  profiles/r4_dw_persistent.txt.)
-template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream)
+template <int WM, int WN, int NS, int EPI, bool AL = true, int TNC = 128, int KS = 64> static int dw_launch_group(const RtxDw* d, int n, hipStream_t stream)
 {
-    constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
+    constexpr int TM = WM * 32, LDS = NS * (KS * TM * 2 + KS * TNC * 2);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn_group<WM, WN, NS, EPI, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn_group<WM, WN, NS, EPI, AL, TNC, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
     RtxDwGroup g = {};
@@ -483,17 +499,17 @@ template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch_
         total += (unsigned)(8 * ((d[k].m_tiles * d[k].n_tiles + 7) / 8));
     }
     g.first[n] = total;
-    hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI, AL>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
+    hipLaunchKernelGGL((rtx_dw_tn_group<WM, WN, NS, EPI, AL, TNC, KS>), dim3(total), dim3(WM * WN * 64), LDS, stream, g);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
 
-template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(const RtxDw& d, hipStream_t stream)
+template <int WM, int WN, int NS, int EPI, bool AL = true, int TNC = 128, int KS = 64> static int dw_launch(const RtxDw& d, hipStream_t stream)
 {
-    constexpr int TM = WM * 32, LDS = NS * (64 * TM * 2 + 64 * 256);
+    constexpr int TM = WM * 32, LDS = NS * (KS * TM * 2 + KS * TNC * 2);
     static bool configured = false;
     if (!configured) {
-        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RTX_HIP(hipFuncSetAttribute((const void*)rtx_dw_tn<WM, WN, NS, EPI, AL, TNC, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
     const int total = d.m_tiles * d.n_tiles;
@@ -501,12 +517,13 @@ template <int WM, int WN, int NS, int EPI, bool AL = true> static int dw_launch(
     RtxDw dd = d;
     dd.dbg_skip = g_dw_skip; dd.dbg_stamps = g_dw_stamps;
     const int lds = std::min(LDS + (d.lds_pad > 0 ? d.lds_pad : 0), 160 * 1024);   // (RtxDw::lds_pad: room for a kernel running beside this one)
-    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI, AL>), grid, dim3(WM * WN * 64), lds, stream, dd);
+    hipLaunchKernelGGL((rtx_dw_tn<WM, WN, NS, EPI, AL, TNC, KS>), grid, dim3(WM * WN * 64), lds, stream, dd);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
 
 int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : (cfg == RTX_DW_128x128 || cfg == RTX_DW_128x128_W4) ? 128 : 32; }
+int rtx_dw_tile_cols(int cfg) { return (cfg >= RTX_DW_32x256 && cfg <= RTX_DW_32x256_K32) ? 256 : 128; }
 
 template <int EPI, bool AL = true> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
 {
@@ -516,17 +533,20 @@ template <int EPI, bool AL = true> static int dw_launch_cfg(const RtxDw& d, int 
     case RTX_DW_128x128: return dw_launch<4, 2, 2, EPI, AL>(d, stream);     // 8 waves, 2 stages (64 KB), 32 x 64 per wave: half the
                                                                              //   operand bytes per parameter of the 64-row tile
     case RTX_DW_128x128_W4: return dw_launch<4, 1, 2, EPI, AL>(d, stream);  // 4 waves, 2 stages (64 KB), 32 x 128 per wave
+    case RTX_DW_32x256: return dw_launch<1, 8, 2, EPI, AL, 256>(d, stream);     // 8 waves (32 x 32 each), 2 stages (72 KB): 2 workgroups per CU
+    case RTX_DW_32x256_S3: return dw_launch<1, 8, 3, EPI, AL, 256>(d, stream);  // 3 stages (108 KB): 1 workgroup per CU
+    case RTX_DW_32x256_K32: return dw_launch<1, 8, 4, EPI, AL, 256, 32>(d, stream);  // 32-row slices, 4 stages (72 KB): 2 workgroups per CU, three slices ahead
     default: return dw_launch<2, 4, 3, EPI, AL>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
     }
 }
 
-// d.m_tiles = M_pad / rtx_dw_tile_rows(cfg), d.n_tiles = N_pad / 128, d.k_slices = K_pad / 64 (K_pad a multiple of 128)
+// d.m_tiles = M_pad / rtx_dw_tile_rows(cfg), d.n_tiles = ceil(N_pad / rtx_dw_tile_cols(cfg)), d.k_slices = K_pad / 64 (K_pad a multiple of 128)
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
 {
     RTX_CHECK(d.A && d.B && d.m_tiles > 0 && d.n_tiles > 0 && d.k_slices >= 2, RTX_EINVAL, "dw: bad problem (%d x %d tiles, %d K slices)", d.m_tiles, d.n_tiles,
               d.k_slices);
     RTX_CHECK(epilogue == RTX_DW_GRAD || epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw: bad epilogue %d", epilogue);
-    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128_W4, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_32x256_K32, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
     if (epilogue == RTX_DW_ADAM) {
         RTX_CHECK(d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of at least 4 floats (got %d)", d.N_real);
@@ -549,6 +569,9 @@ template <int EPI, bool AL = true> static int dw_launch_group_cfg(const RtxDw* d
     case RTX_DW_32x128_S2: return dw_launch_group<1, 4, 2, EPI, AL>(d, n, stream);
     case RTX_DW_128x128: return dw_launch_group<4, 2, 2, EPI, AL>(d, n, stream);
     case RTX_DW_128x128_W4: return dw_launch_group<4, 1, 2, EPI, AL>(d, n, stream);
+    case RTX_DW_32x256: return dw_launch_group<1, 8, 2, EPI, AL, 256>(d, n, stream);
+    case RTX_DW_32x256_S3: return dw_launch_group<1, 8, 3, EPI, AL, 256>(d, n, stream);
+    case RTX_DW_32x256_K32: return dw_launch_group<1, 8, 4, EPI, AL, 256, 32>(d, n, stream);
     default: return dw_launch_group<2, 4, 3, EPI, AL>(d, n, stream);
     }
 }
@@ -558,7 +581,7 @@ int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_
     RTX_CHECK(d && n >= 1 && n <= RTX_DW_GROUP_MAX, RTX_EINVAL, "dw group: 1..%d problems (got %d)", RTX_DW_GROUP_MAX, n);
     if (n == 1) return rtx_dw_launch(d[0], epilogue, cfg, stream);
     RTX_CHECK(epilogue == RTX_DW_ADAM || epilogue == RTX_DW_GRAD, RTX_EINVAL, "dw group: bad epilogue %d", epilogue);
-    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128_W4, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_32x256_K32, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     bool any_unaligned = false;   // one matrix with rows of N_real % 4 != 0 floats: the whole launch takes the unaligned epilogue
     for (int k = 0; k < n; ++k) {
         const RtxDw& q = d[k];

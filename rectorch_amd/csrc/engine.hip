@@ -1429,7 +1429,7 @@ static int loss_grads_impl(rtx_engine* e, const rtx_batch* batch, const rtx_step
         const bool fused = fuse && layer_fusable(e, l);
         d = RtxDw{};
         d.A = l.D; d.lda = l.outp; d.B = l.A; d.ldb = l.inp;
-        d.m_tiles = l.outp / rtx_dw_tile_rows(dw_cfg); d.n_tiles = l.inp / 128; d.k_slices = Bp / 64;
+        d.m_tiles = l.outp / rtx_dw_tile_rows(dw_cfg); d.n_tiles = (l.inp + rtx_dw_tile_cols(dw_cfg) - 1) / rtx_dw_tile_cols(dw_cfg); d.k_slices = Bp / 64;
         d.M_real = l.out; d.N_real = l.in;
         if (fused) {
             RtxAdamArgs sc = {};
@@ -2251,7 +2251,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "small_bwd") e->opt_small_bwd = value != 0;
     else if (k == "big_batch_tiles") e->opt_big_batch_tiles = value != 0;
     else if (k == "dw_cfg") {
-        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128_W4, RTX_EINVAL, "set_option: dw_cfg must be 0..4");
+        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_32x256_K32, RTX_EINVAL, "set_option: dw_cfg must be 0..7");
         e->opt_dw_cfg = value;
         e->opt_dw_cfg_set = 1;
     } else if (k == "splitk") {

@@ -1315,6 +1315,7 @@ struct RtxTopkArgs {
     double* recall;   // [n_k][B]  (nullable)
     int32_t* topk;    // [B][K]    (nullable)
     int B;
+    int dbg_stop;     // measurement (env RTX_TOPK_STOP at launch): the kernel returns after stage dbg_stop (0 = runs to the end)
 };
 
 // bitonic sort of n (a power of two <= RTX_TOPK_MAX) (key, index) pairs in LDS: key descending, index ascending among equal keys
@@ -1376,84 +1377,176 @@ template <typename F> __device__ __forceinline__ void topk_scan_row(const float*
 
 // NV > 0: the whole row (<= NV * 1024 items, 16-byte aligned) is loaded ONCE, NV 16-byte loads per thread in one burst, and stays in
 // registers for both passes over it (maxima, collection); NV = 0: the row is streamed twice (any length / alignment).
+//
+// Round 6: the kernel is ONE workgroup's latency (500 rows = 500 workgroups, all resident at once), and that latency was barriers:
+// two bitonic sorts in LDS (36 + 36..45 compare-exchange steps, a __syncthreads each), six two-barrier block sums per cut-off,
+// a serial atomic counter for the candidates and four double-precision log2 per thread.  Now
+//   * order statistics by COUNTING: every thread ranks its own keys against all the others through broadcast LDS reads (16 bytes
+//     = 4 keys per instruction, every lane the same address: no bank conflict) -- one barrier per "sort";
+//   * candidates placed by a block prefix sum of per-thread counts (no atomics; the order is irrelevant, they are ranked next);
+//   * the held-out row (indices, values) requested at kernel entry together with the score row, parked in LDS: the relevance look-up
+//     searches LDS, and its sum / positive count are block sums instead of a serial loop per thread;
+//   * every cut-off's three sums reduced together: one barrier for all of them;  log2 only for ranks < K.
+// (reference: rectorch/metrics.py:136-147, 187-196; evaluation.py:100-106)
+// log2(r + 2) for every rank r < RTX_TOPK_MAX, written once per device by the host (glibc's log2, the function numpy calls in the
+// reference's metrics): four software double-precision logarithms per thread were ~8 us of this kernel
+__device__ double g_topk_log2[RTX_TOPK_MAX];
+#define RTX_TOPK_HELD_CAP 512      // held-out entries of a row parked in LDS (longer rows: the global-memory look-up of rounds 1-5)
+
+// rank (0 = first) of element (k, id) among the n (key, id) pairs in LDS, ordered by key descending, id ascending among equal keys;
+// n4 = ceil(n / 4): the arrays are padded to a multiple of 4 with key 0 (below every real key)
+__device__ __forceinline__ uint32_t topk_rank_of(const uint32_t* __restrict__ keys, const int32_t* __restrict__ ids, int n4, uint32_t k, int32_t id)
+{
+    uint32_t gt = 0, eq = 0;
+    const uint4* k4 = (const uint4*)keys;
+    for (int i = 0; i < n4; ++i) {
+        const uint4 q = k4[i];
+        gt += (q.x > k) + (q.y > k) + (q.z > k) + (q.w > k);
+        eq += (q.x == k) + (q.y == k) + (q.z == k) + (q.w == k);
+    }
+    if (eq > 1) {   // ties (rare: masked entries, rows of equal scores): the smaller index first
+        for (int i = 0; i < n4 * 4; ++i) gt += (keys[i] == k && ids[i] < id);
+    }
+    return gt;
+}
+
+// number of keys greater than k among the n4 * 4 keys in LDS (two instructions per key: a compare and an add-with-carry)
+__device__ __forceinline__ uint32_t topk_count_gt(const uint32_t* __restrict__ keys, int n4, uint32_t k)
+{
+    uint32_t g0 = 0, g1 = 0;
+    const uint4* k4 = (const uint4*)keys;
+    for (int i = 0; i < n4; ++i) {
+        const uint4 q = k4[i];
+        g0 += (q.x > k) + (q.y > k);
+        g1 += (q.z > k) + (q.w > k);
+    }
+    return g0 + g1;
+}
+__device__ __forceinline__ uint32_t topk_max4(const uint4& q) { return max(max(q.x, q.y), max(q.z, q.w)); }
+
 template <int NV>
 __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
 {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t ckey[RTX_TOPK_MAX];
-    __shared__ int32_t cidx[RTX_TOPK_MAX];
-    __shared__ float rel[RTX_TOPK_MAX];
-    __shared__ double dred[4];
-    __shared__ uint32_t sh_prefix, sh_mask, sh_need, sh_cnt_gt, sh_cnt_eq;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t ckey[RTX_TOPK_MAX];
+    __shared__ __attribute__((aligned(16))) int32_t cidx[RTX_TOPK_MAX];
+    __shared__ int32_t sidx[RTX_TOPK_MAX];       // the ranked items
+    __shared__ uint32_t relb[RTX_TOPK_MAX];      // step 4: a counter per rank; from step 5 on: the relevance of the ranked item as float bits
+    __shared__ int32_t hidx[RTX_TOPK_HELD_CAP];
+    __shared__ float hval[RTX_TOPK_HELD_CAP];
+    __shared__ double dred[16 * 12];
+    __shared__ double hred[8];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t sh_prefix, sh_mask, sh_need, sh_cnt_gt, sh_cnt_eq, sh_L, sh_tie;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = a.scores + (size_t)b * a.ld;
     const int K = a.K;
+    // ---- 0. everything this workgroup will read from memory is requested here: the held-out row's bounds (uniform: scalar loads),
+    //         the score row (NV x 16 B per thread), the held-out entries (<= 2 per thread)
+    const int64_t u = csr_row(a.held, b);
+    const int64_t hb = a.held.indptr[u], he = a.held.indptr[u + 1];
+    const int hn = (int)(he - hb);
+    const bool held_in_lds = hn <= RTX_TOPK_HELD_CAP;
     float4 rv[NV > 0 ? NV : 1];
     const int n4 = a.n_items >> 2;
     if constexpr (NV > 0) {
         const float4* __restrict__ r4 = (const float4*)row;
 #pragma unroll
-        for (int u = 0; u < NV; ++u) rv[u] = r4[min(tid + u * 256, n4 > 0 ? n4 - 1 : 0)];   // (clamped: the guard is at the use)
+        for (int q = 0; q < NV; ++q) rv[q] = r4[min(tid + q * 256, n4 > 0 ? n4 - 1 : 0)];   // (clamped: the guard is at the use)
     }
-    auto scan = [&](auto&& f) __attribute__((always_inline)) {
+    double l2r[RTX_TOPK_MAX / 256];             // log2(r + 2) of this thread's ranks (only ranks < K are ever used)
+#pragma unroll
+    for (int m = 0; m < RTX_TOPK_MAX / 256; ++m) l2r[m] = g_topk_log2[tid + 256 * m];
+    int32_t hi0 = 0x7fffffff, hi1 = 0x7fffffff;
+    float hv0 = 0.f, hv1 = 0.f;
+    if (held_in_lds) {
+        if (tid < hn) { hi0 = a.held.indices[hb + tid]; hv0 = a.held.values ? a.held.values[hb + tid] : 1.f; }
+        if (tid + 256 < hn) { hi1 = a.held.indices[hb + tid + 256]; hv1 = a.held.values ? a.held.values[hb + tid + 256] : 1.f; }
+    }
+    // the row as order-preserving keys (registers); f4(keys of four neighbours, index of the first) / f1(key, index) visit every element
+    uint4 kv[NV > 0 ? NV : 1];
+    if constexpr (NV > 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) kv[q] = make_uint4(score_key(rv[q].x), score_key(rv[q].y), score_key(rv[q].z), score_key(rv[q].w));
+    }
+    auto scan = [&](auto&& f4, auto&& f1) __attribute__((always_inline)) {
         if constexpr (NV > 0) {
 #pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int j = tid + u * 256;
-                if (j < n4) {
-                    const int i0 = j * 4;
-                    f(score_key(rv[u].x), i0); f(score_key(rv[u].y), i0 + 1); f(score_key(rv[u].z), i0 + 2); f(score_key(rv[u].w), i0 + 3);
-                }
+            for (int q = 0; q < NV; ++q) {
+                const int j = tid + q * 256;
+                if (j < n4) f4(kv[q], j * 4);
             }
-            for (int i = n4 * 4 + tid; i < a.n_items; i += 256) f(score_key(row[i]), i);
+            for (int i = n4 * 4 + tid; i < a.n_items; i += 256) f1(score_key(row[i]), i);
         } else {
-            topk_scan_row(row, a.n_items, tid, f);
+            topk_scan_row(row, a.n_items, tid, f1);
         }
     };
     // ---- 1. per-thread maxima
     const int c = (K + 255) / 256;              // 1 .. 4
     uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;    // this thread's largest keys, descending (0 = below every real key)
-    if (c == 1) {
-        scan([&](uint32_t k, int) { t0 = max(t0, k); });
-    } else {
-        scan([&](uint32_t k, int) {
-            if (k > t0) { const uint32_t x = t0; t0 = k; k = x; }
-            if (k > t1) { const uint32_t x = t1; t1 = k; k = x; }
-            if (k > t2) { const uint32_t x = t2; t2 = k; k = x; }
-            if (k > t3) t3 = k;
-        });
-    }
-    // ---- 2. L = K-th largest of the 256 c thread maxima
+    auto ins = [&](uint32_t k) __attribute__((always_inline)) {
+        if (k > t0) { const uint32_t x = t0; t0 = k; k = x; }
+        if (k > t1) { const uint32_t x = t1; t1 = k; k = x; }
+        if (k > t2) { const uint32_t x = t2; t2 = k; k = x; }
+        if (k > t3) t3 = k;
+    };
+    if (c == 1) scan([&](const uint4& q, int) { t0 = max(t0, topk_max4(q)); }, [&](uint32_t k, int) { t0 = max(t0, k); });
+    else scan([&](const uint4& q, int) { ins(q.x); ins(q.y); ins(q.z); ins(q.w); }, [&](uint32_t k, int) { ins(k); });
+    if (a.dbg_stop == 1) { if (t0 == 1u) a.ndcg[b] = 0.0; return; }
+    // ---- 2. L = K-th largest of the 256 c thread maxima: a LOWER BOUND of the row's K-th largest score (they are distinct elements).
+    //         L = the smallest key that fewer than K keys exceed: only "greater than" counts are needed, ties included
     const int n1 = c == 1 ? 256 : (c == 2 ? 512 : 1024);
-    ckey[tid] = t0; cidx[tid] = tid;
-    if (c >= 2) { ckey[256 + tid] = t1; cidx[256 + tid] = 256 + tid; }
-    if (c >= 3) {
-        ckey[512 + tid] = t2; cidx[512 + tid] = 512 + tid;
-        ckey[768 + tid] = c >= 4 ? t3 : 0u; cidx[768 + tid] = 768 + tid;
+    ckey[tid] = t0;
+    if (c >= 2) ckey[256 + tid] = t1;
+    if (c >= 3) { ckey[512 + tid] = t2; ckey[768 + tid] = c >= 4 ? t3 : 0u; }
+    if (held_in_lds) { hidx[tid] = hi0; hval[tid] = hv0; hidx[tid + 256] = hi1; hval[tid + 256] = hv1; }
+    if (tid == 0) { sh_L = 0xffffffffu; sh_tie = 0; }
+    __syncthreads();
+    {
+        uint32_t cand = 0xffffffffu;
+        if (topk_count_gt(ckey, n1 / 4, t0) < (uint32_t)K) cand = t0;
+        if (c >= 2) {
+            if (topk_count_gt(ckey, n1 / 4, t1) < (uint32_t)K) cand = min(cand, t1);
+            if (c >= 3) {
+                if (topk_count_gt(ckey, n1 / 4, t2) < (uint32_t)K) cand = min(cand, t2);
+                if (c >= 4 && topk_count_gt(ckey, n1 / 4, t3) < (uint32_t)K) cand = min(cand, t3);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, (uint32_t)__shfl_xor((int)cand, o, 64));
+        if (lane == 0) atomicMin(&sh_L, cand);
     }
     __syncthreads();
-    topk_sort(ckey, cidx, n1, tid);
-    const uint32_t L = ckey[K - 1];             // (K <= 256 c; 0 when the row has fewer than K elements: everything is collected)
+    const uint32_t L = sh_L;                    // (a row of fewer than K elements: a padding key, 0 -- everything is collected)
+    if (a.dbg_stop == 2) { if (L == 1u) a.ndcg[b] = 0.0; return; }
+    // ---- 3. collect the elements >= L: per-thread counts, block prefix sum, placement.  One element in a hundred qualifies: a group of
+    //         four neighbours is looked at only when its maximum does
+    uint32_t mine = 0;
+    scan([&](const uint4& q, int) { if (topk_max4(q) >= L) mine += (q.x >= L) + (q.y >= L) + (q.z >= L) + (q.w >= L); },
+         [&](uint32_t k, int) { mine += k >= L; });
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    for (int i = tid; i < RTX_TOPK_MAX; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; relb[i] = 0u; }   // (everybody has read the maxima: barrier above)
     __syncthreads();
-    // ---- 3. collect the elements >= L
-    if (tid == 0) { sh_cnt_gt = 0; sh_cnt_eq = 0; }
-    for (int i = tid; i < RTX_TOPK_MAX; i += 256) { ckey[i] = 0; cidx[i] = 0x7fffffff; }
-    __syncthreads();
-    scan([&](uint32_t k, int i) {
-        if (k >= L) {
-            const uint32_t p = atomicAdd(&sh_cnt_gt, 1u);
-            if (p < (uint32_t)RTX_TOPK_MAX) { ckey[p] = k; cidx[p] = i; }
-        }
-    });
-    __syncthreads();
-    const uint32_t n_cand = sh_cnt_gt;
-    int n_sort = a.Kp2;
+    uint32_t base = incl - mine;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const uint32_t n_cand = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (n_cand <= (uint32_t)RTX_TOPK_MAX) {
-        while ((uint32_t)n_sort < n_cand) n_sort <<= 1;
-    } else {
+        uint32_t pos = base;
+        auto put = [&](uint32_t k, int i) __attribute__((always_inline)) { if (k >= L) { ckey[pos] = k; cidx[pos] = i; ++pos; } };
+        scan([&](const uint4& q, int i0) { if (topk_max4(q) >= L) { put(q.x, i0); put(q.y, i0 + 1); put(q.z, i0 + 2); put(q.w, i0 + 3); } }, put);
+    }
+    __syncthreads();
+    int n_rank = (int)n_cand;                   // candidates to rank
+    if (a.dbg_stop == 3) { if (ckey[tid] == 1u) a.ndcg[b] = 0.0; return; }
+    if (n_cand > (uint32_t)RTX_TOPK_MAX) {
         // ---- a row with more than RTX_TOPK_MAX elements tied at / above the bound: radix select of the K-th largest key T, then
         //      everything above T and need_eq of the ties (ties at the K-th place are arbitrary in the reference's argpartition too)
-        __syncthreads();
         if (tid == 0) { sh_prefix = 0; sh_mask = 0; sh_need = (uint32_t)K; }
         __syncthreads();
         for (int shift = 24; shift >= 0; shift -= 8) {
@@ -1499,47 +1592,77 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
             }
         }
         __syncthreads();
+        n_rank = K;
     }
-    // ---- sort the candidates (key desc, index asc); the padding (key 0, idx max) sinks to the end: the first K are the top K
-    topk_sort(ckey, cidx, n_sort, tid);
-    // ---- relevance of every ranked item: value of the held-out row at that item (0 if absent)
-    const int64_t u = csr_row(a.held, b);
-    const int64_t hb = a.held.indptr[u], he = a.held.indptr[u + 1];
-    for (int r = tid; r < K; r += 256) {
-        const int item = cidx[r];
-        float v = 0.f;
-        int64_t lo = hb, hi = he;     // binary search (column ids are sorted within a row)
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            const int cc = a.held.indices[mid];
-            if (cc < item) lo = mid + 1; else hi = mid;
+    // ---- 4. rank the candidates (key descending, index ascending among equal keys): the ranks < K are the answer, in order.
+    //         First by "greater than" counts alone (two instructions per pair); two candidates of one rank below K -- equal scores
+    //         among the ranked items: rare -- are noticed through a counter per rank, and only then the exact ranks (ties by index)
+    //         are computed.
+    for (int i = tid; i < K; i += 256) sidx[i] = 0x7fffffff;     // (a row of fewer than K elements: the tail stays "no item")
+    __syncthreads();
+    const int r4n = (n_rank + 3) >> 2;
+    for (int p = tid; p < n_rank; p += 256) {
+        const uint32_t r = topk_count_gt(ckey, r4n, ckey[p]);
+        if (r < (uint32_t)K) {
+            if (atomicAdd(&relb[r], 1u) != 0u) sh_tie = 1;
+            sidx[r] = cidx[p];
         }
-        if (lo < he && a.held.indices[lo] == item) v = a.held.values ? a.held.values[lo] : 1.f;
-        rel[r] = v;
-        if (a.topk) a.topk[(size_t)b * K + r] = item;
     }
     __syncthreads();
-    // ---- metrics.  The terms are the reference's (metrics.py:136-147, 187-196: rel / log2(r + 2), 1 / log2(r + 2)); they are
-    //      computed one per thread and summed by a fixed-order block reduction in double (the serial loop of rounds 1-3 spent
-    //      ~250 double-precision log2 calls on ONE lane per user)
-    double gsum = 0.0;
-    long npos = 0;
-    for (int64_t k = hb; k < he; ++k) {      // (every thread: ~20 entries, no divergence)
-        const float v = a.held.values ? a.held.values[k] : 1.f;
-        gsum += (double)v;
-        npos += v > 0.f;
+    if (sh_tie) {
+        for (int p = tid; p < n_rank; p += 256) {
+            const int32_t id = cidx[p];
+            const uint32_t r = topk_rank_of(ckey, cidx, r4n, ckey[p], id);
+            if (r < (uint32_t)K) sidx[r] = id;
+        }
+        __syncthreads();
     }
-    auto block_sum_f64 = [&](double v) -> double {
+    if (a.dbg_stop == 4) { if (sidx[tid] == -5) a.ndcg[b] = 0.0; return; }
+    // ---- 5. relevance of every ranked item: value of the held-out row at that item (0 if absent)
+    for (int r = tid; r < K; r += 256) {
+        const int item = sidx[r];
+        float v = 0.f;
+        if (held_in_lds) {
+            int lo = 0, hi = hn;          // binary search (column ids are sorted within a row)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (hidx[mid] < item) lo = mid + 1; else hi = mid;
+            }
+            if (lo < hn && hidx[lo] == item) v = hval[lo];
+        } else {
+            int64_t lo = hb, hi = he;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                const int cc = a.held.indices[mid];
+                if (cc < item) lo = mid + 1; else hi = mid;
+            }
+            if (lo < he && a.held.indices[lo] == item) v = a.held.values ? a.held.values[lo] : 1.f;
+        }
+        relb[r] = __float_as_uint(v);
+        if (a.topk) a.topk[(size_t)b * K + r] = item;
+    }
+    if (a.dbg_stop == 5) return;
+    // ---- 6. metrics.  The terms are the reference's (metrics.py:136-147, 187-196: rel / log2(r + 2), 1 / log2(r + 2)), one rank per
+    //      thread and pass, summed in double by a fixed-order block reduction (64-lane butterfly, then the four waves pairwise).
+    //      Sum and positive count of the held-out row: block sums over its parked entries (float values are small integers or
+    //      ratings: exact in double in any order).
+    double gs = 0.0, np = 0.0;
+    if (held_in_lds) {
+        gs = (double)hv0 + (double)hv1;
+        np = (hv0 > 0.f ? 1.0 : 0.0) + (hv1 > 0.f ? 1.0 : 0.0);
+    } else {
+        for (int64_t k = hb + tid; k < he; k += 256) {
+            const float v = a.held.values ? a.held.values[k] : 1.f;
+            gs += (double)v;
+            np += v > 0.f ? 1.0 : 0.0;
+        }
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) dred[tid >> 6] = v;
-        __syncthreads();
-        return (dred[0] + dred[1]) + (dred[2] + dred[3]);
-    };
-    double l2r[RTX_TOPK_MAX / 256];             // log2(r + 2) of this thread's ranks: once, not once per cut-off
-#pragma unroll
-    for (int m = 0; m < RTX_TOPK_MAX / 256; ++m) l2r[m] = log2((double)(tid + 256 * m + 2));
+    for (int o = 32; o > 0; o >>= 1) { gs += __shfl_xor(gs, o, 64); np += __shfl_xor(np, o, 64); }
+    if (lane == 0) { hred[wave] = gs; hred[4 + wave] = np; }
+    __syncthreads();    // (also: the relevances are complete)
+    const double gsum = (hred[0] + hred[1]) + (hred[2] + hred[3]);
+    const long npos = (long)((hred[4] + hred[5]) + (hred[6] + hred[7]));
     for (int q = 0; q < a.n_k; ++q) {
         const int kk = min(min(a.ks[q], a.n_items), K);
         const long nid = min((long)gsum, (long)min(a.ks[q], a.n_items));      // tp[:min(int(n), k)].sum()   (metrics.py:146)
@@ -1548,16 +1671,20 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
         for (int m = 0; m < RTX_TOPK_MAX / 256; ++m) {
             const int r = tid + 256 * m;
             const double l2 = l2r[m];
-            if (r < kk) { dcg += (double)rel[r] / l2; hits += rel[r] > 0.f ? 1.0 : 0.0; }
-            if (r < nid) idcg += 1.0 / l2;
+            if (r < kk) { const float rl = __uint_as_float(relb[r]); dcg += (double)rl / l2; hits += rl > 0.f ? 1.0 : 0.0; }
+            if (r < nid && r < K) idcg += 1.0 / l2;
         }
-        dcg = block_sum_f64(dcg);
-        idcg = block_sum_f64(idcg);
-        hits = block_sum_f64(hits);
-        if (tid == 0) {
-            if (a.ndcg) a.ndcg[(size_t)q * a.B + b] = dcg / idcg;
-            if (a.recall) a.recall[(size_t)q * a.B + b] = (double)(float)hits / (double)min((long)min(a.ks[q], a.n_items), npos);   // metrics.py:194-195
-        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { dcg += __shfl_xor(dcg, o, 64); idcg += __shfl_xor(idcg, o, 64); hits += __shfl_xor(hits, o, 64); }
+        if (lane == 0) { dred[q * 12 + wave] = dcg; dred[q * 12 + 4 + wave] = idcg; dred[q * 12 + 8 + wave] = hits; }
+    }
+    __syncthreads();
+    if (tid < a.n_k) {
+        const int q = tid;
+        const double* d = dred + q * 12;
+        const double dcg = (d[0] + d[1]) + (d[2] + d[3]), idcg = (d[4] + d[5]) + (d[6] + d[7]), hits = (d[8] + d[9]) + (d[10] + d[11]);
+        if (a.ndcg) a.ndcg[(size_t)q * a.B + b] = dcg / idcg;
+        if (a.recall) a.recall[(size_t)q * a.B + b] = (double)(float)hits / (double)min((long)min(a.ks[q], a.n_items), npos);   // metrics.py:194-195
     }
 }
 
@@ -1578,6 +1705,19 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
         a.ks[q] = ks[q];
     }
     a.ndcg = ndcg; a.recall = recall; a.topk = topk; a.B = B;
+    if (const char* dbg = getenv("RTX_TOPK_STOP")) a.dbg_stop = atoi(dbg);
+    {
+        static bool table_ready[64] = {};
+        int devid = 0;
+        RTX_HIP(hipGetDevice(&devid));
+        if (devid >= 0 && devid < 64 && !table_ready[devid]) {
+            std::vector<double> t(RTX_TOPK_MAX);
+            for (int r = 0; r < RTX_TOPK_MAX; ++r) t[r] = std::log2((double)(r + 2));
+            RTX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_topk_log2), t.data(), sizeof(double) * RTX_TOPK_MAX));
+            table_ready[devid] = true;
+        }
+        RTX_CHECK(devid >= 0 && devid < 64, RTX_EINVAL, "topk_metrics: device index %d", devid);
+    }
     if ((((uintptr_t)scores) & 15) == 0 && (ld & 3) == 0 && n_items <= 20 * 1024)
         hipLaunchKernelGGL(k_topk_metrics<20>, dim3(B), dim3(256), 0, stream, a);
     else

@@ -115,13 +115,16 @@ int rtx_gemm_f32_km_launch(const RtxGemm& g, int epilogue, hipStream_t stream);
 // ---- weight gradient in TN form, optionally fused with the Adam update (dw_adam.hip; bf16 operands) ------------------
 enum RtxDwEpilogue { RTX_DW_GRAD = 0, RTX_DW_ADAM = 1 };
 enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2, RTX_DW_128x128 = 3,
-                RTX_DW_128x128_W4 = 4 };   // round 5: 128 x 128 on FOUR waves (32 x 128 of dW per wave: 4 MFMAs per 5 fragment reads instead of
+                RTX_DW_128x128_W4 = 4,     // round 5: 128 x 128 on FOUR waves (32 x 128 of dW per wave: 4 MFMAs per 5 fragment reads instead of
                                            //   1 per 2): the long-K tile (a batch of thousands of rows: configs[3] on one GPU)
+                RTX_DW_32x256 = 5,         // round 6: 32 x 256 on eight waves, two stages (72 KB): a tile row of the optimizer state is 1 KB
+                RTX_DW_32x256_S3 = 6,      //   the same with three stages (108 KB: one workgroup per CU)
+                RTX_DW_32x256_K32 = 7 };   //   32-row K slices, four stages (72 KB): two workgroups per CU, three slices ahead
 struct RtxDw {
     const void* A;       // delta      bf16 [K_pad][lda]: k = batch row, m = output feature (contiguous)
     const void* B;       // activation bf16 [K_pad][ldb]: n = input feature (contiguous); column N_real holds ones
     long lda, ldb;
-    int m_tiles, n_tiles;   // M_pad / tile rows, N_pad / 128
+    int m_tiles, n_tiles;   // M_pad / rtx_dw_tile_rows(cfg), ceil(N_pad / rtx_dw_tile_cols(cfg))
     int k_slices;           // K_pad / 64 (>= 2)
     int M_real, N_real;
     float* gW;           // RTX_DW_GRAD: float32 [M_real][N_real] (nullable)
@@ -145,6 +148,7 @@ void rtx_gemm_dma_set_stamps(unsigned long long* dev);   // measurement hook: 32
 void rtx_dw_set_stamps(unsigned long long* dev);   // measurement hooks (dw_adam.hip g_dw_stamps / g_dw_skip): 8 entries per workgroup
 void rtx_dw_set_skip(int mask);
 int rtx_dw_tile_rows(int cfg);
+int rtx_dw_tile_cols(int cfg);
 int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream);
 #define RTX_DW_GROUP_MAX 6
 // the same for up to RTX_DW_GROUP_MAX matrices in ONE launch (equal k_slices, one epilogue)

@@ -141,25 +141,44 @@ def evaluate_device(model, test_loader, metric_list):
     validation function: ``model.train(..., valid_func=ValidFunc(evaluate_device))``.  Anything it cannot do on the
     device (other metrics, k > 1024, a host sampler) goes through :func:`evaluate`.
     """
-    from .engine import topk_metrics
+    from .engine import topk_metrics, RowBatch
     parsed = _device_plan(test_loader, metric_list)
     if parsed is None:
         return evaluate_host(model, test_loader, metric_list)
     ks = sorted({k for _, _, k in parsed})
     out = _PerUserResults(metric_list)
-    # (Round 6 measured two other forms of this loop, alternating in one process (code in the git history): the selection kernel of batch i on a second
-    # stream under the forward of batch i + 1, and on top of that the engine resolved once with two reused score buffers and one flat
-    # metrics buffer: +2-3 % at 500 users per batch in bf16, -3-4 % in float32 and at 2000 users.  The forward (~95 us per 500 users)
-    # and the selection kernel (41 us) contend for the same CUs, and the host is not the limit: the simple loop stays.)
-    per_batch = []
-    for rb in test_loader.iter_rows():
-        scores = model.predict(rb)[0]                    # HIP forward on the sparse rows, -inf at the train items
-        per_batch.append(topk_metrics(scores, rb.te, rb.rows, ks))
+    # The loop: `predict` on the resident sparse rows, the selection kernel behind it on the same stream.  Round 6, after the selection
+    # kernel went from 41 to 20 us per 500 users (the GPU is busy ~103 us per batch, profiles/r6_eval_timeline.txt): the host's share
+    # decides, so when `predict` is the framework's own (not a user's override, not a row-sharded optimizer mid-epoch) the engine is
+    # resolved ONCE for the loader, every batch's scores land in ONE reused buffer (the selection kernel of batch i precedes the forward
+    # of batch i + 1 in stream order) and the metrics in one flat [batch][cut-off][user] buffer: no allocation and no Python-side
+    # checks per batch.  (Measured and dropped earlier this round: the selection kernel on a second stream under the next forward --
+    # both contend for the same CUs: +2-3 % in bf16 at 500 users, -3-4 % in float32 and at 2000.)
+    batches = list(test_loader.iter_rows())
+    if not batches:
+        return out.finish()
+    n_k, bmax = len(ks), max(len(rb) for rb in batches)
+    fast = _predict_is_ours(model) and hasattr(model, "_predict_engine") and getattr(model, "_variant", None) in ("vae", "dae")
+    import os
+    if os.environ.get("RTX_EVAL_SIMPLE_LOOP"): fast = False
+    flat_n = torch.empty((len(batches), n_k * bmax), dtype=torch.float64, device="cuda")
+    flat_r = torch.empty_like(flat_n)
+    eng = model._predict_engine(bmax) if fast else None
+    scores_buf = torch.empty((bmax, eng.n_items), dtype=torch.float32, device="cuda") if fast else None
+    for i, rb in enumerate(batches):
+        nb = len(rb)
+        x_in = model.network._as_input(rb) if fast else None     # (exactly what predict() does with a batch of resident rows)
+        if fast and isinstance(x_in, RowBatch):
+            scores = eng.forward(x_in, training=False, remove_train=True, out=scores_buf, want_latent=False)[0]
+        else:
+            scores = model.predict(rb)[0]                # HIP forward on the sparse rows, -inf at the train items
+        o = (flat_n[i, :n_k * nb].view(n_k, nb), flat_r[i, :n_k * nb].view(n_k, nb))
+        topk_metrics(scores, rb.te, rb.rows, ks, out=o)
     # ONE device -> host copy for the whole loader (the per-batch .cpu() of round 3 was a host sync per 500 users)
-    if per_batch:
-        ndcg = torch.cat([n for n, _ in per_batch], dim=1).cpu().numpy()
-        recall = torch.cat([r for _, r in per_batch], dim=1).cpu().numpy()
-        out.add({m: (ndcg if name == "ndcg" else recall)[ks.index(k)] for m, name, k in parsed})
+    hn, hr = flat_n.cpu().numpy(), flat_r.cpu().numpy()
+    ndcg = np.concatenate([hn[i, :n_k * len(rb)].reshape(n_k, len(rb)) for i, rb in enumerate(batches)], axis=1)
+    recall = np.concatenate([hr[i, :n_k * len(rb)].reshape(n_k, len(rb)) for i, rb in enumerate(batches)], axis=1)
+    out.add({m: (ndcg if name == "ndcg" else recall)[ks.index(k)] for m, name, k in parsed})
     return out.finish()
 
 

@@ -427,7 +427,7 @@ static int run_dw_case(const char* name, int cfg, int epi, int M_real, int N_rea
     CK(hipMemcpy(sumsq, &hss, 4, hipMemcpyHostToDevice));
     RtxDw d = {};
     d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
-    d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+    d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = (Np + rtx_dw_tile_cols(cfg) - 1) / rtx_dw_tile_cols(cfg); d.k_slices = Kp / 64;
     d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
     const float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const int step = 3;
@@ -550,7 +550,7 @@ static void perf_dw(const char* name, int cfg, int epi, int M_real, int N_real, 
     CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
     RtxDw d = {};
     d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
-    d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+    d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = (Np + rtx_dw_tile_cols(cfg) - 1) / rtx_dw_tile_cols(cfg); d.k_slices = Kp / 64;
     d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
     d.adam.ld_sh = Np;
     d.adam.step_size = 1e-3f; d.adam.bc2_sqrt = 0.05f; d.adam.beta1 = 0.9f; d.adam.beta2 = 0.999f; d.adam.eps = 1e-8f;
@@ -610,7 +610,7 @@ static int run_dw_group_case(int cfg, int odd = 0)   // odd: one matrix with row
             RtxDw& q = d[s][k];
             q = RtxDw{};
             q.A = b[k].D; q.lda = b[k].Mp; q.B = b[k].X; q.ldb = b[k].Np;
-            q.m_tiles = b[k].Mp / rtx_dw_tile_rows(cfg); q.n_tiles = b[k].Np / 128; q.k_slices = Kp / 64;
+            q.m_tiles = b[k].Mp / rtx_dw_tile_rows(cfg); q.n_tiles = (b[k].Np + rtx_dw_tile_cols(cfg) - 1) / rtx_dw_tile_cols(cfg); q.k_slices = Kp / 64;
             q.M_real = M; q.N_real = N;
             q.adam.p = b[k].p[s]; q.adam.m = b[k].m[s]; q.adam.v = b[k].v[s]; q.adam.sh = b[k].sh[s]; q.adam.ld_sh = b[k].Np;
             q.adam.step_size = 1e-3f * (k + 1); q.adam.bc2_sqrt = 0.05f; q.adam.beta1 = 0.9f; q.adam.beta2 = 0.999f; q.adam.eps = 1e-8f;
@@ -699,7 +699,7 @@ static int run_f32_case(const char* name, int form, int M, int N, int K, int spl
 static int run_dw_cases()
 {
     int fails = 0;
-    for (int cfg = 0; cfg < 5; ++cfg) {   // 64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / 128x128 on four waves
+    for (int cfg = 0; cfg < 8; ++cfg) {   // (5, 6, 7: 32x256 on two / three stages, on four stages of 32-row slices)   64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / 128x128 on four waves
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
         fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
@@ -900,7 +900,7 @@ static int run_adam_approx_isolation(int cfg)
         CK(hipMemcpy(X, hX.data(), hX.size() * 2, hipMemcpyHostToDevice));
         RtxDw d = {};
         d.A = D; d.lda = Mp; d.B = X; d.ldb = Np;
-        d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = Np / 128; d.k_slices = Kp / 64;
+        d.m_tiles = Mp / rtx_dw_tile_rows(cfg); d.n_tiles = (Np + rtx_dw_tile_cols(cfg) - 1) / rtx_dw_tile_cols(cfg); d.k_slices = Kp / 64;
         d.M_real = M_real; d.N_real = N_real; d.gbias = gb;
         const float step_size = (float)(lr / (1.0 - pow((double)b1, step))), bc2 = (float)sqrt(1.0 - pow((double)b2, step));
         d.adam.p = p; d.adam.m = m; d.adam.v = v; d.adam.gkeep = gk; d.adam.sh = sh; d.adam.ld_sh = Np;
@@ -1093,7 +1093,7 @@ int main(int argc, char** argv)
         rtx_dw_set_skip(0);
         for (int shape = 0; shape < 2 && !base_only; ++shape) {
             const int M = shape ? 600 : 20108, N = shape ? 20108 : 600;
-            const int wgs = 8 * (((rtx_pad(M) / rtx_dw_tile_rows(cfg)) * (rtx_pad(N) / 128) + 7) / 8);
+            const int wgs = 8 * (((rtx_pad(M) / rtx_dw_tile_rows(cfg)) * ((rtx_pad(N) + rtx_dw_tile_cols(cfg) - 1) / rtx_dw_tile_cols(cfg)) + 7) / 8);
             unsigned long long* dst;
             CK(hipMalloc(&dst, (size_t)wgs * 64));
             CK(hipMemset(dst, 0, (size_t)wgs * 64));
@@ -1149,10 +1149,11 @@ int main(int argc, char** argv)
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "dwperf")) {   // the two n_items x 600 launches of the step, warm and cold
-        for (int rep = 0; rep < 3; ++rep) {
-            perf_dw("dW4+adam", 0, RTX_DW_ADAM, 20108, 600, 500, 3);
-            perf_dw("dW1+adam", 0, RTX_DW_ADAM, 600, 20108, 500, 3);
-        }
+        for (int rep = 0; rep < 3; ++rep)
+            for (int cfg : {0, 5, 7}) {   // 64 x 128; 32 x 256 on two / three stages (round 6)
+                perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
+                perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
+            }
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "dw")) {   // only the weight-gradient (+ Adam) kernels

@@ -620,6 +620,75 @@ def test_evaluate_device_equals_host_evaluate():
     assert set(mixed) == {"mrr@10", "ndcg@10"} and np.allclose(mixed["ndcg@10"], host_res["ndcg@10"], equal_nan=True)
 
 
+def test_topk_kernel_order_statistics_stress():
+    """Round 6: the selection kernel ranks by counting instead of sorting.  Against numpy's stable order (score descending, item id
+    ascending among equal scores -- the kernel's documented tie rule) on the cases the counting has to get right: heavy ties
+    (scores quantised to a few levels), rows that are entirely -inf, more than 1024 elements tied above the bound (the radix
+    fall-back), K from 1 to 1000 (1 .. 4 maxima per thread), widths that are not a multiple of 4, rows shorter than K, and
+    held-out rows longer than the 512 entries the kernel parks in LDS.  Metrics against rectorch's own formulas (metrics.py:136-147,
+    187-196) evaluated with that same order."""
+    from rectorch_amd.engine import CsrMatrix, topk_metrics
+    rng = np.random.RandomState(11)
+
+    def ref(scores, held, ks):
+        B, I = scores.shape
+        order = np.lexsort((np.broadcast_to(np.arange(I), (B, I)), -scores.astype(np.float64)), axis=1)   # primary: score desc, then id asc
+        nd, rc = np.empty((len(ks), B)), np.empty((len(ks), B))
+        for q, k in enumerate(ks):
+            kk = min(k, I)
+            for b in range(B):
+                relv = held[b, order[b, :kk]]
+                disc = 1.0 / np.log2(np.arange(2, kk + 2))
+                dcg = float((relv * disc).sum())
+                n = int(held[b].sum())
+                idcg = float(disc[:min(n, kk)].sum())
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    nd[q, b] = np.float64(dcg) / np.float64(idcg)
+                    rc[q, b] = np.float64(np.float32((relv > 0).sum())) / np.float64(min(kk, int((held[b] > 0).sum())))
+        return order, nd, rc
+
+    cases = []
+    for (B, I, levels, ks, held_n) in [(9, 20108, 7, [100, 50], 30), (5, 20108, 0, [1000, 300, 1], 700), (6, 4099, 3, [257, 10], 20),
+                                        (4, 90, 0, [100, 5], 10), (7, 20108, 2000, [512, 100], 5), (3, 1030, 1, [10], 3)]:
+        sc = rng.randn(B, I).astype(np.float32)
+        if levels:
+            sc = np.round(sc * levels / 3.0).astype(np.float32) * (3.0 / levels)     # `levels` distinct values per unit: ties everywhere
+        sc[0, :] = -np.inf                                                           # a fully masked row
+        if B > 2:
+            sc[1, rng.rand(I) < 0.3] = -np.inf
+            sc[2, :] = 0.25                                                          # every element tied: > 1024 candidates at the bound
+        held = np.zeros((B, I), np.float64)
+        for b in range(B):
+            n = held_n if b != B - 1 else 0                                          # the last user has an empty held-out row (nan metrics)
+            held[b, rng.choice(I, size=min(n, I), replace=False)] = 1.0
+        cases.append((sc, held, ks))
+    n_unamb = 0
+    for sc, held, ks in cases:
+        B, I = sc.shape
+        hm = CsrMatrix(csr_matrix(held))
+        rows = torch.arange(B, dtype=torch.int32, device="cuda")
+        ndcg, recall, topk = topk_metrics(dev(sc), hm, rows, ks, want_topk=True)
+        order, nd, rc = ref(sc, held, ks)
+        kmax = min(max(ks), I)
+        got = topk.cpu().numpy()
+        want = order[:, :kmax]
+        fin = np.take_along_axis(sc, want, 1) > -np.inf
+        # Which of the elements TIED AT THE K-TH PLACE make the list is arbitrary when the radix fall-back runs (as in the reference's
+        # argpartition): ids and metrics are asserted on the rows without such a tie, the scores of the ranked items on every row.
+        unamb = np.zeros(B, bool)
+        for b in range(B):
+            srt = np.sort(sc[b])[::-1]
+            unamb[b] = srt[kmax - 1] > -np.inf and (kmax >= I or (sc[b] >= srt[kmax - 1]).sum() == kmax)
+            assert np.array_equal(sc[b][got[b][fin[b]]], sc[b][want[b][fin[b]]]), (I, ks, b)
+            if unamb[b]:
+                assert np.array_equal(got[b][fin[b]], want[b][fin[b]]), (I, ks, b)
+        n_unamb += int(unamb.sum())
+        for q in range(len(ks)):
+            assert np.allclose(ndcg[q].cpu().numpy()[unamb], nd[q][unamb], rtol=1e-12, atol=0, equal_nan=True), (I, ks, q)
+            assert np.allclose(recall[q].cpu().numpy()[unamb], rc[q][unamb], rtol=1e-12, atol=0, equal_nan=True), (I, ks, q)
+    assert n_unamb >= 6      # (the cases above hold enough rows whose ranked list is unique)
+
+
 # ------------------------------------------------------------------------------------------------ EASE (SURVEY 8f-1)
 # Tolerance: the reference computes in float64 with LAPACK's LU inverse, the device in float64 with a Cholesky
 # inverse; both are backward stable on the SPD matrix X^T X + lam I (condition number <= (|X|_2^2 + lam) / lam), so

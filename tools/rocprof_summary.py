@@ -182,4 +182,7 @@ def diag(directory):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline, "mfma": mfma, "pmcjson": pmcjson, "diag": diag}[sys.argv[1]](sys.argv[2])
+    if sys.argv[1] == "timeline" and len(sys.argv) > 3:     # timeline DB ANCHOR [NTH] [COUNT]
+        timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 40, int(sys.argv[5]) if len(sys.argv) > 5 else 2)
+    else:
+        {"stats": stats, "pmc": pmc, "bygrid": bygrid, "timeline": timeline, "mfma": mfma, "pmcjson": pmcjson, "diag": diag}[sys.argv[1]](sys.argv[2])
