@@ -283,6 +283,15 @@ int rtx_sum_l2_norms(const float* const* tensors, const int64_t* sizes, int32_t 
  * 136-147, 187-196): per user the exact top-max(ks) of the score row, then nDCG@k and Recall@k for every cut-off
  * against that user's held-out CSR row (column ids sorted).  ndcg / recall: device double [n_k][batch] (nullable);
  * topk_idx: device int32 [batch][max(ks, kmax)] sorted by descending score (nullable).  ks_host is a HOST array. */
+/* evaluation.evaluate's whole loop (rectorch/evaluation.py:100-106) in ONE call: for every batch i, the users
+ * row_ids[batch_offsets[i] .. batch_offsets[i + 1]) (device int32; batch_offsets is a HOST array of n_batches + 1 entries) are scored
+ * in eval mode from their rows of `train`, their train items set to -inf (predict(remove_train=True)), and reduced to nDCG@k /
+ * Recall@k against their rows of `heldout`.  scores_scratch: device float32 [max batch][n_items], overwritten batch after batch.
+ * ndcg / recall: device double [n_k][total users] (nullable), user j of the loader in column j.  ks_host is a HOST array. */
+int rtx_engine_evaluate_topk(rtx_engine* e, const rtx_csr* train, const rtx_csr* heldout, const int32_t* row_ids,
+                             const int64_t* batch_offsets, int32_t n_batches, const int32_t* ks_host, int32_t n_k,
+                             float* scores_scratch, double* ndcg, double* recall, void* stream);
+
 int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_items, const rtx_csr* heldout,
                      const int32_t* row_ids, const int32_t* ks_host, int32_t n_k, double* ndcg, double* recall,
                      int32_t* topk_idx, int32_t kmax, void* stream);

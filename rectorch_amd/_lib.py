@@ -119,6 +119,7 @@ SIGNATURES = {
     "rtx_multinomial_loss": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, _P]),
     "rtx_sum_l2_norms": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "rtx_topk_metrics": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
+    "rtx_engine_evaluate_topk": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
     "rtx_ease_fit": (C.c_int, [_P, C.c_double, C.POINTER(_P), _P]),
     "rtx_ease_destroy": (C.c_int, [_P]),
     "rtx_ease_weights": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32)]),

@@ -850,7 +850,7 @@ __global__ void k_pad_convert(const float* src, int B, int n, T* dst, int ld, in
 extern "C" {
 
 const char* rtx_last_error(void) { return rtx_last_error_str(); }
-int32_t rtx_abi_version(void) { return 7; }   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step); 6: rtx_svae_set_option; 7: rtx_dp_cfg.comm_side / ops_side / shard_min_elems (bucket A's own communicator), rtx_engine_loss_mailbox / rtx_engine_wait_loss
+int32_t rtx_abi_version(void) { return 8; }   // 8: rtx_engine_evaluate_topk;   // 2: rtx_cfg.cond_dim, rtx_ease_*; 3: rtx_engine_set_option, step fuses Adam by default; 4: rtx_comm_*, rtx_engine_apply_adam_rows / shadow_region; 5: rtx_engine_dp_attach / train_step_dp (the engine schedules the data-parallel step); 6: rtx_svae_set_option; 7: rtx_dp_cfg.comm_side / ops_side / shard_min_elems (bucket A's own communicator), rtx_engine_loss_mailbox / rtx_engine_wait_loss
 
 // ---- CSR -------------------------------------------------------------------------------------------
 int rtx_csr_upload(const int64_t* indptr_host, const int32_t* indices_host, const float* values_host, int64_t n_rows,
@@ -2355,6 +2355,42 @@ int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_i
     for (int q = 0; q < n_k; ++q) km = std::max(km, (int)ks_host[q]);
     RtxCsrView v = {heldout->indptr, heldout->indices, heldout->values, row_ids};
     return rtx_launch_topk_metrics(scores, (long)ld, batch, n_items, v, ks_host, n_k, km, ndcg, recall, topk_idx, (hipStream_t)stream);
+}
+
+// The body of evaluation.evaluate's loop (rectorch/evaluation.py:100-106) for EVERY batch of a held-out loader in one call: the host
+// enqueues batch after batch without returning to Python in between (round 6: the selection kernel's 20 us left the host's ~100 us of
+// per-batch Python and ctypes work as the limit of evaluate_device).
+int rtx_engine_evaluate_topk(rtx_engine* e, const rtx_csr* train, const rtx_csr* heldout, const int32_t* row_ids, const int64_t* batch_offsets,
+                             int32_t n_batches, const int32_t* ks_host, int32_t n_k, float* scores_scratch, double* ndcg, double* recall,
+                             void* stream)
+{
+    RTX_TRY(check_ready(e, false));
+    RTX_CHECK(train && heldout && row_ids && batch_offsets && ks_host && scores_scratch, RTX_EINVAL, "evaluate_topk: NULL argument");
+    RTX_CHECK(n_batches >= 0 && n_k >= 1, RTX_EINVAL, "evaluate_topk: bad counts");
+    RTX_CHECK(heldout->n_cols == e->I, RTX_EINVAL, "evaluate_topk: held-out matrix has %d columns, the network scores %d items", heldout->n_cols, e->I);
+    hipStream_t st = (hipStream_t)stream;
+    RTX_TRY(ensure_shadows(e, st));
+    const int64_t total = batch_offsets[n_batches] - batch_offsets[0];
+    int km = 0;
+    for (int q = 0; q < n_k; ++q) km = std::max(km, (int)ks_host[q]);
+    for (int32_t i = 0; i < n_batches; ++i) {
+        const int64_t lo = batch_offsets[i], n = batch_offsets[i + 1] - lo;
+        RTX_CHECK(n >= 1 && n <= e->cfg.max_batch, RTX_EINVAL, "evaluate_topk: batch %d has %lld rows (max_batch = %d)", i, (long long)n, e->cfg.max_batch);
+        rtx_batch b = {};
+        b.csr = train; b.row_ids = row_ids + lo; b.batch = (int32_t)n;
+        RtxCsrView in = {}, tg = {};
+        RTX_TRY(resolve_batch(e, &b, &in, &tg, st, 0));
+        RTX_TRY(run_forward(e, &in, &in, (int)n, 0, nullptr, 0, 0, e->NL, scores_scratch, e->I, nullptr, nullptr, st));
+        {
+            TIMED("neg_inf");
+            RTX_TRY(rtx_launch_neg_inf(in, (int)n, scores_scratch, e->I, e->I, st));
+        }
+        RtxCsrView hv = {heldout->indptr, heldout->indices, heldout->values, row_ids + lo};
+        const int64_t col = lo - batch_offsets[0];
+        RTX_TRY(rtx_launch_topk_metrics(scores_scratch, (long)e->I, (int)n, e->I, hv, ks_host, n_k, km, ndcg ? ndcg + col : nullptr,
+                                        recall ? recall + col : nullptr, nullptr, st, (long)total));
+    }
+    return RTX_OK;
 }
 
 // ---- instrumentation -------------------------------------------------------------------------------

@@ -1315,6 +1315,7 @@ struct RtxTopkArgs {
     double* recall;   // [n_k][B]  (nullable)
     int32_t* topk;    // [B][K]    (nullable)
     int B;
+    long out_ld;      // doubles between two cut-offs' rows of ndcg / recall (>= B; B = one [n_k][B] block per call)
     int dbg_stop;     // measurement (env RTX_TOPK_STOP at launch): the kernel returns after stage dbg_stop (0 = runs to the end)
 };
 
@@ -1683,13 +1684,13 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
         const int q = tid;
         const double* d = dred + q * 12;
         const double dcg = (d[0] + d[1]) + (d[2] + d[3]), idcg = (d[4] + d[5]) + (d[6] + d[7]), hits = (d[8] + d[9]) + (d[10] + d[11]);
-        if (a.ndcg) a.ndcg[(size_t)q * a.B + b] = dcg / idcg;
-        if (a.recall) a.recall[(size_t)q * a.B + b] = (double)(float)hits / (double)min((long)min(a.ks[q], a.n_items), npos);   // metrics.py:194-195
+        if (a.ndcg) a.ndcg[(size_t)q * a.out_ld + b] = dcg / idcg;
+        if (a.recall) a.recall[(size_t)q * a.out_ld + b] = (double)(float)hits / (double)min((long)min(a.ks[q], a.n_items), npos);   // metrics.py:194-195
     }
 }
 
 int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, const RtxCsrView& held, const int* ks, int n_k,
-                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream)
+                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream, long out_ld)
 {
     if (B <= 0) return RTX_OK;
     RTX_CHECK(n_k >= 1 && n_k <= 16, RTX_EINVAL, "topk_metrics: 1..16 cut-offs supported, got %d", n_k);
@@ -1705,6 +1706,7 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
         a.ks[q] = ks[q];
     }
     a.ndcg = ndcg; a.recall = recall; a.topk = topk; a.B = B;
+    a.out_ld = out_ld > 0 ? out_ld : B;
     if (const char* dbg = getenv("RTX_TOPK_STOP")) a.dbg_stop = atoi(dbg);
     {
         static bool table_ready[64] = {};

@@ -227,6 +227,24 @@ class Engine:
                                        _ptr(logits), _ptr(mu), _ptr(logvar), stream_ptr()))
         return logits, mu, logvar
 
+    def evaluate_topk(self, tr, te, rows, offsets, ks, scratch=None):
+        """``rtx_engine_evaluate_topk``: every batch ``rows[offsets[i]:offsets[i + 1]]`` (device int32 row numbers into the resident
+        :class:`CsrMatrix` pair ``tr`` / ``te``) scored in eval mode with the train items at -inf and reduced to nDCG@k / Recall@k, all
+        enqueued by ONE call.  Returns float64 device tensors ``(ndcg, recall)`` of shape ``[len(ks), len(rows)]``."""
+        offs = (C.c_int64 * len(offsets))(*[int(o) for o in offsets])
+        ks = [int(k) for k in ks]
+        arr = (C.c_int32 * len(ks))(*ks)
+        total = int(offsets[-1] - offsets[0])
+        bmax = max(int(b) - int(a) for a, b in zip(offsets[:-1], offsets[1:])) if len(offsets) > 1 else 0
+        dev = rows.device
+        if scratch is None or scratch.shape[0] < bmax:
+            scratch = torch.empty((max(bmax, 1), self.n_items), dtype=torch.float32, device=dev)
+        ndcg = torch.empty((len(ks), total), dtype=torch.float64, device=dev)
+        recall = torch.empty_like(ndcg)
+        check(lib().rtx_engine_evaluate_topk(self.handle, tr.handle, te.handle, _ptr(rows), offs, len(offsets) - 1, arr, len(ks),
+                                             _ptr(scratch), _ptr(ndcg), _ptr(recall), stream_ptr()))
+        return ndcg, recall
+
     def encode(self, x, training=False, seed=0, offset=0, mask=None):
         keep = []
         b = make_batch(x, keep=keep, n_items=self.n_items, n_in=self.n_in)

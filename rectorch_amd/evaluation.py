@@ -147,37 +147,39 @@ def evaluate_device(model, test_loader, metric_list):
         return evaluate_host(model, test_loader, metric_list)
     ks = sorted({k for _, _, k in parsed})
     out = _PerUserResults(metric_list)
-    # The loop: `predict` on the resident sparse rows, the selection kernel behind it on the same stream.  Round 6, after the selection
-    # kernel went from 41 to 20 us per 500 users (the GPU is busy ~103 us per batch, profiles/r6_eval_timeline.txt): the host's share
-    # decides, so when `predict` is the framework's own (not a user's override, not a row-sharded optimizer mid-epoch) the engine is
-    # resolved ONCE for the loader, every batch's scores land in ONE reused buffer (the selection kernel of batch i precedes the forward
-    # of batch i + 1 in stream order) and the metrics in one flat [batch][cut-off][user] buffer: no allocation and no Python-side
-    # checks per batch.  (Measured and dropped earlier this round: the selection kernel on a second stream under the next forward --
-    # both contend for the same CUs: +2-3 % in bf16 at 500 users, -3-4 % in float32 and at 2000.)
+    # Round 6, after the selection kernel went from 41 to 20 us per 500 users: the GPU is busy ~103 us per batch
+    # (profiles/r6_eval_timeline.txt) and the host needed as long to get through one iteration of a Python loop (predict -> ctypes ->
+    # eight launches, the selection kernel's call, two allocations).  When `predict` is the framework's own (a user's override must be
+    # what scores, as in the reference) the WHOLE loop is one C call -- rtx_engine_evaluate_topk enqueues forward, -inf scatter and
+    # selection kernel batch after batch into one scores buffer and one [cut-off][user] metrics buffer -- and ONE device -> host copy
+    # follows.  (Measured and dropped earlier this round: the selection kernel on a second stream under the next forward -- both
+    # contend for the same CUs; and the Python loop with reused buffers: +-1 %.)
     batches = list(test_loader.iter_rows())
     if not batches:
         return out.finish()
-    n_k, bmax = len(ks), max(len(rb) for rb in batches)
-    fast = _predict_is_ours(model) and hasattr(model, "_predict_engine") and getattr(model, "_variant", None) in ("vae", "dae")
+    fast = (_predict_is_ours(model) and hasattr(model, "_predict_engine") and getattr(model, "_variant", None) in ("vae", "dae")
+            and all(isinstance(model.network._as_input(rb), RowBatch) and rb.tr is batches[0].tr and rb.te is batches[0].te for rb in batches))
     import os
-    if os.environ.get("RTX_EVAL_SIMPLE_LOOP"): fast = False
-    flat_n = torch.empty((len(batches), n_k * bmax), dtype=torch.float64, device="cuda")
-    flat_r = torch.empty_like(flat_n)
-    eng = model._predict_engine(bmax) if fast else None
-    scores_buf = torch.empty((bmax, eng.n_items), dtype=torch.float32, device="cuda") if fast else None
-    for i, rb in enumerate(batches):
-        nb = len(rb)
-        x_in = model.network._as_input(rb) if fast else None     # (exactly what predict() does with a batch of resident rows)
-        if fast and isinstance(x_in, RowBatch):
-            scores = eng.forward(x_in, training=False, remove_train=True, out=scores_buf, want_latent=False)[0]
+    if os.environ.get("RTX_EVAL_SIMPLE_LOOP"): fast = False          # (measurement: the per-batch Python loop)
+    if fast:
+        eng = model._predict_engine(max(len(rb) for rb in batches))
+        offsets = np.concatenate([[0], np.cumsum([len(rb) for rb in batches])])
+        base, off0 = batches[0].rows._base, batches[0].rows.storage_offset()
+        if (base is not None and base.dim() == 1 and base.is_contiguous()
+                and all(rb.rows._base is base and rb.rows.storage_offset() == off0 + int(o) for rb, o in zip(batches, offsets))):
+            rows = base[off0:off0 + int(offsets[-1])]        # the sampler's batches are consecutive slices of ONE row-number tensor
         else:
+            rows = torch.cat([rb.rows for rb in batches])
+        dn, dr = eng.evaluate_topk(batches[0].tr, batches[0].te, rows, offsets, ks)
+        ndcg, recall = dn.cpu().numpy(), dr.cpu().numpy()
+    else:
+        per_batch = []
+        for rb in batches:
             scores = model.predict(rb)[0]                # HIP forward on the sparse rows, -inf at the train items
-        o = (flat_n[i, :n_k * nb].view(n_k, nb), flat_r[i, :n_k * nb].view(n_k, nb))
-        topk_metrics(scores, rb.te, rb.rows, ks, out=o)
-    # ONE device -> host copy for the whole loader (the per-batch .cpu() of round 3 was a host sync per 500 users)
-    hn, hr = flat_n.cpu().numpy(), flat_r.cpu().numpy()
-    ndcg = np.concatenate([hn[i, :n_k * len(rb)].reshape(n_k, len(rb)) for i, rb in enumerate(batches)], axis=1)
-    recall = np.concatenate([hr[i, :n_k * len(rb)].reshape(n_k, len(rb)) for i, rb in enumerate(batches)], axis=1)
+            per_batch.append(topk_metrics(scores, rb.te, rb.rows, ks))
+        # ONE device -> host copy for the whole loader (the per-batch .cpu() of round 3 was a host sync per 500 users)
+        ndcg = torch.cat([n for n, _ in per_batch], dim=1).cpu().numpy()
+        recall = torch.cat([r for _, r in per_batch], dim=1).cpu().numpy()
     out.add({m: (ndcg if name == "ndcg" else recall)[ks.index(k)] for m, name, k in parsed})
     return out.finish()
 

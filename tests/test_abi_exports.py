@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, "declared in include/*.h but not exported: %s" % missing
     # the ctypes signature table covers exactly the declared symbols
     assert set(_lib.SIGNATURES) == syms
-    assert _lib.lib().rtx_abi_version() == 7
+    assert _lib.lib().rtx_abi_version() == 8
 
 
 def test_struct_layouts_match_the_header():
