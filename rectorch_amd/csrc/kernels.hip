@@ -1395,20 +1395,19 @@ __device__ double g_topk_log2[RTX_TOPK_MAX];
 #define RTX_TOPK_HELD_CAP 512      // held-out entries of a row parked in LDS (longer rows: the global-memory look-up of rounds 1-5)
 
 // rank (0 = first) of element (k, id) among the n (key, id) pairs in LDS, ordered by key descending, id ascending among equal keys;
-// n4 = ceil(n / 4): the arrays are padded to a multiple of 4 with key 0 (below every real key)
+// n4 = ceil(n / 4): the arrays are padded to a multiple of 4 with (key 0, id INT_MAX): below every real element
 __device__ __forceinline__ uint32_t topk_rank_of(const uint32_t* __restrict__ keys, const int32_t* __restrict__ ids, int n4, uint32_t k, int32_t id)
 {
-    uint32_t gt = 0, eq = 0;
+    uint32_t r0 = 0, r1 = 0;
     const uint4* k4 = (const uint4*)keys;
+    const int4* i4 = (const int4*)ids;
     for (int i = 0; i < n4; ++i) {
         const uint4 q = k4[i];
-        gt += (q.x > k) + (q.y > k) + (q.z > k) + (q.w > k);
-        eq += (q.x == k) + (q.y == k) + (q.z == k) + (q.w == k);
+        const int4 d = i4[i];
+        r0 += (q.x > k) + ((q.x == k) & (d.x < id)) + (q.y > k) + ((q.y == k) & (d.y < id));
+        r1 += (q.z > k) + ((q.z == k) & (d.z < id)) + (q.w > k) + ((q.w == k) & (d.w < id));
     }
-    if (eq > 1) {   // ties (rare: masked entries, rows of equal scores): the smaller index first
-        for (int i = 0; i < n4 * 4; ++i) gt += (keys[i] == k && ids[i] < id);
-    }
-    return gt;
+    return r0 + r1;
 }
 
 // number of keys greater than k among the n4 * 4 keys in LDS (two instructions per key: a compare and an add-with-carry)

@@ -9,7 +9,11 @@ sys.path.insert(0, ROOT)
 from rectorch_amd.engine import CsrMatrix, topk_metrics
 B, I = int(sys.argv[1]) if len(sys.argv) > 1 else 500, 20108
 rng = np.random.RandomState(0)
+torch.manual_seed(0)
 sc = torch.randn(B, I, device="cuda")
+if len(sys.argv) > 2 and sys.argv[2] == "ties":      # two equal scores among every row's top ten: the exact-rank pass runs in every workgroup
+    top = sc.topk(10, dim=1).indices
+    sc.scatter_(1, top[:, 3:4], sc.gather(1, top[:, 2:3]))
 held = np.zeros((B, I)); 
 for b in range(B): held[b, rng.choice(I, 20, replace=False)] = 1
 hm = CsrMatrix(csr_matrix(held))
