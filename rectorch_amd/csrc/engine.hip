@@ -2381,14 +2381,11 @@ int rtx_engine_evaluate_topk(rtx_engine* e, const rtx_csr* train, const rtx_csr*
         RtxCsrView in = {}, tg = {};
         RTX_TRY(resolve_batch(e, &b, &in, &tg, st, 0));
         RTX_TRY(run_forward(e, &in, &in, (int)n, 0, nullptr, 0, 0, e->NL, scores_scratch, e->I, nullptr, nullptr, st));
-        {
-            TIMED("neg_inf");
-            RTX_TRY(rtx_launch_neg_inf(in, (int)n, scores_scratch, e->I, e->I, st));
-        }
+        // (the train items' -inf: inside the selection kernel, which takes the train rows as an exclusion list)
         RtxCsrView hv = {heldout->indptr, heldout->indices, heldout->values, row_ids + lo};
         const int64_t col = lo - batch_offsets[0];
         RTX_TRY(rtx_launch_topk_metrics(scores_scratch, (long)e->I, (int)n, e->I, hv, ks_host, n_k, km, ndcg ? ndcg + col : nullptr,
-                                        recall ? recall + col : nullptr, nullptr, st, (long)total));
+                                        recall ? recall + col : nullptr, nullptr, st, (long)total, &in));
     }
     return RTX_OK;
 }

@@ -1315,6 +1315,8 @@ struct RtxTopkArgs {
     double* recall;   // [n_k][B]  (nullable)
     int32_t* topk;    // [B][K]    (nullable)
     int B;
+    RtxCsrView excl;  // has_excl: the users' rows of the TRAIN matrix -- their stored items (< n_items) rank as -inf without the
+    int has_excl;     //   scores being touched (predict(remove_train=True) folded into the selection: rtx_engine_evaluate_topk)
     long out_ld;      // doubles between two cut-offs' rows of ndcg / recall (>= B; B = one [n_k][B] block per call)
     int dbg_stop;     // measurement (env RTX_TOPK_STOP at launch): the kernel returns after stage dbg_stop (0 = runs to the end)
 };
@@ -1438,6 +1440,7 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
     __shared__ double hred[8];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t sh_prefix, sh_mask, sh_need, sh_cnt_gt, sh_cnt_eq, sh_L, sh_tie;
+    __shared__ uint32_t excl_bm[NV > 0 ? NV * 32 : 1];      // one bit per item of the row: stored in the user's train row
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = a.scores + (size_t)b * a.ld;
     const int K = a.K;
@@ -1469,6 +1472,39 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
 #pragma unroll
         for (int q = 0; q < NV; ++q) kv[q] = make_uint4(score_key(rv[q].x), score_key(rv[q].y), score_key(rv[q].z), score_key(rv[q].w));
     }
+    // the user's train items rank as -inf (reference models.py:470-471, 952-953: recon_x[x.nonzero()] = -inf): a bitmap of the row in
+    // LDS, set from the train row's stored entries, read back four bits per group of neighbours -- instead of a scatter kernel of its
+    // own over the score matrix (5 us per batch of 500)
+    const bool use_excl = NV > 0 && a.has_excl;
+    if constexpr (NV > 0) {
+        if (use_excl) {
+            for (int i = tid; i < NV * 32; i += 256) excl_bm[i] = 0u;
+            __syncthreads();
+            const int64_t ue = csr_row(a.excl, b);
+            for (int64_t k = a.excl.indptr[ue] + tid; k < a.excl.indptr[ue + 1]; k += 256) {
+                const float val = a.excl.values ? a.excl.values[k] : 1.f;
+                const int i = a.excl.indices[k];
+                if (val != 0.f && i < a.n_items) atomicOr(&excl_bm[i >> 5], 1u << (i & 31));
+            }
+            __syncthreads();
+            const uint32_t NEG = score_key(-INFINITY);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int j = tid + q * 256;          // items 4 j .. 4 j + 3: bits (4 j) & 31 .. of word j >> 3
+                const uint32_t nib = (excl_bm[j >> 3] >> ((j & 7) * 4)) & 15u;
+                if (nib) {
+                    if (nib & 1u) kv[q].x = NEG;
+                    if (nib & 2u) kv[q].y = NEG;
+                    if (nib & 4u) kv[q].z = NEG;
+                    if (nib & 8u) kv[q].w = NEG;
+                }
+            }
+        }
+    }
+    auto tail_key = [&](int i) __attribute__((always_inline)) -> uint32_t {     // (NV > 0: the < 4 elements behind the last whole group)
+        if (use_excl && ((excl_bm[i >> 5] >> (i & 31)) & 1u)) return score_key(-INFINITY);
+        return score_key(row[i]);
+    };
     auto scan = [&](auto&& f4, auto&& f1) __attribute__((always_inline)) {
         if constexpr (NV > 0) {
 #pragma unroll
@@ -1476,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
                 const int j = tid + q * 256;
                 if (j < n4) f4(kv[q], j * 4);
             }
-            for (int i = n4 * 4 + tid; i < a.n_items; i += 256) f1(score_key(row[i]), i);
+            for (int i = n4 * 4 + tid; i < a.n_items; i += 256) f1(tail_key(i), i);
         } else {
             topk_scan_row(row, a.n_items, tid, f1);
         }
@@ -1689,7 +1725,7 @@ __global__ __launch_bounds__(256) void k_topk_metrics(const RtxTopkArgs a)
 }
 
 int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, const RtxCsrView& held, const int* ks, int n_k,
-                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream, long out_ld)
+                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream, long out_ld, const RtxCsrView* excl)
 {
     if (B <= 0) return RTX_OK;
     RTX_CHECK(n_k >= 1 && n_k <= 16, RTX_EINVAL, "topk_metrics: 1..16 cut-offs supported, got %d", n_k);
@@ -1706,6 +1742,11 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
     }
     a.ndcg = ndcg; a.recall = recall; a.topk = topk; a.B = B;
     a.out_ld = out_ld > 0 ? out_ld : B;
+    const bool burst = (((uintptr_t)scores) & 15) == 0 && (ld & 3) == 0 && n_items <= 20 * 1024;
+    if (excl) {
+        if (burst) { a.excl = *excl; a.has_excl = 1; }
+        else RTX_TRY(rtx_launch_neg_inf(*excl, B, (float*)scores, ld, n_items, stream));   // (the streamed form of the kernel: the scatter kernel first)
+    }
     if (const char* dbg = getenv("RTX_TOPK_STOP")) a.dbg_stop = atoi(dbg);
     {
         static bool table_ready[64] = {};
@@ -1719,7 +1760,7 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
         }
         RTX_CHECK(devid >= 0 && devid < 64, RTX_EINVAL, "topk_metrics: device index %d", devid);
     }
-    if ((((uintptr_t)scores) & 15) == 0 && (ld & 3) == 0 && n_items <= 20 * 1024)
+    if (burst)
         hipLaunchKernelGGL(k_topk_metrics<20>, dim3(B), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(k_topk_metrics<0>, dim3(B), dim3(256), 0, stream, a);

@@ -265,4 +265,4 @@ int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, 
 
 // evaluate() on the device: exact top-kmax per score row + nDCG@k / Recall@k for each cut-off in ks (host array)
 int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, const RtxCsrView& held, const int* ks, int n_k,
-                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream, long out_ld = 0);
+                            int kmax, double* ndcg, double* recall, int32_t* topk, hipStream_t stream, long out_ld = 0, const RtxCsrView* excl = nullptr);
