@@ -96,7 +96,7 @@ def evaluate(model, test_loader, metric_list):
 
     Same signature, same values -- and since round 5 the same SPEED as :func:`evaluate_device` wherever that applies: a
     device-resident :class:`DataSampler` with held-out rows and ``ndcg@k`` / ``recall@k`` metrics (k <= 1024) are scored by the
-    top-k kernel on the GPU (3.6 M users/s against 8 K through the host loop), so ``model.train(...)``'s default
+    top-k kernel on the GPU (4.3 M users/s against 8 K through the host loop), so ``model.train(...)``'s default
     ``valid_func=ValidFunc(evaluate)`` no longer spends its time copying score matrices.  Everything else -- other metrics, host
     samplers, models without the device path, ``model.device_metrics = False`` -- takes the reference's loop
     (:func:`evaluate_host`); the two agree to 1e-12 (``test_evaluate_device_equals_host_evaluate``).  A subclass that overrides
