@@ -335,6 +335,12 @@ int rtx_svae_destroy(rtx_svae* s);
  * weight gradients) takes its operands rounded to bf16 and accumulates in float32 on the bf16 MFMA -- the dtype BASELINE.json
  * configs[4] names; the GRU recurrences, the losses, the master weights and Adam stay float32.  Default: float32 products (the
  * reference's arithmetic, ~1e-6 parity). */
+/* ABI 8 -- THIS step's loss without draining the stream (rtx_engine_loss_mailbox / rtx_engine_wait_loss for the sequence model):
+ * once enabled, every rtx_svae_train_step / rtx_svae_train_pack also stores its loss into coherent host memory as soon as it is
+ * final -- before the backward recurrence -- and rtx_svae_wait_loss returns the loss of the LAST step enqueued (steps are waited
+ * for in order).  Reference: `return loss.item()` at the end of train_batch (rectorch/models.py:835). */
+int rtx_svae_loss_mailbox(rtx_svae* s, int32_t enable);
+int rtx_svae_wait_loss(rtx_svae* s, float* loss_host, double timeout_s);
 int rtx_svae_set_option(rtx_svae* s, const char* key, int32_t value);
 int32_t rtx_svae_n_tensors(const rtx_svae* s);
 int rtx_svae_tensor_shape(const rtx_svae* s, int32_t t, int32_t* rows, int32_t* cols);

@@ -129,6 +129,8 @@ SIGNATURES = {
     "rtx_svae_create": (C.c_int, [_P, C.POINTER(_P)]),
     "rtx_svae_destroy": (C.c_int, [_P]),
     "rtx_svae_set_option": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "rtx_svae_loss_mailbox": (C.c_int, [_P, C.c_int32]),
+    "rtx_svae_wait_loss": (C.c_int, [_P, C.POINTER(C.c_float), C.c_double]),
     "rtx_svae_n_tensors": (C.c_int32, [_P]),
     "rtx_svae_tensor_shape": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtx_svae_bind": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -1292,8 +1292,8 @@ int rtx_launch_sumsq(const float* const* params_host, const long* sizes, int n, 
 
 // ------------------------------------------------------------------------------------------------
 // Device-side ranking metrics for evaluate() (reference rectorch/metrics.py:136-147, 187-196):
-// per user, exact top-K of the score row by 4-pass radix select on order-preserving keys, bitonic sort of the
-// K survivors in LDS, then nDCG@k / Recall@k for every requested k <= K against the held-out CSR row.  Only
+// per user, exact top-K of the score row on order-preserving keys (a lower bound from per-thread maxima, the few hundred elements above
+// it ranked by counting; a radix select only for rows of > 1024 ties), then nDCG@k / Recall@k for every requested k <= K against the held-out CSR row.  Only
 // [n_k][B] doubles leave the GPU instead of the [B, n_items] score matrix (40 MB per 500 users at ml-20m).
 // ------------------------------------------------------------------------------------------------
 #define RTX_TOPK_MAX 1024
@@ -1321,32 +1321,13 @@ struct RtxTopkArgs {
     int dbg_stop;     // measurement (env RTX_TOPK_STOP at launch): the kernel returns after stage dbg_stop (0 = runs to the end)
 };
 
-// bitonic sort of n (a power of two <= RTX_TOPK_MAX) (key, index) pairs in LDS: key descending, index ascending among equal keys
-__device__ __forceinline__ void topk_sort(uint32_t* ckey, int32_t* cidx, int n, int tid)
-{
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < n / 2; i += 256) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const uint32_t k0 = ckey[lo], k1 = ckey[hi];
-                const int32_t i0 = cidx[lo], i1 = cidx[hi];
-                const bool first_before = (k0 > k1) || (k0 == k1 && i0 < i1);   // lo should precede hi in descending order
-                if (first_before != desc) { ckey[lo] = k1; ckey[hi] = k0; cidx[lo] = i1; cidx[hi] = i0; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // Exact top-K of a score row + the ranking metrics.  Round 4: the selection no longer histograms the row.  The 4-pass radix
 // select of rounds 1-3 put 20 108 LDS atomics per pass on one or two bins (the scores of a row share sign and exponent bits, so
 // the first digits are the same for nearly all of them): 285 us per 500 users, half of evaluate_device (profiles/r4_eval_kernel_stats.txt).
 //   1. every thread keeps the c = ceil(K / 256) largest keys of its 79 elements (registers, no atomics);
 //   2. the K-th largest of these 256 c keys -- all distinct elements -- is a LOWER BOUND L of the K-th largest score of the row
-//      (bitonic sort of <= 1024 keys in LDS);
-//   3. the elements >= L (a few hundred) are collected and sorted; the first K are the answer.
+//      (rounds 4-5: a bitonic sort of <= 1024 keys in LDS; round 6: counting, see k_topk_metrics);
+//   3. the elements >= L (a few hundred) are collected and ranked; the first K are the answer.
 // More than RTX_TOPK_MAX elements >= L (a row of ties): the radix select below, unchanged, takes over.
 // f(key, index) for every element of a score row.  16-byte loads, eight of them in flight per thread, wherever the row is 16-byte
 // aligned (round 5: the 4-byte loads of rounds 1-4 walked the 80-KB row in 79 dependent round trips per thread -- with two

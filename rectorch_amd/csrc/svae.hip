@@ -25,7 +25,9 @@
 
 #include <math.h>
 #include <string.h>
+#include <sched.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #define SV_MAX_LAYERS RTX_MAX_LAYERS
@@ -67,6 +69,10 @@ struct rtx_svae {
     int gru_nc = 0, gru_rp = 0;      //      its row chunks and rows per chunk
     size_t part_elems = 0;
     std::vector<void*> allocs;
+    // rtx_svae_loss_mailbox: {loss bits, ticket} in coherent host memory, stored by k_sv_final_loss -- train_batch returns THIS step's
+    // loss (reference models.py:835) as soon as the forward half of the step has run, without draining the stream behind it
+    uint32_t* loss_mailbox = nullptr;
+    uint32_t loss_ticket = 0;
 };
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_sv_loss(const float* logits, int T, int
 
 __global__ __launch_bounds__(256) void k_sv_final_loss(const float* row_loss, const float* kl_rows, int T, float inv_d, float beta_over_T,
                                                        const float* __restrict__ nll_scale, const float* __restrict__ kl_scale, float* loss_out,
-                                                       float* loss_accum)
+                                                       float* loss_accum, uint32_t* mailbox, uint32_t seq)
 {
     __shared__ float red[4];
     float a = 0.f, b = 0.f;
@@ -1184,6 +1190,10 @@ __global__ __launch_bounds__(256) void k_sv_final_loss(const float* row_loss, co
         const float l = a * inv_d + beta_over_T * b;
         if (loss_out) loss_out[0] = l;
         if (loss_accum) loss_accum[0] += l;
+        if (mailbox) {   // (system scope: the host spins on the ticket -- rtx_svae_wait_loss)
+            __hip_atomic_store(mailbox, __float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1447,7 +1457,49 @@ int rtx_svae_destroy(rtx_svae* s)
     if (s->ev_fork2) (void)hipEventDestroy(s->ev_fork2);
     if (s->ev_join2) (void)hipEventDestroy(s->ev_join2);
     for (void* p : s->allocs) (void)hipFree(p);
+    if (s->loss_mailbox) { (void)hipDeviceSynchronize(); (void)hipHostFree(s->loss_mailbox); }
     delete s;
+    return RTX_OK;
+}
+
+// The step's loss without draining the stream (ABI 8; the engine's rtx_engine_loss_mailbox / rtx_engine_wait_loss for the sequence model):
+// `SVAE.train_batch` ends in `return loss.item()` (reference models.py:835), which made the host wait for the WHOLE step -- the loss is
+// final before the backward recurrence starts -- and the GPU then idle while the host prepared the next user (60 us of 843 per user).
+int rtx_svae_loss_mailbox(rtx_svae* s, int32_t enable)
+{
+    RTX_CHECK(s, RTX_EINVAL, "svae is NULL");
+    if (enable && !s->loss_mailbox) {
+        void* p = nullptr;
+        RTX_HIP(hipHostMalloc(&p, 64, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(p, 0, 64);
+        s->loss_mailbox = (uint32_t*)p;
+        s->loss_ticket = 0;
+    } else if (!enable && s->loss_mailbox) {
+        RTX_HIP(hipDeviceSynchronize());
+        (void)hipHostFree(s->loss_mailbox);
+        s->loss_mailbox = nullptr;
+    }
+    return RTX_OK;
+}
+
+int rtx_svae_wait_loss(rtx_svae* s, float* loss_host, double timeout_s)
+{
+    RTX_CHECK(s && loss_host, RTX_EINVAL, "svae_wait_loss: NULL argument");
+    RTX_CHECK(s->loss_mailbox && s->loss_ticket != 0, RTX_ESTATE, "svae_wait_loss: no training step has reported to the mailbox (rtx_svae_loss_mailbox(s, 1) first)");
+    volatile uint32_t* mb = s->loss_mailbox;
+    const uint32_t want = s->loss_ticket;       // the LAST step enqueued: steps are waited for in order
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (__atomic_load_n(&mb[1], __ATOMIC_ACQUIRE) == want) break;
+        if ((spin & 0x3ff) == 0x3ff) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            RTX_CHECK(el < (timeout_s > 0 ? timeout_s : 60.0), RTX_EHIP, "svae_wait_loss: the step did not report its loss within %.1f s (ticket %u of %u)", el,
+                      (unsigned)mb[1], (unsigned)want);
+            if (el > 0.002) sched_yield();
+        }
+    }
+    const uint32_t bits = __atomic_load_n(&mb[0], __ATOMIC_RELAXED);
+    memcpy(loss_host, &bits, 4);
     return RTX_OK;
 }
 
@@ -1558,7 +1610,7 @@ static int sv_train(rtx_svae* s, const int32_t* items, int T, const int32_t* seq
     RTX_HIP(hipMemsetAsync(s->grads[sv_tail(s, SV_T_EMB)], 0, sizeof(float) * (size_t)I * E, s->side));
     RTX_HIP(hipEventRecord(s->ev_join, s->side));
     hipLaunchKernelGGL(k_sv_final_loss, dim3(1), dim3(256), 0, st, s->row_loss, s->kl_rows, T, inv_d, beta_over_T, nll_scale, kl_scale, loss_out,
-                       loss_accum);
+                       loss_accum, s->loss_mailbox, s->loss_mailbox ? ++s->loss_ticket : 0u);
     // ---- GRU backward through time, then its weight gradients over all steps at once
     if (s->gru_bwd_ks_lds > 0)
         hipLaunchKernelGGL((k_sv_gru_bwd_ks<SV_KS_SL, SV_KS_NR, SV_KS_KG>), dim3(seq_ptr ? n_seq : 1), dim3(512), s->gru_bwd_ks_lds, st, s->dH,

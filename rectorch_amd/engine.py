@@ -621,6 +621,17 @@ class SvaeEngine:
         self.n_tensors = lib().rtx_svae_n_tensors(h)
         self._keep = []
 
+    def loss_mailbox(self, enable=True):
+        """``rtx_svae_loss_mailbox``: every training step also reports its loss to coherent host memory as soon as it is final"""
+        check(lib().rtx_svae_loss_mailbox(self.handle, int(bool(enable))))
+        self._mailbox = bool(enable)
+
+    def wait_loss(self, timeout_s=60.0):
+        """the loss of the LAST step enqueued, without draining the stream behind it (``rtx_svae_wait_loss``)"""
+        out = C.c_float()
+        check(lib().rtx_svae_wait_loss(self.handle, C.byref(out), float(timeout_s)))
+        return float(out.value)
+
     def set_option(self, key, value):
         """``"gemm_bf16"``: bf16 operands / float32 accumulate in every matrix product of the model (include/rectorch_hip.h)"""
         check(lib().rtx_svae_set_option(self.handle, key.encode(), int(value)))

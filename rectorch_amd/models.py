@@ -874,6 +874,8 @@ class SVAE(MultiVAE):
         pack = tr_batch if isinstance(tr_batch, SvaePack) else None
         T = pack.n_steps if pack is not None else int(tr_batch.numel())
         eng = self.network.svae_engine(T, train_buffers=(st.grads, m, v))
+        if self.loss_mailbox and not getattr(eng, "_mailbox", False):
+            eng.loss_mailbox(True)
         if pack is not None:
             d = 1.0           # every user's own normaliser travels with the pack's rows
         elif isinstance(te_batch, SvaeTarget):
@@ -904,6 +906,8 @@ class SVAE(MultiVAE):
         else:
             eng.train_step(tr_batch, te_batch, step, st.loss_buf[0:1], st.loss_buf[1:2])
         self.gradient_updates += 1.
+        if getattr(eng, "_mailbox", False):
+            return eng.wait_loss()        # this step's loss (models.py:835) from the host mailbox: the backward half of the step is still running
         return st.loss_buf[0].item()
 
     def predict(self, x, remove_train=True):

@@ -1056,6 +1056,42 @@ def test_svae_vs_oracle_longer_sequences(R):
             assert float(dlt.max()) < 1e-3 and float(np.mean(dlt > 2e-5)) < 1e-4, (T, k, float(dlt.max()))
 
 
+def test_svae_loss_mailbox_returns_this_steps_loss():
+    """Round 6: SVAE.train_batch takes its return value (reference models.py:835 `return loss.item()`) from a host mailbox the loss
+    kernel writes mid-step, so the host does not wait for the backward half.  Same losses and the same parameters (to float32 round-off) as
+    with the draining read-back, over sequences of very different lengths back to back (a short step behind a long one: the ticket
+    of the LAST step is the one waited for)."""
+    from rectorch_amd.nets import SVAE_net
+    from rectorch_amd.models import SVAE
+    I, E, R, H, L, D = 400, 48, 96, 64, 24, 56
+    rng = np.random.RandomState(4)
+    seqs = []
+    for T in (210, 3, 1, 97, 2, 300, 5):
+        items = rng.randint(0, I, size=T)
+        y = np.zeros((T, I), dtype=np.float32)
+        for t in range(T):
+            y[t, rng.choice(I, size=3, replace=False)] = 1.0
+        seqs.append((items, y, rng.randn(T, L).astype(np.float32)))
+    runs = {}
+    for mailbox in (True, False):
+        torch.manual_seed(21)
+        net = SVAE_net(n_items=I, embed_size=E, rnn_size=R, dec_dims=[L, D, I], enc_dims=[R, H, L])
+        model = SVAE(net.to("cuda"), beta=0.2, anneal_steps=0)
+        model.loss_mailbox = mailbox
+        losses = []
+        for items, y, eps in seqs:
+            model._rtx.inject = (None, dev(eps))
+            losses.append(model.train_batch(torch.from_numpy(items[None, :]), torch.from_numpy(y[None])))
+        eng = net._svae_engine
+        assert bool(getattr(eng, "_mailbox", False)) == mailbox
+        torch.cuda.synchronize()
+        runs[mailbox] = (losses, [p.detach().cpu().numpy().copy() for p in net._param_list()])
+    # (not bit for bit: the bias and embedding gradients are atomic sums -- k_sv_colsum1, k_sv_embed_grad -- whose order varies from run to run)
+    assert np.allclose(runs[True][0], runs[False][0], rtol=2e-6, atol=0), (runs[True][0], runs[False][0])
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert np.allclose(a, b, rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("widths,lens", [((300, 48, 40, 36, 16, 28), (2, 9, 41, 17, 130, 3, 66)),
                                          # the benchmarked GRU width: the K-sliced recurrence kernels, one workgroup per user of the pack
                                          ((800, 256, 200, 150, 64, 150), (2, 9, 41, 17, 400, 3, 66))])
