@@ -16,203 +16,11 @@
 //   the row-major matrices K-major (ds_read_b64_tr_b16 for bf16, plain 4-byte reads for f32).
 //   All pads are zero (memset at creation; producers rewrite the batch padding every call), so no GEMM
 //   needs a bounds check in its main loop.
-#include "../../include/rectorch_hip.h"
-#include "rtx_gemm.h"
-#include "rtx_kernels.h"
+#include "engine_internal.h"
 
-#include <math.h>
-#include <stdlib.h>
-#include <string.h>
-#include <sched.h>
-#include <algorithm>
-#include <chrono>
-#include <map>
-#include <string>
-#include <vector>
-
-const char* rtx_last_error_str();
-
-
-struct Layer {
-    int in = 0, out = 0, inp = 0, outp = 0;
-    bool tanh_act = false;
-    void* Wsh = nullptr;      // the compute copy every reader of this step uses
-    void* Wsh_alt = nullptr;  // the fused optimizer writes the NEXT step's copy here (they swap after the step), so the
-                              // weight-gradient kernels may run beside the data-gradient chain that still reads Wsh
-    void* WshT = nullptr;     // hidden layers, bf16: the transposed compute copy [inp][outp] the backward chain reads (small_layers.hip)
-    void* A = nullptr;
-    float* O32 = nullptr;
-    void* D = nullptr;
-};
-
-struct TimingSite {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    double total_ms = 0;
-    int launches = 0;
-};
-
-struct TempCsr {  // dense batch converted to CSR on the device
-    int64_t* indptr = nullptr;
-    int32_t* counts = nullptr;
-    int32_t* indices = nullptr;
-    float* values = nullptr;
-    int64_t cap = 0;
-};
-
-// data-parallel step scheduled by the engine (rtx_engine_dp_attach): the exchange buffer every gradient is produced into, in
-// comm dtype.  Layout (elements; every tensor starts at a multiple of 64): W[NL-1], b[NL-1], W[NL-2], b[NL-2], ..., W[1], b[1],
-// b[0], W[0] -- bucket A (the decoder matrix, exchanged on the side stream beside the data-gradient chain) first, bucket B
-// (everything else, behind the chain) after it, the sharded encoder matrix last so that the replicated tensors of a bucket
-// form ONE contiguous all-reduce range.  A sharded matrix's region is rows padded to P(out) = roundup(out + 1, 128) (zeros):
-// world equal row blocks.
-struct DpState {
-    bool on = false;
-    rtx_dp_cfg cfg = {};
-    rtx_dp_ops ops = {};                      // bucket B (and everything on ONE stream): the caller's stream
-    rtx_dp_ops ops_side = {};                 // bucket A on the side stream: a communicator of its own when the plan brings one (ABI 7)
-    bool two_comms = false;                   // ops_side is a different communicator / table than ops
-    void* xg = nullptr;                       // exchange buffer, comm dtype
-    size_t xbytes = 0, xesz = 4;
-    size_t xoff[2 * 2 * RTX_MAX_LAYERS] = {};   // element offset of tensor t
-    bool shard[2 * RTX_MAX_LAYERS] = {};        // per layer: weight matrix reduce-scattered / updated by rows / all-gathered
-    bool broken = false;                      // a collective failed inside a group: no further step until the plan is attached again
-    // what the LAST step's exchange moved, per rank (buffer bytes handed to the collectives; rtx_engine_get_option "dp_*")
-    int64_t st_all_reduce = 0, st_reduce_scatter = 0, st_all_gather = 0;
-    int st_collectives = 0;
-    void* emu_scratch = nullptr;              // emulate: where the stand-in copies go
-    size_t emu_bytes = 0;
-    // emulate: the collectives of one group become ONE copy launch (as RCCL fuses a group into one kernel)
-    struct EmuPiece { void* buf; size_t bytes; int back; };
-    EmuPiece emu_q[8];
-    int emu_n = 0, emu_grouped = 0;
-    hipStream_t emu_stream = nullptr;
-};
-
-struct rtx_engine {
-    rtx_cfg cfg;
-    int NL = 0, I = 0, Z = 0, Ip = 0, Zp = 0;
-    int Iin = 0;   // input columns = I + cfg.cond_dim
-    int Bp_alloc = 0;
-    bool bf16 = false, vae = false;
-    size_t esz = 4;
-    std::vector<Layer> L;
-    std::vector<void*> allocs;
-    float* Y = nullptr;
-    float* Cacc = nullptr;
-    size_t cacc_elems = 0;
-    float *mu32 = nullptr, *lv32 = nullptr, *eps32 = nullptr;
-    float2* lse_part = nullptr;
-    int lse_strips = 0;
-    float *tsum = nullptr, *lse = nullptr, *row_loss = nullptr, *sumsq = nullptr, *scratch_loss = nullptr;
-    // bound tensors
-    std::vector<float*> params, grads, m, v;
-    std::vector<uint16_t*> grads16;   // optional bf16 gradient images (rtx_engine_bind_grads16; RTX_STEP_GRADS_BF16)
-    bool bound = false, can_train = false, shadows_valid = false;
-    TempCsr tmp_in, tmp_tg;
-    // chunk stream of the batch's stored entries for the sparse first layer (spmm_in.hip)
-    uint32_t* in_ent = nullptr;
-    int32_t *in_desc = nullptr, *in_wsplit = nullptr;
-    int64_t in_cap_chunks = 0;
-    // batch image A[0] written by scatter (k_gather_scatter): per row slot, the columns the last launch wrote
-    int32_t *img_written = nullptr, *img_nwritten = nullptr;
-    int img_cap = 0;
-    bool img_exact = false;           // A[0] is zero except the listed columns (any other writer of A[0] clears this flag)
-    // The OTHER batch image (round 5): the NEXT step's gather (rtx_engine_set_next_batch) runs on the side stream, which idles
-    // under this step's last weight-gradient + Adam launch, into a second image with lists and target sums of its own; the step
-    // that then gets the announced batch swaps the two sets and starts with the first-layer product (the gather -- 7-9 us of pure
-    // latency at the head of every step -- leaves the critical path).  swap_img_sets() exchanges these with L[0].A, tsum, img_*.
-    void* A0_alt = nullptr;
-    float* tsum_alt = nullptr;
-    int32_t *img_written_alt = nullptr, *img_nwritten_alt = nullptr;
-    int img_cap_alt = 0;
-    bool img_exact_alt = false;
-    struct { bool valid = false; rtx_batch b = {}; rtx_step s = {}; } next;        // announced for the step after the next call
-    struct { bool valid = false; rtx_batch b = {}; uint64_t seed = 0, offset = 0; const uint8_t* mask = nullptr; } pre;   // gathered
-    bool gather_done = false;         // run_forward: A[0] / tsum already hold this batch (a prefetch hit)
-    int opt_prefetch = 1;             // 0: announced batches are ignored (A/B knob)
-    int st_prefetch_hits = 0, st_prefetch_issued = 0;
-    int st_join_folds = 0;             // deferred joins resolved INSIDE a first-layer product (get_option "join_folds")
-    int opt_gather_scatter = 1;       // 0: k_gather rewrites the whole image every batch (rounds 1-3)
-    // the weight-gradient + Adam kernels of the fused step run on a second stream beside the data-gradient chain
-    hipStream_t side = nullptr;
-    hipStream_t side_for = nullptr;   // the caller's stream the side stream was probed against (make_side_stream)
-    std::map<hipStream_t, std::pair<hipStream_t, int>> side_cache;   // caller's stream -> (probed side stream, concurrent): a caller that
-                                      //   alternates streams pays the ~1.5 ms probe once per stream, not on every change
-    int side_concurrent = 0;          // 1: the probe saw the two streams run at the same time
-    hipEvent_t ev_d[2 * RTX_MAX_LAYERS + 1] = {};   // ev_d[l]: D[l] is complete on the caller's stream
-    hipEvent_t ev_done = nullptr;      // everything the step put on the side stream is complete
-    // the two cross-stream dependencies of the fused step as stream memory operations (hipStreamWriteValue32 on the producing
-    // stream, hipStreamWaitValue32 on the consuming one; option "hop_values", default on since round 4) instead of an event
-    // record / wait: -3 us per step in three alternating pairs (283.7 / 280.1 / 276.0 -> 280.1 / 276.8 / 273.2,
-    // profiles/r4_hop_values.txt); where the device cannot wait on a value the events remain
-    int opt_hop_values = 1;
-    int opt_f32_tail_split = 0;        // (measured: 963 vs 951 us/step, profiles/r5_fp32_tail_split.txt -- off) float32 parity mode: the last partial wave of a big weight-gradient product split over K (RtxGemm::tail_*)
-    int n_cus = 256;                   // compute units of the device (hipDeviceAttributeMultiprocessorCount)
-    int opt_f32_adam_overlap = 0;      // (measured: 960.5 vs 960.7 us/step, no gain -- off; profiles/r5_fp32_tail_split.txt) float32 train step: the decoder matrix's Adam pass on the side stream under the remaining products
-    int opt_f32_dw_split = 1;          // float32 parity mode: small weight-gradient products split over the batch (0: one workgroup per tile)
-    int opt_splitk_bwd = 0;            // measurement: split factor of the K = n_items data-gradient product alone (0 = automatic)
-    int opt_splitk_fwd = 0;            // measurement: split factor of the dense first-layer product alone (0 = automatic)
-    uint32_t* hopk_mem = nullptr;      // the same two words in plain device memory, for the kernel form of the hop (k_hop_set / k_hop_wait)
-    uint32_t hopk_seq = 0;
-    // a step flagged RTX_STEP_DEFER_JOIN ends with a k_hop_set on the side stream instead of a wait on the caller's: the NEXT use of
-    // the engine on a stream resolves it (resolve_join) -- folded into the first-layer product of the next training step when that
-    // step starts from a prefetched batch image, as a one-wave k_hop_wait otherwise
-    bool join_pending = false, join_fold = false;
-    uint32_t join_seq = 0;
-    int opt_timing_calibrate = 0;      // every timed bracket is followed by an empty one (site "<name>#empty"): what the events themselves cost
-    // unused LDS of the decoder matrix's side-stream launch (RtxDw::lds_pad; knob "dw_side_pad").  12288 = one workgroup per CU beside the chain:
-    // the chain's kernels then find registers at once (chain 95 -> 74 us on the timeline) and the step gains 2.3-4.3 us on fast and slow boxes
-    // alike (profiles/r6_ab_small_waves_side_pad.txt) -- but the throttled launch itself stretches from 90 to 126 us and runs into the
-    // encoder matrix's launch (90 -> 101 us): the step's dominant kernel would be REPORTED at 0.32 of the HBM roof instead of 0.40 for a 1 %
-    // faster step.  Default off: the roofline of the dominant kernel is quoted for an unthrottled launch.
-    int opt_dw_side_pad = 0;
-    int opt_hop_fold = 1;              // the step's fork (caller's stream -> side stream) folded into the data-gradient product (loss_grads_impl)
-    int opt_hop_kernels = 0;           // (measured: no gain, a one-wave kernel costs its stream 5-6 us like the packet it replaces) the two cross-stream dependencies of the step as one-wave kernels (stream_dependency)
-    uint32_t* hop_mem = nullptr;       // [0]: caller's stream -> side stream, [1]: side stream -> caller's stream (signal memory)
-    uint32_t hop_seq = 0;
-    uint32_t hop_wrap = 0x7ffffff0u;   // the sequence restarts from zero here (option "hop_wrap": tests lower it)
-    // measurement knobs (rtx_engine_set_option; defaults are the shipped configuration)
-    int opt_fuse_adam = 1;      // bf16: Adam of every weight matrix inside its weight-gradient kernel (dw_adam.hip)
-    int opt_dw_cfg = RTX_DW_64x128;
-    int opt_dp_shard_min_elems = 1 << 20;   // sharded optimizer: weight matrices of at least this many elements are reduce-scattered /
-                                //   updated by rows / all-gathered, smaller ones all-reduced and replicated (tests lower it so that
-                                //   small golden networks exercise the sharded path with real data)
-    uint32_t* loss_mailbox = nullptr;   // coherent host memory {loss bits, ticket, step}: rtx_engine_loss_mailbox / rtx_engine_wait_loss
-    uint32_t loss_ticket = 0;           // ticket of the last loss reduction enqueued with the mailbox on (monotonic; never a step count)
-    int opt_dp_one_comm = 0;    // 1: bucket A shares bucket B's communicator even when the plan brings a second one (ABI 5-6 schedule; A/B knob)
-    int opt_dw_cfg_set = 0;     // 1: chosen through rtx_engine_set_option (the data-parallel step otherwise picks its own tile, see dw_cfg_of)
-    int opt_lse_fuse = 1;       // log-sum-exp partials from the logits GEMM's epilogue (no separate pass over the logits)
-    int opt_logits16 = 1;       // bf16 training step: the logits leave their product as IEEE half, written where d loss / d logits
-                                //   (bf16, same size) goes, and the loss kernel turns them into it IN PLACE: 41 + 41 MB of float32
-                                //   logits traffic per ml-20m step become 21 + 21 MB (the log-sum-exp still comes from the float32
-                                //   accumulators; half keeps 11 significant bits -- the bf16 products' own error level)
-    int opt_two_stream = 1;     // fused step: weight-gradient kernels on a side stream beside the data-gradient chain (-10 us)
-    int opt_side_low_prio = 0;  // ... created with the lowest stream priority (1).  Round 3: OFF.  Neutral for the single-GPU step
-                                //   (307.1 / 308.0 vs 308.2 / 308.5 us, A/B in one call), and with a live RCCL communicator in the process
-                                //   -- any data-parallel job -- a lowest-priority queue beside RCCL's makes EVERY kernel of the step run 2-3x
-                                //   slower (769 vs 343 us/step, profiles/r3_dp_priority_experiment.txt)
-    int opt_in_on_main = 1;     // ... and the encoder matrix's kernel on the caller's stream behind the chain (see loss_grads_impl)
-    int opt_sparse_in = 0;      // bf16, 1: the first encoder layer as a sparse VALU product over the stored entries (spmm_in.hip).
-                                //   Default since round 4: the dense [batch, n_items] x [n_items, hidden] contraction on MFMA
-                                //   (k_gather -> split-K rtx_gemm_nt -> k_post), the configuration BASELINE.json's north star names;
-                                //   the sparse product is the measured alternative (2-6 us per ml-20m step faster at B = 500)
-    int opt_small_fwd = 1;      // bf16: hidden layers / VAE head of the forward pass as one register-resident launch each (small_layers.hip)
-    int opt_small_bwd = 1;      // ... and of the data-gradient chain (reads the transposed compute copies of the hidden layers)
-    int opt_big_batch_tiles = 1;   // batches of >= 1024 rows: 512 x 128 data-gradient tiles (configs[3] on one GPU: 1486 -> 1343 us/step)
-    int last_sparse_in = 0;     // what the last forward pass did with the first layer (rtx_engine_get_option "last_sparse_in")
-    int opt_nt_regstage = 1;    // bf16: the K = n_items / N = n_items NT contractions on the register-staged kernel (gemm.hip):
-                                //   33 + 30 us in the step against 41 + 40 us on the LDS-DMA kernel at B = 500 (1 workgroup / CU)
-    // timing
-    bool timing_all = false;
-    std::map<std::string, int> timing_sites;   // site -> sampling period (every N-th launch of the site is bracketed by events)
-    std::map<std::string, long> timing_seen;
-    std::map<std::string, TimingSite> sites;
-    std::vector<hipEvent_t> event_pool;
-    DpState dp;
-};
 
 // ------------------------------------------------------------------------------------------------
-static int dev_alloc(rtx_engine* e, void** p, size_t bytes, bool zero = true)
+int dev_alloc(rtx_engine* e, void** p, size_t bytes, bool zero)
 {
     if (bytes == 0) bytes = 16;
     hipError_t rc = hipMalloc(p, bytes);
@@ -268,62 +76,6 @@ static int build_layers(const rtx_cfg& c, std::vector<Layer>& L)
     }
     return RTX_OK;
 }
-
-// ---- timing -------------------------------------------------------------------------------------
-struct ScopedTimer {
-    rtx_engine* e;
-    hipStream_t s;
-    TimingSite* site = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::string name;
-    ScopedTimer(rtx_engine* eng, const char* nm, hipStream_t st) : e(eng), s(st), name(nm)
-    {
-        const char* name = nm;
-        if (!e->timing_all && e->timing_sites.empty()) return;
-        if (!e->timing_all) {
-            auto it = e->timing_sites.find(name);
-            if (it == e->timing_sites.end()) return;
-            // an event record costs microseconds on the stream it is recorded on (two per timed launch): sample
-            if (it->second > 1 && (e->timing_seen[name]++ % it->second) != 0) return;
-        }
-        site = &e->sites[name];
-        auto get = [&]() {
-            hipEvent_t ev;
-            if (!e->event_pool.empty()) {
-                ev = e->event_pool.back();
-                e->event_pool.pop_back();
-            } else if (hipEventCreate(&ev) != hipSuccess) {
-                ev = nullptr;
-            }
-            return ev;
-        };
-        e0 = get();
-        e1 = get();
-        if (e0) (void)hipEventRecord(e0, s);
-    }
-    ~ScopedTimer()
-    {
-        if (!site) return;
-        if (e1) (void)hipEventRecord(e1, s);
-        if (e0 && e1) site->pending.push_back({e0, e1});
-        if (e->opt_timing_calibrate && e1) {
-            // an EMPTY bracket right behind the timed one, on the same stream at the same moment: the time between two event records
-            // with nothing in between is what the bracket above contains besides its kernel (option "timing_calibrate";
-            // reported as site "<name>#empty", the caller subtracts)
-            hipEvent_t a = nullptr, b = nullptr;
-            if (!e->event_pool.empty()) { a = e->event_pool.back(); e->event_pool.pop_back(); } else if (hipEventCreate(&a) != hipSuccess) a = nullptr;
-            if (!e->event_pool.empty()) { b = e->event_pool.back(); e->event_pool.pop_back(); } else if (hipEventCreate(&b) != hipSuccess) b = nullptr;
-            if (a && b) {
-                (void)hipEventRecord(a, s);
-                (void)hipEventRecord(b, s);
-                e->sites[name + "#empty"].pending.push_back({a, b});
-            }
-        }
-    }
-};
-#define RTX_CAT2(a, b) a##b
-#define RTX_CAT(a, b) RTX_CAT2(a, b)
-#define TIMED(name) ScopedTimer RTX_CAT(_timer_, __LINE__)(e, name, st)
 
 // ---- GEMM helpers -------------------------------------------------------------------------------------
 // A contraction whose output goes to the fp32 scratch Cacc (possibly as split-K slabs):
@@ -401,7 +153,7 @@ static bool fold_has_room(const rtx_engine* e, int Mp, int Np, int Kp)
     return grid + 16 <= 2L * e->n_cus;
 }
 
-static size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
+size_t plan_cacc_elems(rtx_engine* e, int Np, int Kp)
 {
     size_t mx = 0;
     const int keep = e->opt_nt_regstage, keep2 = e->opt_two_stream;
@@ -760,7 +512,7 @@ static int run_forward(rtx_engine* e, const RtxCsrView* in, const RtxCsrView* tg
     return RTX_OK;
 }
 
-static int check_ready(rtx_engine* e, bool train)
+int check_ready(rtx_engine* e, bool train)
 {
     RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
     RTX_CHECK(e->bound, RTX_ESTATE, "rtx_engine_bind() has not been called");
@@ -768,7 +520,7 @@ static int check_ready(rtx_engine* e, bool train)
     return RTX_OK;
 }
 
-static int ensure_shadows(rtx_engine* e, hipStream_t st)
+int ensure_shadows(rtx_engine* e, hipStream_t st)
 {
     RTX_TRY(resolve_join(e, st));   // (a join the last training step left open: before anything else of the engine runs on `st`)
     if (e->shadows_valid) return RTX_OK;
@@ -1203,7 +955,7 @@ static int make_side_stream(rtx_engine* e, hipStream_t st)
 }
 
 // tensors of the exchange buffer in layout order (DpState): W[NL-1], b[NL-1], ..., W[1], b[1], b[0], W[0]
-static int dp_layout_order(const rtx_engine* e, int* order)
+int dp_layout_order(const rtx_engine* e, int* order)
 {
     int n = 0;
     for (int li = e->NL - 1; li >= 1; --li) { order[n++] = 2 * li; order[n++] = 2 * li + 1; }
@@ -1211,7 +963,7 @@ static int dp_layout_order(const rtx_engine* e, int* order)
     order[n++] = 0;
     return n;
 }
-static size_t dp_region_elems(const rtx_engine* e, const DpState& d, int t)
+size_t dp_region_elems(const rtx_engine* e, const DpState& d, int t)
 {
     const Layer& l = e->L[t / 2];
     if (t & 1) return (size_t)l.out;
@@ -1951,175 +1703,6 @@ int rtx_cast_f32_bf16(const float* src, uint16_t* dst, int64_t n, void* stream)
     return rtx_launch_cast_f32_bf16(src, dst, (long)n, (hipStream_t)stream);
 }
 
-// ---- data parallel: attach / step --------------------------------------------------------------------------------
-static int dp_rccl_all_reduce(void* c, void* buf, int64_t n, int32_t dt, void* st) { return rtx_comm_allreduce((rtx_comm*)c, buf, n, dt, st); }
-static int dp_rccl_reduce_scatter(void* c, void* buf, int64_t n, int32_t dt, void* st) { return rtx_comm_reduce_scatter((rtx_comm*)c, buf, n, dt, st); }
-static int dp_rccl_all_gather(void* c, void* buf, int64_t bytes, void* st) { return rtx_comm_allgather((rtx_comm*)c, buf, bytes, st); }
-static int dp_rccl_group_start(void* c) { return rtx_comm_group_start((rtx_comm*)c); }
-static int dp_rccl_group_end(void* c) { return rtx_comm_group_end((rtx_comm*)c); }
-
-// emulate: the bytes one rank of `world` sends + receives in a ring collective, as device copies through a scratch buffer
-// (reduce-scatter / all-gather: (world - 1) / world of the buffer read and written once; all-reduce: twice -- there and back,
-// numerically a no-op).  One launch per collective, or per group of collectives, like RCCL's own kernels.
-struct EmuCopyArgs {
-    struct { const uint4* src; uint4* dst; unsigned long n16; int back; } p[8];
-    int n;
-};
-__global__ __launch_bounds__(256) void k_emu_copy(const EmuCopyArgs a)
-{
-    for (int k = 0; k < a.n; ++k) {
-        const uint4* __restrict__ src = a.p[k].src;
-        uint4* __restrict__ dst = a.p[k].dst;
-        for (unsigned long i = (unsigned long)blockIdx.x * 256 + threadIdx.x; i < a.p[k].n16; i += (unsigned long)gridDim.x * 256) {
-            const uint4 v = src[i];
-            dst[i] = v;
-            if (a.p[k].back) ((uint4*)src)[i] = v;   // the all-gather half of an all-reduce writes the block back
-        }
-    }
-}
-static int dp_emu_flush(DpState* d)
-{
-    if (d->emu_n == 0) return RTX_OK;
-    EmuCopyArgs a = {};
-    size_t used = 0;
-    for (int k = 0; k < d->emu_n; ++k) {
-        const size_t w = (size_t)d->cfg.world, bytes = d->emu_q[k].bytes;
-        size_t s = (bytes / w * (w - 1)) & ~(size_t)15;
-        s = std::min(s, d->emu_bytes - used);
-        if (s == 0) continue;
-        a.p[a.n].src = (const uint4*)((char*)d->emu_q[k].buf + ((bytes - s) & ~(size_t)15));   // "the other ranks' blocks"
-        a.p[a.n].dst = (uint4*)((char*)d->emu_scratch + used);
-        a.p[a.n].n16 = s / 16;
-        a.p[a.n].back = d->emu_q[k].back;
-        used += s;
-        ++a.n;
-    }
-    d->emu_n = 0;
-    if (a.n == 0) return RTX_OK;
-    hipLaunchKernelGGL(k_emu_copy, dim3(2048), dim3(256), 0, d->emu_stream, a);
-    RTX_HIP(hipGetLastError());
-    return RTX_OK;
-}
-static int dp_emu_move(DpState* d, void* buf, size_t bytes, bool back, hipStream_t st)
-{
-    if (d->emu_n == 8) RTX_TRY(dp_emu_flush(d));
-    d->emu_stream = st;
-    d->emu_q[d->emu_n++] = DpState::EmuPiece{buf, bytes, back ? 1 : 0};
-    return d->emu_grouped ? RTX_OK : dp_emu_flush(d);
-}
-static int dp_emu_group_start(void* c) { ((DpState*)c)->emu_grouped = 1; return RTX_OK; }
-static int dp_emu_group_end(void* c) { ((DpState*)c)->emu_grouped = 0; return dp_emu_flush((DpState*)c); }
-static int dp_emu_all_reduce(void* c, void* buf, int64_t n, int32_t dt, void* st)
-{
-    return dp_emu_move((DpState*)c, buf, (size_t)n * (dt == RTX_BF16 ? 2 : 4), true, (hipStream_t)st);
-}
-static int dp_emu_reduce_scatter(void* c, void* buf, int64_t n, int32_t dt, void* st)
-{
-    return dp_emu_move((DpState*)c, buf, (size_t)n * (dt == RTX_BF16 ? 2 : 4), false, (hipStream_t)st);
-}
-static int dp_emu_all_gather(void* c, void* buf, int64_t bytes, void* st) { return dp_emu_move((DpState*)c, buf, (size_t)bytes, false, (hipStream_t)st); }
-
-static void dp_release(rtx_engine* e)
-{
-    DpState& d = e->dp;
-    for (void* p : {d.xg, d.emu_scratch})
-        if (p) {
-            auto it = std::find(e->allocs.begin(), e->allocs.end(), p);
-            if (it != e->allocs.end()) e->allocs.erase(it);
-            (void)hipFree(p);
-        }
-    d = DpState();
-}
-
-int rtx_engine_dp_attach(rtx_engine* e, const rtx_dp_cfg* cfg)
-{
-    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
-    RTX_HIP(hipDeviceSynchronize());
-    e->join_pending = e->join_fold = false;   // (every stream has drained)
-    dp_release(e);
-    if (!cfg) return RTX_OK;
-    RTX_CHECK(cfg->world >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world, RTX_EINVAL, "dp_attach: rank %d of %d", cfg->rank, cfg->world);
-    RTX_CHECK(cfg->comm_dtype == RTX_FP32 || cfg->comm_dtype == RTX_BF16, RTX_EINVAL, "dp_attach: comm_dtype must be RTX_FP32 or RTX_BF16");
-    RTX_CHECK((cfg->emulate != 0) + (cfg->comm != nullptr) + (cfg->ops != nullptr) == 1, RTX_EINVAL,
-              "dp_attach: give exactly one of comm (RCCL), ops (caller's collectives) or emulate");
-    DpState& d = e->dp;
-    d.cfg = *cfg;
-    if (cfg->emulate) {
-        d.ops = rtx_dp_ops{dp_emu_all_reduce, dp_emu_reduce_scatter, dp_emu_all_gather, dp_emu_group_start, dp_emu_group_end, &e->dp};
-    } else if (cfg->comm) {
-        int32_t r = -1, w = -1;
-        RTX_TRY(rtx_comm_rank(cfg->comm, &r, &w));
-        RTX_CHECK(r == cfg->rank && w == cfg->world, RTX_EINVAL, "dp_attach: the communicator is rank %d of %d, the plan says %d of %d", r, w, cfg->rank, cfg->world);
-        d.ops = rtx_dp_ops{dp_rccl_all_reduce, dp_rccl_reduce_scatter, dp_rccl_all_gather, dp_rccl_group_start, dp_rccl_group_end, cfg->comm};
-    } else {
-        RTX_CHECK(cfg->ops->all_reduce && cfg->ops->reduce_scatter && cfg->ops->all_gather, RTX_EINVAL, "dp_attach: ops needs all_reduce, reduce_scatter and all_gather");
-        d.ops = *cfg->ops;
-    }
-    d.cfg.ops = nullptr;
-    // bucket A's table: a second communicator / function table when the plan brings one, else the same as bucket B's
-    d.ops_side = d.ops;
-    d.two_comms = false;
-    if (!cfg->emulate && cfg->comm && cfg->comm_side && !e->opt_dp_one_comm) {
-        int32_t r = -1, w = -1;
-        RTX_TRY(rtx_comm_rank(cfg->comm_side, &r, &w));
-        RTX_CHECK(r == cfg->rank && w == cfg->world, RTX_EINVAL, "dp_attach: comm_side is rank %d of %d, the plan says %d of %d", r, w, cfg->rank, cfg->world);
-        RTX_CHECK(cfg->comm_side != cfg->comm, RTX_EINVAL, "dp_attach: comm_side must be a communicator of its own (or NULL)");
-        d.ops_side.ctx = cfg->comm_side;
-        d.two_comms = true;
-    } else if (!cfg->emulate && cfg->ops && cfg->ops_side && !e->opt_dp_one_comm) {
-        RTX_CHECK(cfg->ops_side->all_reduce && cfg->ops_side->reduce_scatter && cfg->ops_side->all_gather, RTX_EINVAL,
-                  "dp_attach: ops_side needs all_reduce, reduce_scatter and all_gather");
-        d.ops_side = *cfg->ops_side;
-        d.two_comms = true;
-    }
-    d.cfg.ops_side = nullptr;
-    d.xesz = cfg->comm_dtype == RTX_BF16 ? 2 : 4;
-    size_t biggest = 0;
-    for (int li = 0; li < e->NL; ++li) {
-        const Layer& l = e->L[li];
-        // a hidden layer that keeps a transposed compute copy (WshT) is never sharded: that copy is a column-block layout
-        const long min_elems = cfg->shard_min_elems > 0 ? (long)cfg->shard_min_elems : (long)e->opt_dp_shard_min_elems;
-        d.shard[li] = cfg->sharded && (long)l.out * l.in >= min_elems && !l.WshT && l.outp % cfg->world == 0;
-        biggest = std::max(biggest, (size_t)l.outp * l.inp * std::max(e->esz, d.xesz));
-    }
-    int order[2 * 2 * RTX_MAX_LAYERS];
-    const int n_order = dp_layout_order(e, order);
-    size_t off = 0;
-    for (int q = 0; q < n_order; ++q) {
-        d.xoff[order[q]] = off;
-        off += (dp_region_elems(e, d, order[q]) + 63) / 64 * 64;
-    }
-    d.xbytes = off * d.xesz;
-    RTX_TRY(dev_alloc(e, &d.xg, d.xbytes));
-    if (cfg->emulate) {
-        d.emu_bytes = 2 * biggest;
-        RTX_TRY(dev_alloc(e, &d.emu_scratch, d.emu_bytes, false));
-        // rows no rank updates here keep their weights in BOTH compute copies (the step alternates between them)
-        RTX_TRY(ensure_shadows(e, nullptr));
-        for (auto& l : e->L)
-            if (l.Wsh_alt) RTX_HIP(hipMemcpy(l.Wsh_alt, l.Wsh, (size_t)l.outp * l.inp * e->esz, hipMemcpyDeviceToDevice));
-    }
-    d.on = true;
-    return RTX_OK;
-}
-
-int rtx_engine_dp_owned_rows(const rtx_engine* e, int32_t layer, int32_t* row_lo, int32_t* row_hi, int32_t* sharded_out)
-{
-    RTX_CHECK(e && layer >= 0 && layer < e->NL, RTX_EINVAL, "dp_owned_rows: bad arguments");
-    const Layer& l = e->L[layer];
-    int lo = 0, hi = l.out, sh = 0;
-    if (e->dp.on && e->dp.shard[layer]) {
-        const int per = l.outp / e->dp.cfg.world;
-        lo = std::min(e->dp.cfg.rank * per, l.out);
-        hi = std::min((e->dp.cfg.rank + 1) * per, l.out);
-        sh = 1;
-    }
-    if (row_lo) *row_lo = lo;
-    if (row_hi) *row_hi = hi;
-    if (sharded_out) *sharded_out = sh;
-    return RTX_OK;
-}
-
 int rtx_engine_train_step_dp(rtx_engine* e, const rtx_batch* batch, const rtx_step* step, float* loss_out, float* loss_accum, void* stream)
 {
     RTX_TRY(check_ready(e, true));
@@ -2205,158 +1788,6 @@ int rtx_engine_set_next_batch(rtx_engine* e, const rtx_batch* next, const rtx_st
     return RTX_OK;
 }
 
-// measurement knobs: one entry point instead of environment variables scattered over the kernels' launchers
-int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
-{
-    RTX_CHECK(e && key, RTX_EINVAL, "set_option: NULL argument");
-    const std::string k(key);
-    if (k == "fuse_adam") e->opt_fuse_adam = value != 0;
-    else if (k == "lse_fuse") e->opt_lse_fuse = value != 0;
-    else if (k == "logits16") e->opt_logits16 = value != 0;
-    else if (k == "hop_values") e->opt_hop_values = value != 0;
-    else if (k == "hop_kernels") e->opt_hop_kernels = value != 0;
-    else if (k == "hop_fold") e->opt_hop_fold = value != 0;
-    else if (k == "dw_side_pad") e->opt_dw_side_pad = value > 0 ? value : 0;
-    else if (k == "small_kw") rtx_small_set_kw(value);         // (process-wide: K split of small_layers.hip's kernels over waves)
-    else if (k == "small_waves") rtx_small_set_waves(value);   // (process-wide: a launch-shape knob of small_layers.hip)
-    else if (k == "timing_calibrate") e->opt_timing_calibrate = value != 0;
-    else if (k == "hop_wrap") {
-        RTX_CHECK(value >= 2, RTX_EINVAL, "set_option: hop_wrap must be >= 2");
-        e->hop_wrap = (uint32_t)value;
-    }
-    else if (k == "f32_dw_split") e->opt_f32_dw_split = value != 0;
-    else if (k == "f32_tail_split") e->opt_f32_tail_split = value != 0;
-    else if (k == "f32_adam_overlap") e->opt_f32_adam_overlap = value != 0;
-    else if (k == "splitk_fwd") e->opt_splitk_fwd = value;
-    else if (k == "splitk_bwd") e->opt_splitk_bwd = value;
-    else if (k == "gather_scatter") e->opt_gather_scatter = value != 0;
-    else if (k == "dp_shard_min_elems") {
-        RTX_CHECK(!e->dp.on && value >= 1, RTX_ESTATE, "set_option: dp_shard_min_elems (>= 1) must be set before rtx_engine_dp_attach");
-        e->opt_dp_shard_min_elems = value;
-    }
-    else if (k == "dp_one_comm") {
-        RTX_CHECK(!e->dp.on, RTX_ESTATE, "set_option: dp_one_comm must be set before rtx_engine_dp_attach");
-        e->opt_dp_one_comm = value != 0;
-    }
-    else if (k == "prefetch") e->opt_prefetch = value != 0;
-    else if (k == "two_stream") e->opt_two_stream = value != 0;
-    else if (k == "side_low_prio") {
-        RTX_CHECK(e->side_cache.empty(), RTX_ESTATE, "set_option: side_low_prio must be set before the first training step");
-        e->opt_side_low_prio = value != 0;
-    }
-    else if (k == "nt_regstage") e->opt_nt_regstage = value != 0;
-    else if (k == "in_on_main") e->opt_in_on_main = value != 0;
-    else if (k == "sparse_in") e->opt_sparse_in = value != 0;
-    else if (k == "small_fwd") e->opt_small_fwd = value != 0;
-    else if (k == "small_bwd") e->opt_small_bwd = value != 0;
-    else if (k == "big_batch_tiles") e->opt_big_batch_tiles = value != 0;
-    else if (k == "dw_cfg") {
-        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_32x256_K32, RTX_EINVAL, "set_option: dw_cfg must be 0..7");
-        e->opt_dw_cfg = value;
-        e->opt_dw_cfg_set = 1;
-    } else if (k == "splitk") {
-        RTX_CHECK(value >= 0, RTX_EINVAL, "set_option: splitk must be >= 0");
-        // the scratch was sized for the automatic choice: only accept factors it can hold
-        const int old = e->cfg.splitk;
-        e->cfg.splitk = value;
-        size_t need = 0;
-        for (int li = 0; li < e->NL; ++li) {
-            if (li < e->NL - 1) need = std::max(need, plan_cacc_elems(e, e->L[li].outp, e->L[li].inp));
-            if (li > 0) need = std::max(need, plan_cacc_elems(e, e->L[li].inp, e->L[li].outp));
-        }
-        if (need > e->cacc_elems) {
-            e->cfg.splitk = old;
-            rtx_set_error("set_option: split factor %d needs %zu scratch floats, the engine holds %zu", value, need, e->cacc_elems);
-            return RTX_EINVAL;
-        }
-    } else {
-        rtx_set_error("set_option: unknown key '%s' (fuse_adam, lse_fuse, two_stream, side_low_prio, nt_regstage, in_on_main, sparse_in, small_fwd, small_bwd, big_batch_tiles, dw_cfg, splitk)", key);
-        return RTX_EINVAL;
-    }
-    return RTX_OK;
-}
-
-int rtx_engine_get_option(const rtx_engine* e, const char* key, int32_t* value)
-{
-    RTX_CHECK(e && key && value, RTX_EINVAL, "get_option: NULL argument");
-    const std::string k(key);
-    if (k == "fuse_adam") *value = e->opt_fuse_adam;
-    else if (k == "lse_fuse") *value = e->opt_lse_fuse;
-    else if (k == "logits16") *value = e->opt_logits16;
-    else if (k == "hop_values") *value = e->opt_hop_values;
-    else if (k == "hop_kernels") *value = e->opt_hop_kernels;
-    else if (k == "hop_fold") *value = e->opt_hop_fold;
-    else if (k == "gather_scatter") *value = e->opt_gather_scatter;
-    else if (k == "dp_shard_min_elems") *value = e->opt_dp_shard_min_elems;
-    else if (k == "dp_bytes_all_reduce") *value = (int32_t)std::min<int64_t>(e->dp.st_all_reduce, INT32_MAX);       // per rank, last step
-    else if (k == "dp_bytes_reduce_scatter") *value = (int32_t)std::min<int64_t>(e->dp.st_reduce_scatter, INT32_MAX);
-    else if (k == "dp_bytes_all_gather") *value = (int32_t)std::min<int64_t>(e->dp.st_all_gather, INT32_MAX);
-    else if (k == "dp_collectives") *value = e->dp.st_collectives;
-    else if (k == "dp_one_comm") *value = e->opt_dp_one_comm;
-    else if (k == "prefetch") *value = e->opt_prefetch;
-    else if (k == "join_folds") *value = e->st_join_folds;             // deferred joins that rode on a first-layer product
-    else if (k == "prefetch_hits") *value = e->st_prefetch_hits;       // steps that started from a prefetched batch image
-    else if (k == "prefetch_issued") *value = e->st_prefetch_issued;
-    else if (k == "dp_two_comms") *value = e->dp.on && e->dp.two_comms;   // bucket A's collectives have a communicator of their own
-    else if (k == "two_stream") *value = e->opt_two_stream;
-    else if (k == "side_low_prio") *value = e->opt_side_low_prio;
-    else if (k == "nt_regstage") *value = e->opt_nt_regstage;
-    else if (k == "in_on_main") *value = e->opt_in_on_main;
-    else if (k == "sparse_in") *value = e->opt_sparse_in;
-    else if (k == "small_fwd") *value = e->opt_small_fwd;
-    else if (k == "small_bwd") *value = e->opt_small_bwd;
-    else if (k == "big_batch_tiles") *value = e->opt_big_batch_tiles;
-    else if (k == "dw_cfg") *value = e->opt_dw_cfg;
-    else if (k == "splitk") *value = e->cfg.splitk;
-    else if (k == "last_sparse_in") *value = e->last_sparse_in;
-    else if (k == "side_concurrent") *value = e->side_concurrent;   // 1: the step's second stream was seen to run beside the caller's   // 1: the last forward pass ran the first layer as the sparse product
-    else {
-        rtx_set_error("get_option: unknown key '%s'", key);
-        return RTX_EINVAL;
-    }
-    return RTX_OK;
-}
-
-int rtx_multinomial_loss(const float* recon, const float* x, int32_t batch, int32_t n_items, const float* mu, const float* logvar,
-                         int32_t latent, float beta, float* loss_out, void* stream)
-{
-    RTX_CHECK(recon && x && loss_out && batch >= 1 && n_items >= 1, RTX_EINVAL, "multinomial_loss: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    float* row_loss = nullptr;
-    RTX_HIP(hipMallocAsync((void**)&row_loss, sizeof(float) * batch, st));
-    int rc = rtx_launch_dense_loss(recon, x, batch, n_items, (mu && logvar) ? mu : nullptr, logvar, latent, beta, 1.f / (float)batch,
-                                   row_loss, st);
-    if (!rc) rc = rtx_launch_reduce_loss(row_loss, batch, 0.f, nullptr, 0, loss_out, nullptr, st);
-    (void)hipFreeAsync(row_loss, st);
-    return rc;
-}
-
-int rtx_sum_l2_norms(const float* const* tensors, const int64_t* sizes, int32_t n, float* out, void* stream)
-{
-    RTX_CHECK(tensors && sizes && out && n >= 1 && n <= RTX_MAX_TENSORS, RTX_EINVAL, "sum_l2_norms: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    float* sumsq = nullptr;
-    RTX_HIP(hipMallocAsync((void**)&sumsq, sizeof(float) * n, st));
-    std::vector<long> sz(sizes, sizes + n);
-    int rc = rtx_launch_sumsq(tensors, sz.data(), n, sumsq, st);
-    if (!rc) rc = rtx_launch_reduce_loss(nullptr, 0, 1.f, sumsq, n, out, nullptr, st);
-    (void)hipFreeAsync(sumsq, st);
-    return rc;
-}
-
-int rtx_topk_metrics(const float* scores, int64_t ld, int32_t batch, int32_t n_items, const rtx_csr* heldout,
-                     const int32_t* row_ids, const int32_t* ks_host, int32_t n_k, double* ndcg, double* recall,
-                     int32_t* topk_idx, int32_t kmax, void* stream)
-{
-    RTX_CHECK(scores && heldout && ks_host, RTX_EINVAL, "topk_metrics: NULL argument");
-    RTX_CHECK(heldout->n_cols == n_items, RTX_EINVAL, "topk_metrics: held-out matrix has %d columns, scores have %d", heldout->n_cols, n_items);
-    RTX_CHECK(row_ids || batch <= heldout->n_rows, RTX_EINVAL, "topk_metrics: batch larger than the held-out matrix");
-    int km = kmax;
-    for (int q = 0; q < n_k; ++q) km = std::max(km, (int)ks_host[q]);
-    RtxCsrView v = {heldout->indptr, heldout->indices, heldout->values, row_ids};
-    return rtx_launch_topk_metrics(scores, (long)ld, batch, n_items, v, ks_host, n_k, km, ndcg, recall, topk_idx, (hipStream_t)stream);
-}
-
 // The body of evaluation.evaluate's loop (rectorch/evaluation.py:100-106) for EVERY batch of a held-out loader in one call: the host
 // enqueues batch after batch without returning to Python in between (round 6: the selection kernel's 20 us left the host's ~100 us of
 // per-batch Python and ctypes work as the limit of evaluate_device).
@@ -2387,70 +1818,6 @@ int rtx_engine_evaluate_topk(rtx_engine* e, const rtx_csr* train, const rtx_csr*
         RTX_TRY(rtx_launch_topk_metrics(scores_scratch, (long)e->I, (int)n, e->I, hv, ks_host, n_k, km, ndcg ? ndcg + col : nullptr,
                                         recall ? recall + col : nullptr, nullptr, st, (long)total, &in));
     }
-    return RTX_OK;
-}
-
-// ---- instrumentation -------------------------------------------------------------------------------
-int rtx_engine_set_timing(rtx_engine* e, const char* site, int32_t enable)
-{
-    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
-    if (!site) {
-        e->timing_all = enable != 0;
-        if (!enable) e->timing_sites.clear();
-    } else if (enable) {
-        e->timing_sites[site] = enable;
-        e->timing_seen[site] = 0;
-    } else {
-        e->timing_sites.erase(site);
-    }
-    return RTX_OK;
-}
-
-int rtx_engine_get_timings(rtx_engine* e, int32_t cap, char (*names)[48], float* total_ms, int32_t* launches, int32_t* n_out)
-{
-    RTX_CHECK(e && n_out, RTX_EINVAL, "get_timings: NULL argument");
-    RTX_HIP(hipDeviceSynchronize());
-    int n = 0;
-    for (auto& kv : e->sites) {
-        TimingSite& s = kv.second;
-        for (auto& pr : s.pending) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                s.total_ms += ms;
-                s.launches += 1;
-            }
-            e->event_pool.push_back(pr.first);
-            e->event_pool.push_back(pr.second);
-        }
-        s.pending.clear();
-        if (n < cap && names && total_ms && launches) {
-            strncpy(names[n], kv.first.c_str(), 47);
-            names[n][47] = 0;
-            total_ms[n] = (float)s.total_ms;
-            launches[n] = s.launches;
-            ++n;
-        }
-        s.total_ms = 0;
-        s.launches = 0;
-    }
-    *n_out = n;
-    return RTX_OK;
-}
-
-int rtx_engine_step_cost(const rtx_engine* e, int32_t batch, double* hbm_bytes, double* flops)
-{
-    RTX_CHECK(e, RTX_EINVAL, "engine is NULL");
-    // bytes = 38*P + 12*B*I  (fp32 master params + Adam state, logits written once and read twice)
-    //               flops = forward 2*sum(in*out) + weight grads 2*sum(in*out) + data grads 2*sum_{l>0}(in*out), per user
-    double P = 0, f_all = 0, f_rest = 0;
-    for (int li = 0; li < e->NL; ++li) {
-        const double w = (double)e->L[li].in * e->L[li].out;
-        P += w + e->L[li].out;
-        f_all += w;
-        if (li > 0) f_rest += w;
-    }
-    if (hbm_bytes) *hbm_bytes = 38.0 * P + 12.0 * (double)batch * e->I;
-    if (flops) *flops = (double)batch * 2.0 * (2.0 * f_all + f_rest);
     return RTX_OK;
 }
 

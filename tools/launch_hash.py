@@ -4,8 +4,8 @@ into the counter summary, bench.py compares it before citing that summary as ``r
 import hashlib
 import os
 
-LAUNCH_SOURCES = ("rectorch_amd/csrc/dw_adam.hip", "rectorch_amd/csrc/engine.hip", "rectorch_amd/csrc/rtx_kernels.h",
-                  "rectorch_amd/csrc/rtx_gemm.h", "rectorch_amd/csrc/rtx_common.h")
+LAUNCH_SOURCES = ("rectorch_amd/csrc/dw_adam.hip", "rectorch_amd/csrc/engine.hip", "rectorch_amd/csrc/engine_internal.h", "rectorch_amd/csrc/engine_api.hip",
+                  "rectorch_amd/csrc/rtx_kernels.h", "rectorch_amd/csrc/rtx_gemm.h", "rectorch_amd/csrc/rtx_common.h")   # (engine_api.hip: the options that pick tiles and streams)
 
 
 def launch_sources_sha(root):
