@@ -1737,6 +1737,7 @@ int rtx_launch_topk_metrics(const float* scores, long ld, int B, int n_items, co
             std::vector<double> t(RTX_TOPK_MAX);
             for (int r = 0; r < RTX_TOPK_MAX; ++r) t[r] = std::log2((double)(r + 2));
             RTX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_topk_log2), t.data(), sizeof(double) * RTX_TOPK_MAX));
+            RTX_HIP(hipStreamSynchronize(nullptr));   // (the copy runs on the NULL stream, which a non-blocking caller's stream does not wait for: engine.hip dev_alloc has the story)
             table_ready[devid] = true;
         }
         RTX_CHECK(devid >= 0 && devid < 64, RTX_EINVAL, "topk_metrics: device index %d", devid);
