@@ -522,7 +522,7 @@ template <int WM, int WN, int NS, int EPI, bool AL = true, int TNC = 128, int KS
     return RTX_OK;
 }
 
-int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : (cfg == RTX_DW_128x128 || cfg == RTX_DW_128x128_W4) ? 128 : 32; }
+int rtx_dw_tile_rows(int cfg) { return cfg == RTX_DW_64x128 ? 64 : (cfg == RTX_DW_128x128 || cfg == RTX_DW_128x128_W4 || cfg == RTX_DW_128x128_K32) ? 128 : 32; }
 int rtx_dw_tile_cols(int cfg) { return (cfg >= RTX_DW_32x256 && cfg <= RTX_DW_32x256_K32) ? 256 : 128; }
 
 template <int EPI, bool AL = true> static int dw_launch_cfg(const RtxDw& d, int cfg, hipStream_t stream)
@@ -536,6 +536,7 @@ template <int EPI, bool AL = true> static int dw_launch_cfg(const RtxDw& d, int 
     case RTX_DW_32x256: return dw_launch<1, 8, 2, EPI, AL, 256>(d, stream);     // 8 waves (32 x 32 each), 2 stages (72 KB): 2 workgroups per CU
     case RTX_DW_32x256_S3: return dw_launch<1, 8, 3, EPI, AL, 256>(d, stream);  // 3 stages (108 KB): 1 workgroup per CU
     case RTX_DW_32x256_K32: return dw_launch<1, 8, 4, EPI, AL, 256, 32>(d, stream);  // 32-row slices, 4 stages (72 KB): 2 workgroups per CU, three slices ahead
+    case RTX_DW_128x128_K32: return dw_launch<4, 2, 4, EPI, AL, 128, 32>(d, stream); // half the operand bytes per parameter of 64 x 128, four 16-KB stages (64 KB): 2 workgroups per CU
     default: return dw_launch<2, 4, 3, EPI, AL>(d, stream);                 // 8 waves, 3 stages (72 KB): 2 workgroups per CU
     }
 }
@@ -546,7 +547,7 @@ int rtx_dw_launch(const RtxDw& d, int epilogue, int cfg, hipStream_t stream)
     RTX_CHECK(d.A && d.B && d.m_tiles > 0 && d.n_tiles > 0 && d.k_slices >= 2, RTX_EINVAL, "dw: bad problem (%d x %d tiles, %d K slices)", d.m_tiles, d.n_tiles,
               d.k_slices);
     RTX_CHECK(epilogue == RTX_DW_GRAD || epilogue == RTX_DW_ADAM, RTX_EINVAL, "dw: bad epilogue %d", epilogue);
-    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_32x256_K32, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128_K32, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     RTX_CHECK(d.M_real >= 1 && d.N_real >= 1, RTX_EINVAL, "dw: empty tensor");
     if (epilogue == RTX_DW_ADAM) {
         RTX_CHECK(d.N_real >= 4, RTX_EINVAL, "dw: the fused Adam epilogue needs rows of at least 4 floats (got %d)", d.N_real);
@@ -572,6 +573,7 @@ template <int EPI, bool AL = true> static int dw_launch_group_cfg(const RtxDw* d
     case RTX_DW_32x256: return dw_launch_group<1, 8, 2, EPI, AL, 256>(d, n, stream);
     case RTX_DW_32x256_S3: return dw_launch_group<1, 8, 3, EPI, AL, 256>(d, n, stream);
     case RTX_DW_32x256_K32: return dw_launch_group<1, 8, 4, EPI, AL, 256, 32>(d, n, stream);
+    case RTX_DW_128x128_K32: return dw_launch_group<4, 2, 4, EPI, AL, 128, 32>(d, n, stream);
     default: return dw_launch_group<2, 4, 3, EPI, AL>(d, n, stream);
     }
 }
@@ -581,7 +583,7 @@ int rtx_dw_launch_group(const RtxDw* d, int n, int epilogue, int cfg, hipStream_
     RTX_CHECK(d && n >= 1 && n <= RTX_DW_GROUP_MAX, RTX_EINVAL, "dw group: 1..%d problems (got %d)", RTX_DW_GROUP_MAX, n);
     if (n == 1) return rtx_dw_launch(d[0], epilogue, cfg, stream);
     RTX_CHECK(epilogue == RTX_DW_ADAM || epilogue == RTX_DW_GRAD, RTX_EINVAL, "dw group: bad epilogue %d", epilogue);
-    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_32x256_K32, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
+    RTX_CHECK(cfg >= RTX_DW_64x128 && cfg <= RTX_DW_128x128_K32, RTX_EINVAL, "dw: bad tile configuration %d", cfg);
     bool any_unaligned = false;   // one matrix with rows of N_real % 4 != 0 floats: the whole launch takes the unaligned epilogue
     for (int k = 0; k < n; ++k) {
         const RtxDw& q = d[k];

@@ -50,7 +50,7 @@ int rtx_engine_set_option(rtx_engine* e, const char* key, int32_t value)
     else if (k == "small_bwd") e->opt_small_bwd = value != 0;
     else if (k == "big_batch_tiles") e->opt_big_batch_tiles = value != 0;
     else if (k == "dw_cfg") {
-        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_32x256_K32, RTX_EINVAL, "set_option: dw_cfg must be 0..7");
+        RTX_CHECK(value >= RTX_DW_64x128 && value <= RTX_DW_128x128_K32, RTX_EINVAL, "set_option: dw_cfg must be 0..8");
         e->opt_dw_cfg = value;
         e->opt_dw_cfg_set = 1;
     } else if (k == "splitk") {

@@ -119,7 +119,8 @@ enum RtxDwCfg { RTX_DW_64x128 = 0, RTX_DW_32x128 = 1, RTX_DW_32x128_S2 = 2, RTX_
                                            //   1 per 2): the long-K tile (a batch of thousands of rows: configs[3] on one GPU)
                 RTX_DW_32x256 = 5,         // round 6: 32 x 256 on eight waves, two stages (72 KB): a tile row of the optimizer state is 1 KB
                 RTX_DW_32x256_S3 = 6,      //   the same with three stages (108 KB: one workgroup per CU)
-                RTX_DW_32x256_K32 = 7 };   //   32-row K slices, four stages (72 KB): two workgroups per CU, three slices ahead
+                RTX_DW_32x256_K32 = 7,     //   32-row K slices, four stages (72 KB): two workgroups per CU, three slices ahead
+                RTX_DW_128x128_K32 = 8 };  // round 6: 128 x 128 on eight waves, 32-row slices, four stages (64 KB, two workgroups per CU): half the operand bytes of 64 x 128 through a CU's memory queue
 struct RtxDw {
     const void* A;       // delta      bf16 [K_pad][lda]: k = batch row, m = output feature (contiguous)
     const void* B;       // activation bf16 [K_pad][ldb]: n = input feature (contiguous); column N_real holds ones

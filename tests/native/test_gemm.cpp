@@ -699,7 +699,7 @@ static int run_f32_case(const char* name, int form, int M, int N, int K, int spl
 static int run_dw_cases()
 {
     int fails = 0;
-    for (int cfg = 0; cfg < 8; ++cfg) {   // (5, 6, 7: 32x256 on two / three stages, on four stages of 32-row slices)   64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / 128x128 on four waves
+    for (int cfg = 0; cfg < 9; ++cfg) {   // (5, 6, 7: 32x256 on two / three stages, on four stages of 32-row slices; 8: 128x128 on four stages of 32-row slices)   64x128 / 32x128 (3 stages) / 32x128 (2 stages) / 128x128 (2 stages, 32x64 per wave) / 128x128 on four waves
         fails += run_dw_case("adam", cfg, RTX_DW_ADAM, 300, 200, 250, 0.f, 0.f, 1);
         fails += run_dw_case("adam-nokeep", cfg, RTX_DW_ADAM, 130, 600, 500, 0.f, 0.f, 0);
         fails += run_dw_case("adam-dae", cfg, RTX_DW_ADAM, 70, 132, 100, 0.2f, 0.001f, 1);
@@ -1150,7 +1150,7 @@ int main(int argc, char** argv)
     }
     if (argc > 1 && !strcmp(argv[1], "dwperf")) {   // the two n_items x 600 launches of the step, warm and cold
         for (int rep = 0; rep < 3; ++rep)
-            for (int cfg : {0, 5, 7}) {   // 64 x 128; 32 x 256 on two / three stages (round 6)
+            for (int cfg : {0, 3, 8}) {   // 64 x 128; 32 x 256 on two / three stages (round 6)
                 perf_dw("dW4+adam", cfg, RTX_DW_ADAM, 20108, 600, 500, 3);
                 perf_dw("dW1+adam", cfg, RTX_DW_ADAM, 600, 20108, 500, 3);
             }
