@@ -1,3 +1,5 @@
+"""Where evaluate_device()'s wall time goes on the host side (round 6): the sampler's row batches, the engine look-up, ONE rtx_engine_evaluate_topk
+call (when it returns vs when the GPU is done), the device -> host copy -- against the whole call.   python tools/eval_host_probe.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
