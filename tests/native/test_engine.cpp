@@ -268,6 +268,40 @@ static void parity_case(const char* name, Net net, int numerics, int B, int n_us
             if (inf != (x[k] != 0.f)) ++bad;
         }
         check("predict -inf mask", (double)bad, 0.0);
+        // ---- rtx_engine_evaluate_topk (ABI 8): the loop of evaluation.evaluate in one call -- two batches of the same users, nDCG@k / Recall@k
+        //      against the held-out matrix, compared with the reference's formulas (rectorch/metrics.py:136-147, 187-196) evaluated on
+        //      the host from the scores rtx_engine_forward(remove_train = 1) has just returned (same bits: the ranking cannot differ)
+        if (!dense_api && B >= 4) {
+            const int ks[2] = {5, 20};
+            const int64_t offs[3] = {0, B / 2, B};
+            float* d_scratch; double *d_nd, *d_rc;
+            CK(hipMalloc(&d_scratch, (size_t)(B + 3) * I * 4)); CK(hipMalloc(&d_nd, 2 * B * 8)); CK(hipMalloc(&d_rc, 2 * B * 8));
+            RT(rtx_engine_evaluate_topk(eng, ctr, cte, d_ids, offs, 2, ks, 2, d_scratch, d_nd, d_rc, nullptr));
+            CK(hipDeviceSynchronize());
+            std::vector<double> nd(2 * B), rc(2 * B);
+            CK(hipMemcpy(nd.data(), d_nd, 2 * B * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(rc.data(), d_rc, 2 * B * 8, hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (int q = 0; q < 2; ++q)
+                for (int b = 0; b < B; ++b) {
+                    const int k = std::min(ks[q], I);
+                    std::vector<int> order(I);
+                    for (int i = 0; i < I; ++i) order[i] = i;
+                    const float* sc = pr.data() + (size_t)b * I;
+                    std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return sc[u] > sc[v]; });   // score descending, index ascending among ties
+                    const float* held = gt.data() + (size_t)b * I;
+                    double dcg = 0, hits = 0, n = 0, npos = 0;
+                    for (int i = 0; i < I; ++i) { n += held[i]; npos += held[i] > 0.f; }
+                    for (int r = 0; r < k; ++r) { dcg += held[order[r]] / log2((double)r + 2.0); hits += held[order[r]] > 0.f; }
+                    double idcg = 0;
+                    for (int r = 0; r < std::min((int)n, k); ++r) idcg += 1.0 / log2((double)r + 2.0);
+                    const double want_n = dcg / idcg, want_r = hits / std::min((double)k, npos);
+                    const double got_n = nd[(size_t)q * B + b], got_r = rc[(size_t)q * B + b];
+                    auto diff = [](double a, double c) { return (std::isnan(a) && std::isnan(c)) ? 0.0 : (std::isnan(a) != std::isnan(c)) ? 1.0 : fabs(a - c) / std::max(1e-300, fabs(c)); };
+                    worst = std::max(worst, std::max(diff(got_n, want_n), diff(got_r, want_r)));
+                }
+            check("evaluate_topk ndcg / recall vs host formulas", worst, 1e-12);
+            hipFree(d_scratch); hipFree(d_nd); hipFree(d_rc);
+        }
     }
 
     // ---- two training steps with injected RNG
